@@ -1,0 +1,567 @@
+"""CPU oracle for the PARADIS advection-diffusion-reaction hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``paradis_model_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker / timed CPU baseline.
+
+This is an independent, functional (state-dict driven) restatement in plain
+PyTorch CPU ops of what the reference computes on its hot path:
+
+* geocyclic halo index map ........ reference ``model/padding.py:11-39``
+* semi-Lagrangian advection ....... reference ``model/advection.py:74-175``
+* CLinear / SepConv / ChannelNorm / GlobalBias / GMBlock / PhysicalDownsample
+                                    reference ``model/blocks.py:57-304``
+* layer step, up-sampling, forward  reference ``model/paradis.py:208-269``
+* ParadisLoss ...................... reference ``utils/loss.py:129-282``
+
+Third-party arithmetic (ATen ``grid_sampler_2d``, ``conv2d``, ``avg_pool2d``,
+``upsample_bilinear2d``) is *not* in the reference tree; the oracle restates the
+published semantics (bicubic Keys kernel A=-0.75, align_corners=True, zero
+padding outside the padded plane) with explicit taps and additionally offers the
+ATen call as a cross-check (``interp_impl="aten"``).
+
+Pinning: the reference ships no tests or golden vectors,
+so the oracle is pinned by fixtures generated *here* by importing the reference
+read-only (``tests/golden/make_golden.py`` -> ``tests/golden/*.pt``) and checked
+in ``tests/test_oracle_golden.py``.
+
+All functions accept fp32 or fp64 CPU tensors (fp64 is used for the tolerance
+protocol of SURVEY.md section 8c).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+EARTH_OMEGA = 7.29212e-5  # reference model/paradis.py:13-14
+KEYS_A = -0.75            # ATen GridSampler.h bicubic constant
+RANK_GLOBAL_BIAS = 128    # reference model/blocks.py:164
+
+
+# ---------------------------------------------------------------------------
+# a1  geocyclic halo  (reference model/padding.py:11-39)
+# ---------------------------------------------------------------------------
+def geocyclic_source_index(H: int, W: int, p: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Integer source (row, col) of every cell of the (H+2p, W+2p) padded plane.
+
+    Rows beyond a pole are the mirror image about the pole row (which is never
+    duplicated) seen from the opposite meridian (shift W/2); longitude wraps.
+    Pure integer arithmetic, hence bit-exact.
+    """
+    if W % 2 != 0:
+        raise AssertionError("Number of longitude points must be even")
+    if p > H - 2:
+        raise AssertionError("pad width must be <= H-2")
+    ii = np.arange(-p, H + p, dtype=np.int64)[:, None]
+    jj = np.mod(np.arange(-p, W + p, dtype=np.int64), W)[None, :]
+    south = ii < 0
+    north = ii >= H
+    row = np.where(south, -ii, np.where(north, 2 * (H - 1) - ii, ii))
+    col = np.where(south | north, np.mod(jj + W // 2, W), jj)
+    row = np.broadcast_to(row, (H + 2 * p, W + 2 * p)).copy()
+    col = np.broadcast_to(col, (H + 2 * p, W + 2 * p)).copy()
+    return row, col
+
+
+def geocyclic_pad(x: Tensor, p: int) -> Tensor:
+    """[B,C,H,W] -> [B,C,H+2p,W+2p] by gathering through the index map."""
+    if p == 0:
+        return x
+    assert x.dim() == 4, "Input must be 4-dimensional [batch, channels, lat, lon]"
+    H, W = x.shape[-2:]
+    row, col = geocyclic_source_index(H, W, p)
+    flat = torch.from_numpy(row * W + col).reshape(-1)
+    out = x.reshape(*x.shape[:2], H * W).index_select(2, flat)
+    return out.reshape(*x.shape[:2], H + 2 * p, W + 2 * p)
+
+
+# ---------------------------------------------------------------------------
+# a3-a5  semi-Lagrangian advection core  (reference model/advection.py:74-169)
+# ---------------------------------------------------------------------------
+@dataclass
+class GridGeometry:
+    """Scalars the reference keeps as buffers (model/advection.py:58-72)."""
+    lat: Tensor  # [H, W] radians
+    lon: Tensor  # [H, W] radians
+    H: int = 0
+    W: int = 0
+    min_lat: Tensor = None
+    min_lon: Tensor = None
+    d_lat: Tensor = None
+    d_lon: Tensor = None
+
+    def __post_init__(self):
+        self.H, self.W = self.lat.shape
+        self.min_lat = self.lat.min()
+        self.min_lon = self.lon.min()
+        self.d_lat = self.lat.max() - self.min_lat
+        self.d_lon = self.lon.max() - self.min_lon
+
+    def to(self, dtype):
+        return GridGeometry(self.lat.to(dtype), self.lon.to(dtype))
+
+
+def pole_mean(x: Tensor) -> Tensor:
+    """Rows 0 and H-1 replaced by their longitudinal mean (advection.py:100-114)."""
+    y = x.clone()
+    y[..., 0, :] = x[..., 0, :].mean(dim=-1, keepdim=True)
+    y[..., -1, :] = x[..., -1, :].mean(dim=-1, keepdim=True)
+    return y
+
+
+def departure_sample_coords(u: Tensor, v: Tensor, dt: float, geo: GridGeometry,
+                            p: int) -> Tuple[Tensor, Tensor]:
+    """Padded-plane sample coordinates (ix, iy) of every arrival point.
+
+    Follows the reference's floating-point operation order, including the
+    normalise (advection.py:149-150) / un-normalise (ATen align_corners=True,
+    ``((g+1)/2)*(size-1)``) round trip.
+    """
+    H, W = geo.H, geo.W
+    lat_a = geo.lat.reshape(1, 1, H, W)
+    lon_a = geo.lon.reshape(1, 1, H, W)
+    lam = -u * dt
+    phi = -v * dt
+    s_phi, c_phi = torch.sin(phi), torch.cos(phi)
+    s_lam, c_lam = torch.sin(lam), torch.cos(lam)
+    s_a, c_a = torch.sin(lat_a), torch.cos(lat_a)
+
+    sin_lat = s_phi * c_a + c_phi * c_lam * s_a
+    lat_d = torch.arcsin(torch.clamp(sin_lat, -1 + 1e-7, 1 - 1e-7))
+    num = c_phi * s_lam
+    den = c_phi * c_lam * c_a - s_phi * s_a
+    lon_d = lon_a + torch.atan2(num, den)
+    lon_d = torch.remainder(lon_d + 2 * math.pi, 2 * math.pi)
+
+    pix_x = (lon_d - geo.min_lon) / geo.d_lon * (float(W) - 1.0)
+    pix_y = (lat_d - geo.min_lat) / geo.d_lat * (float(H) - 1.0)
+    Hp, Wp = H + 2 * p, W + 2 * p
+    gx = 2.0 * ((pix_x + p) / float(Wp - 1)) - 1.0
+    gy = 2.0 * ((pix_y + p) / float(Hp - 1)) - 1.0
+    ix = ((gx + 1) / 2) * (Wp - 1)
+    iy = ((gy + 1) / 2) * (Hp - 1)
+    return ix, iy
+
+
+def _cubic_weights(t: Tensor) -> List[Tensor]:
+    A = KEYS_A
+
+    def c1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def c2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+
+    return [c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t)]
+
+
+def interp_virtual(field: Tensor, ix: Tensor, iy: Tensor, p: int, mode: str) -> Tensor:
+    """Explicit-tap interpolation on the *virtual* padded plane.
+
+    field: [N, H, W] (pole rows already averaged); ix, iy: [N, H, W] padded
+    coordinates.  Taps outside the padded plane contribute zero.
+    """
+    N, H, W = field.shape
+    Hp, Wp = H + 2 * p, W + 2 * p
+    row_map, col_map = geocyclic_source_index(H, W, p)
+    flat_map = torch.from_numpy(row_map * W + col_map).reshape(-1)
+    x0 = torch.floor(ix)
+    y0 = torch.floor(iy)
+    tx = ix - x0
+    ty = iy - y0
+    x0 = x0.long()
+    y0 = y0.long()
+    if mode == "bicubic":
+        wx, wy, offs = _cubic_weights(tx), _cubic_weights(ty), (-1, 0, 1, 2)
+    elif mode == "bilinear":
+        wx, wy, offs = [1.0 - tx, tx], [1.0 - ty, ty], (0, 1)
+    else:
+        raise ValueError(mode)
+    flat_field = field.reshape(N, H * W)
+    out = torch.zeros_like(ix)
+    for a, oa in enumerate(offs):
+        r = y0 + oa
+        for b, ob in enumerate(offs):
+            c = x0 + ob
+            inside = (r >= 0) & (r < Hp) & (c >= 0) & (c < Wp)
+            lin = (r.clamp(0, Hp - 1) * Wp + c.clamp(0, Wp - 1)).reshape(N, -1)
+            src = flat_map[lin.reshape(-1)].reshape(N, -1)
+            val = torch.gather(flat_field, 1, src).reshape(N, H, W)
+            out = out + torch.where(inside, val, torch.zeros_like(val)) * wx[b] * wy[a]
+    return out
+
+
+def sl_advect_core(field: Tensor, u: Tensor, v: Tensor, dt: float, geo: GridGeometry,
+                   mode: str = "bicubic", interp_impl: str = "taps") -> Tensor:
+    """Fused-operator view of advection.py:129-169 without the two projections.
+
+    field, u, v: [B, K, H, W] -> [B, K, H, W].
+    """
+    B, K, H, W = field.shape
+    p = 2 if mode == "bicubic" else 1
+    ft = pole_mean(field)
+    ix, iy = departure_sample_coords(u, v, dt, geo, p)
+    if interp_impl == "taps":
+        out = interp_virtual(ft.reshape(B * K, H, W), ix.reshape(B * K, H, W),
+                             iy.reshape(B * K, H, W), p, mode).reshape(B, K, H, W)
+    elif interp_impl == "aten":
+        Hp, Wp = H + 2 * p, W + 2 * p
+        padded = geocyclic_pad(ft, p).reshape(B * K, 1, Hp, Wp)
+        gx = (ix / (Wp - 1)) * 2 - 1
+        gy = (iy / (Hp - 1)) * 2 - 1
+        # NOTE: re-normalising ix is not bit-identical to the reference's own gx;
+        # for golden comparisons use interp_impl="taps" or the helper below.
+        grid = torch.stack([gx, gy], dim=-1).reshape(B * K, H, W, 2)
+        out = F.grid_sample(padded, grid, mode=mode, padding_mode="zeros",
+                            align_corners=True).reshape(B, K, H, W)
+    else:
+        raise ValueError(interp_impl)
+    return pole_mean(out)
+
+
+def sl_advect_core_aten(field: Tensor, u: Tensor, v: Tensor, dt: float, geo: GridGeometry,
+                        mode: str = "bicubic") -> Tensor:
+    """Same operator through ATen ``grid_sample`` with the reference's own
+    normalised grid (used for the timed CPU baseline: same kernels as the
+    reference executes)."""
+    B, K, H, W = field.shape
+    p = 2 if mode == "bicubic" else 1
+    Hp, Wp = H + 2 * p, W + 2 * p
+    lat_a = geo.lat.reshape(1, 1, H, W)
+    lon_a = geo.lon.reshape(1, 1, H, W)
+    ft = pole_mean(field)
+    lam, phi = -u * dt, -v * dt
+    s_phi, c_phi, s_lam, c_lam = torch.sin(phi), torch.cos(phi), torch.sin(lam), torch.cos(lam)
+    s_a, c_a = torch.sin(lat_a), torch.cos(lat_a)
+    lat_d = torch.arcsin(torch.clamp(s_phi * c_a + c_phi * c_lam * s_a, -1 + 1e-7, 1 - 1e-7))
+    lon_d = lon_a + torch.atan2(c_phi * s_lam, c_phi * c_lam * c_a - s_phi * s_a)
+    lon_d = torch.remainder(lon_d + 2 * math.pi, 2 * math.pi)
+    pix_x = (lon_d - geo.min_lon) / geo.d_lon * (float(W) - 1.0)
+    pix_y = (lat_d - geo.min_lat) / geo.d_lat * (float(H) - 1.0)
+    gx = 2.0 * ((pix_x + p) / float(Wp - 1)) - 1.0
+    gy = 2.0 * ((pix_y + p) / float(Hp - 1)) - 1.0
+    grid = torch.stack([gx.reshape(B * K, H, W), gy.reshape(B * K, H, W)], dim=-1)
+    padded = geocyclic_pad(ft, p).reshape(B * K, 1, Hp, Wp)
+    out = F.grid_sample(padded, grid, mode=mode, padding_mode="zeros", align_corners=True)
+    return pole_mean(out.reshape(B, K, H, W))
+
+
+# ---------------------------------------------------------------------------
+# a6-a11  blocks  (reference model/blocks.py)
+# ---------------------------------------------------------------------------
+def pointwise(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """1x1 channel mixing, weight [Co,Ci,1,1] (blocks.py:74-89)."""
+    return F.conv2d(x, weight, bias)
+
+
+def depthwise_geo(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """Per-channel k x k stencil on the geocyclic-padded plane (blocks.py:101-113)."""
+    k = weight.shape[-1]
+    return F.conv2d(geocyclic_pad(x, (k - 1) // 2), weight, bias, groups=x.shape[1])
+
+
+def channel_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:
+    """Per-pixel normalisation over channels, unbiased variance (blocks.py:118-134)."""
+    C = x.shape[-3]
+    mean = x.mean(dim=-3, keepdim=True)
+    var = ((x - mean) ** 2).sum(dim=-3, keepdim=True) / (C - 1)
+    y = (x - mean) * (var + eps) ** -0.5
+    return y * weight.reshape(-1, 1, 1) + bias.reshape(-1, 1, 1)
+
+
+def global_bias_map(A: Tensor, U: Tensor, V: Tensor, proj: Optional[Tensor]) -> Tensor:
+    """Rank-128 separable bias map [Co,H,W] (blocks.py:188-196)."""
+    m = torch.einsum("ck,kh,kw->chw", A, U, V)
+    if proj is not None:
+        m = torch.einsum("oc,chw->ohw", proj, m)
+    return m
+
+
+def avgpool_geo(x: Tensor, stride: int) -> Tensor:
+    """Geocyclic 5x5 box filter with decimation (blocks.py:57-71)."""
+    return F.avg_pool2d(geocyclic_pad(x, 2), kernel_size=5, stride=stride,
+                        count_include_pad=False)
+
+
+def upsample_lon_periodic(x: Tensor, nlat: int, nlon: int) -> Tensor:
+    """Bilinear, align_corners=True, longitude closed periodically (paradis.py:208-220)."""
+    ext = torch.cat([x, x[..., :1]], dim=-1)
+    y = F.interpolate(ext, size=(nlat, nlon + 1), mode="bilinear", align_corners=True)
+    return y[..., :-1]
+
+
+def activation(x: Tensor, name: str) -> Tensor:
+    if name == "SiLU":
+        return F.silu(x)
+    if name == "GELU":
+        return F.gelu(x)
+    raise ValueError(f"Unknown activation_fn '{name}'. Allowed: ['SiLU', 'GELU']")
+
+
+# ---------------------------------------------------------------------------
+# a10  GMBlock plan  (reference model/blocks.py:210-304)
+# ---------------------------------------------------------------------------
+@dataclass
+class BlockPlan:
+    """Flattened description of one GMBlock: ordered (kind, child_name, meta)."""
+    steps: List[Tuple[str, str, dict]] = field(default_factory=list)
+
+
+def plan_gmblock(layers: Sequence[str], input_dim: int, output_dim: int, *,
+                 kernel_size: int = 5, hidden_dim=0, act: str = "SiLU",
+                 bias_channels: int = 0, activation_last: bool = False,
+                 pre_normalize: bool = False) -> BlockPlan:
+    n = len(layers)
+    if n == 0:
+        raise ValueError("GMBlock: must specify at least one layer")
+    acts = (True,) * (n - 1) + (activation_last,)
+    if isinstance(hidden_dim, (list, tuple)):
+        assert len(hidden_dim) == n - 1
+        hid = tuple(hidden_dim)
+    else:
+        if hidden_dim <= 0:
+            hidden_dim = max(input_dim, output_dim)
+        hid = (hidden_dim,) * (n - 1)
+    plan = BlockPlan()
+    if pre_normalize:
+        plan.steps.append(("ChannelNorm", "0-ChannelNorm", {"dim": input_dim}))
+    cin = input_dim
+    for idx, kind in enumerate(layers):
+        cout = output_dim if idx == n - 1 else hid[idx]
+        if kind not in ("SepConv", "CLinear", "ChannelNorm", "GlobalBias"):
+            raise ValueError(f"Unknown layer type: {kind}")
+        plan.steps.append((kind, f"{idx}-{kind}", {"cin": cin, "cout": cout, "k": kernel_size}))
+        if idx == 0 and bias_channels > 0:
+            plan.steps.append(("GlobalBias", "0-GlobalBias",
+                               {"cin": bias_channels, "cout": cout}))
+        if acts[idx]:
+            plan.steps.append(("Act", f"{idx}-{act}", {"name": act}))
+        cin = cout
+    return plan
+
+
+def run_block(params: Dict[str, Tensor], prefix: str, plan: BlockPlan, x: Tensor) -> Tensor:
+    for kind, name, meta in plan.steps:
+        key = f"{prefix}.{name}"
+        if kind == "ChannelNorm":
+            x = channel_norm(x, params[key + ".weight"], params[key + ".bias"])
+        elif kind == "CLinear":
+            x = pointwise(x, params[key + ".conv.weight"], params.get(key + ".conv.bias"))
+        elif kind == "SepConv":
+            x = depthwise_geo(x, params[key + ".depthwise.weight"])
+            x = pointwise(x, params[key + ".pointwise.weight"], params.get(key + ".pointwise.bias"))
+        elif kind == "GlobalBias":
+            x = x + global_bias_map(params[key + ".A"], params[key + ".U"], params[key + ".V"],
+                                    params.get(key + ".projection.weight")).unsqueeze(0)
+        elif kind == "Act":
+            x = activation(x, meta["name"])
+        else:  # pragma: no cover
+            raise ValueError(kind)
+    return x
+
+
+# ---------------------------------------------------------------------------
+# a12-a15  model  (reference model/paradis.py)
+# ---------------------------------------------------------------------------
+@dataclass
+class ModelSpec:
+    nlat: int
+    nlon: int
+    latent: int
+    num_vels: int
+    num_layers: int
+    interp: str
+    act: str
+    bias_channels: int
+    stride: int
+    dt: float
+    n_static: int
+    in_dim: int
+    out_dim: int
+    plans: Dict[str, BlockPlan]
+    static_dim: int = 128
+
+    @property
+    def coarse(self) -> Tuple[int, int]:
+        return ((self.nlat - 1) // self.stride + 1, self.nlon // self.stride)
+
+
+def _g(cfg, path, default=None):
+    cur = cfg
+    for part in path.split("."):
+        if isinstance(cur, dict):
+            if part not in cur:
+                return default
+            cur = cur[part]
+        else:
+            if not hasattr(cur, part):
+                return default
+            cur = getattr(cur, part)
+    return cur
+
+
+def spec_from_cfg(cfg, nlat: int, nlon: int, num_in_dyn: int, num_in_static: int,
+                  num_out: int) -> ModelSpec:
+    """Reads exactly the cfg keys the reference reads (model/paradis.py:34-193)."""
+    latent = _g(cfg, "model.latent_size")
+    K = _g(cfg, "model.velocity_vectors")
+    L = max(1, _g(cfg, "model.num_layers"))
+    act = _g(cfg, "model.activation")
+    bc = _g(cfg, "model.bias_channels", 4)
+    stride = _g(cfg, "model.coarsening_factor", 1)
+    if stride < 1:
+        raise ValueError("Coarsening factor must be >=1")
+    pb = "model.physblock."
+    plans = {
+        "input_proj": plan_gmblock(_g(cfg, pb + "input_proj.layers"), num_in_dyn + num_in_static,
+                                   latent, hidden_dim=_g(cfg, pb + "input_proj.hidden_dim"),
+                                   act=act, activation_last=True),
+        "velocity": plan_gmblock(_g(cfg, pb + "velocity_net.layers"), latent, 2 * K,
+                                 hidden_dim=_g(cfg, pb + "velocity_net.hidden_dim"), act=act,
+                                 bias_channels=bc, pre_normalize=True),
+        "adv_down": plan_gmblock(_g(cfg, pb + "advection.down_projection.layers"), latent, K,
+                                 hidden_dim=_g(cfg, pb + "advection.down_projection.hidden_dim")),
+        "adv_up": plan_gmblock(_g(cfg, pb + "advection.up_projection.layers"), K, latent,
+                               hidden_dim=_g(cfg, pb + "advection.up_projection.hidden_dim")),
+        "diffusion": plan_gmblock(_g(cfg, pb + "diffusion.layers"), latent, latent,
+                                  hidden_dim=_g(cfg, pb + "diffusion.hidden_dim"), act=act,
+                                  bias_channels=bc, pre_normalize=True),
+        "reaction": plan_gmblock(_g(cfg, pb + "reaction.layers"), latent + 128, latent,
+                                 hidden_dim=_g(cfg, pb + "reaction.hidden_dim"), act=act,
+                                 bias_channels=bc, pre_normalize=True),
+        "output_proj": plan_gmblock(_g(cfg, pb + "output_proj.layers"), latent, num_out,
+                                    hidden_dim=_g(cfg, pb + "output_proj.hidden_dim"), act=act,
+                                    bias_channels=bc, pre_normalize=True),
+    }
+    return ModelSpec(nlat=nlat, nlon=nlon, latent=latent, num_vels=K, num_layers=L,
+                     interp=_g(cfg, "model.adv_interpolation"), act=act, bias_channels=bc,
+                     stride=stride, dt=_g(cfg, "model.base_dt") * EARTH_OMEGA / L,
+                     n_static=len(_g(cfg, "features.input.constants")),
+                     in_dim=num_in_dyn + num_in_static, out_dim=num_out, plans=plans)
+
+
+def static_encoder(params: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """paradis.py:186-193; always SiLU; the middle depthwise conv carries a bias."""
+    pre = "static_encoder."
+    x = depthwise_geo(x, params[pre + "0.depthwise.weight"])
+    x = pointwise(x, params[pre + "0.pointwise.weight"], params[pre + "0.pointwise.bias"])
+    x = F.silu(x)
+    x = depthwise_geo(x, params[pre + "3.weight"], params[pre + "3.bias"])
+    x = F.silu(x)
+    x = depthwise_geo(x, params[pre + "5.depthwise.weight"])
+    return pointwise(x, params[pre + "5.pointwise.weight"], params[pre + "5.pointwise.bias"])
+
+
+def advection(params, spec: ModelSpec, i: int, hidden: Tensor, u: Tensor, v: Tensor,
+              geo: GridGeometry, interp_impl: str = "taps") -> Tensor:
+    proj = run_block(params, f"advection.{i}.down_projection", spec.plans["adv_down"], hidden)
+    if interp_impl == "aten_ref":
+        adv = sl_advect_core_aten(proj, u, v, spec.dt, geo, spec.interp)
+    else:
+        adv = sl_advect_core(proj, u, v, spec.dt, geo, spec.interp, interp_impl)
+    return run_block(params, f"advection.{i}.up_projection", spec.plans["adv_up"], adv)
+
+
+def layer_step(params, spec: ModelSpec, i: int, hidden: Tensor, hidden_static: Tensor,
+               geo: GridGeometry, interp_impl: str = "taps") -> Tensor:
+    """One ADR update (paradis.py:228-254)."""
+    K = spec.num_vels
+    vel = run_block(params, f"velocity_nets.{i}", spec.plans["velocity"], hidden)
+    u, v = vel[:, :K], vel[:, K:]
+    gate = torch.sigmoid(params["alpha_adv"][i]).to(hidden.dtype).reshape(1, -1, 1, 1)
+    adv = advection(params, spec, i, hidden, u, v, geo, interp_impl)
+    hidden = hidden + gate * (adv - hidden)
+    hidden = hidden + run_block(params, f"diffusion.{i}", spec.plans["diffusion"], hidden)
+    cat = torch.cat([hidden, hidden_static], dim=1)
+    return hidden + run_block(params, f"reaction.{i}", spec.plans["reaction"], cat)
+
+
+def coarse_geometry(lat_grid: Tensor, lon_grid: Tensor, stride: int) -> GridGeometry:
+    return GridGeometry(lat_grid[::stride, ::stride].contiguous(),
+                        lon_grid[::stride, ::stride].contiguous())
+
+
+def paradis_forward(params: Dict[str, Tensor], spec: ModelSpec, fields: Tensor,
+                    lat_grid: Tensor, lon_grid: Tensor, interp_impl: str = "taps") -> Tensor:
+    """fields [B, in_dim, H, W] -> [B, out_dim, H, W]  (paradis.py:256-269)."""
+    geo = coarse_geometry(lat_grid.to(fields.dtype), lon_grid.to(fields.dtype), spec.stride)
+    hidden = run_block(params, "input_proj", spec.plans["input_proj"], fields)
+    hs = static_encoder(params, fields[:, -spec.n_static:])
+    skip = hidden
+    hidden = avgpool_geo(hidden, spec.stride)
+    hs = avgpool_geo(hs, spec.stride)
+    for i in range(spec.num_layers):
+        hidden = layer_step(params, spec, i, hidden, hs, geo, interp_impl)
+    hidden = upsample_lon_periodic(hidden, spec.nlat, spec.nlon) + skip
+    return run_block(params, "output_proj", spec.plans["output_proj"], hidden)
+
+
+# ---------------------------------------------------------------------------
+# f1  ParadisLoss  (reference utils/loss.py)
+# ---------------------------------------------------------------------------
+def latitude_weights(lat_deg: Tensor) -> Tensor:
+    """Unit-mean latitude weights (utils/loss.py:129-189)."""
+    lat = lat_deg.to(torch.float64)
+    d = lat[1:] - lat[:-1]
+    if not torch.allclose(d, d[0].expand_as(d), rtol=0.0, atol=1e-6):
+        raise ValueError("Latitude grid is not uniformly spaced.")
+    delta = d[0].abs()
+    has_poles = abs(float(lat.min()) + 90.0) <= 1e-6 and abs(float(lat.max()) - 90.0) <= 1e-6
+    if has_poles:
+        w = torch.cos(torch.deg2rad(lat)) * torch.sin(torch.deg2rad(delta) / 2.0)
+        pole = torch.sin(torch.deg2rad(delta) / 4.0) ** 2
+        w[torch.argmin(lat)] = pole
+        w[torch.argmax(lat)] = pole
+    else:
+        if abs(float(lat.max()) - (90.0 - float(delta) / 2)) > 1e-6 or \
+                abs(float(lat.min()) - (-90.0 + float(delta) / 2)) > 1e-6:
+            raise ValueError("Latitude vector must end at +-(90 - d/2).")
+        w = torch.cos(torch.deg2rad(lat))
+    w = w / w.mean()
+    return w.to(lat_deg.dtype)
+
+
+def feature_weights(var_weights: Tensor, pressure_levels: Tensor, num_features: int,
+                    num_surface: int) -> Tensor:
+    """Per-output-channel weights, including the reference's blocks-of-``num_levels``
+    walk over the first ``num_features-num_surface`` channels (utils/loss.py:191-231)."""
+    pl = pressure_levels.to(torch.float32) / 1000
+    pw = torch.where(pl > 0.2, pl, torch.full_like(pl, 0.2))
+    nl = len(pressure_levels)
+    n_atm = num_features - num_surface
+    fw = torch.zeros(num_features, dtype=torch.float32)
+    for i in range(0, n_atm, nl):
+        fw[i:i + nl] = var_weights[i:i + nl] * pw
+    fw[n_atm:] = var_weights[n_atm:]
+    return fw
+
+
+def reversed_huber(pred: Tensor, target: Tensor, delta: float) -> Tensor:
+    """Smooth reversed Huber (utils/loss.py:233-255)."""
+    err = pred - target
+    a = err.abs()
+    small = delta * a
+    large = (err ** 2 + delta ** 2) / (2 * delta)
+    w = 1 / (1 + torch.exp(-2 * (a - delta)))
+    return (1 - w) * small + w * large
+
+
+def paradis_loss(pred: Tensor, target: Tensor, fw: Tensor, lw: Optional[Tensor],
+                 kind: str = "reversed_huber", delta: float = 1.0) -> Tensor:
+    """utils/loss.py:262-282."""
+    if kind == "reversed_huber":
+        l = reversed_huber(pred, target, delta)
+    elif kind == "mse":
+        l = (pred - target) ** 2
+    else:
+        raise ValueError(kind)
+    l = l * fw.reshape(1, -1, 1, 1).to(l.dtype)
+    if lw is not None:
+        l = l * lw.reshape(1, 1, -1, 1).to(l.dtype)
+    return l.mean()

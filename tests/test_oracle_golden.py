@@ -1,0 +1,240 @@
+"""Pin the CPU oracle against fixtures generated from the reference
+(tests/golden/make_golden.py).  CPU-only; no HIP involved."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import paradis_oracle as O
+from paradis_model_amd.config import default_config, reduced_config, feature_layout
+from tests._util import GOLDEN, assert_chk, load_golden, make_grid, max_rel, rms_rel, seeded
+
+
+# ------------------------------------------------------------------ G1
+def test_geocyclic_index_map_bit_exact():
+    g = load_golden("g1_pad.pt")
+    for key, want in g.items():
+        if key.endswith("sha256"):
+            continue
+        hw, p = key.split("_p")
+        H, W = map(int, hw.split("x"))
+        row, col = O.geocyclic_source_index(H, W, int(p))
+        got = torch.from_numpy(row * W + col).to(torch.int32)
+        assert torch.equal(got, want), key
+        x = torch.arange(H * W, dtype=torch.float32).reshape(1, 1, H, W)
+        assert torch.equal(O.geocyclic_pad(x, int(p))[0, 0].to(torch.int32), want)
+    row, col = O.geocyclic_source_index(721, 1440, 2)
+    digest = hashlib.sha256(np.ascontiguousarray(row * 1440 + col).astype(np.int64).tobytes()).hexdigest()
+    assert digest == g["721x1440_p2_sha256"]
+
+
+def test_geocyclic_rejects_odd_width():
+    with pytest.raises(AssertionError):
+        O.geocyclic_source_index(8, 7, 1)
+
+
+# ------------------------------------------------------------------ G2
+def _advect_case(rec):
+    H, W, K, B = rec["H"], rec["W"], rec["K"], rec["B"]
+    _, lg, og = make_grid(H, W, rec["poles"])
+    s = rec["seed"]
+    f = seeded(s, B, K, H, W)
+    u = seeded(s + 1, B, K, H, W, scale=rec["scale"])
+    v = seeded(s + 2, B, K, H, W, scale=rec["scale"])
+    ct = seeded(s + 3, B, K, H, W)
+    assert_chk([f, u, v, ct], rec["chk"])
+    return f, u, v, ct, O.GridGeometry(lg, og)
+
+
+@pytest.mark.parametrize("impl", ["taps", "aten_ref"])
+def test_advect_core_forward_backward(impl):
+    g = load_golden("g2_advect.pt")
+    for key, rec in g.items():
+        f, u, v, ct, geo = _advect_case(rec)
+        f, u, v = (t.requires_grad_(True) for t in (f, u, v))
+        if impl == "taps":
+            y = O.sl_advect_core(f, u, v, rec["dt"], geo, rec["mode"], "taps")
+        else:
+            y = O.sl_advect_core_aten(f, u, v, rec["dt"], geo, rec["mode"])
+        y.backward(ct)
+        # identical op order for the coordinates => near bit-equality with the reference fp32
+        assert max_rel(y, rec["out_f32"]) < 2e-6, key
+        assert max_rel(f.grad, rec["gfield_f32"]) < 2e-5, key
+        assert max_rel(u.grad, rec["gu_f32"]) < 5e-4, key   # fp32 noise of the reference itself
+        assert max_rel(v.grad, rec["gv_f32"]) < 5e-4, key
+
+
+def test_advect_core_fp64_matches_reference_fp64():
+    g = load_golden("g2_advect.pt")
+    for key, rec in g.items():
+        f, u, v, ct, geo = _advect_case(rec)
+        y = O.sl_advect_core(f.double(), u.double(), v.double(), rec["dt"], geo.to(torch.float64),
+                             rec["mode"], "taps")
+        assert max_rel(y, rec["out_f64"]) < 1e-12, key
+
+
+# ------------------------------------------------------------------ G3
+def _grad_check(y, x, params, rec, tol=2e-5):
+    y.backward(rec["cot"])
+    assert max_rel(y, rec["y"]) < tol
+    assert max_rel(x.grad, rec["gx"]) < tol
+    for k, p in params.items():
+        if k in rec["grads"]:
+            assert max_rel(p.grad, rec["grads"][k]) < 5 * tol, k
+
+
+def _leaf(d):
+    return {k: v.clone().requires_grad_(True) for k, v in d.items()}
+
+
+def test_blocks_against_reference():
+    g = load_golden("g3_blocks.pt")
+    rec = g["clinear"]
+    P = _leaf(rec["params"]); x = rec["x"].clone().requires_grad_(True)
+    _grad_check(O.pointwise(x, P["conv.weight"], P["conv.bias"]), x, P, rec)
+    for k in (5, 7):
+        rec = g[f"sepconv_k{k}"]
+        P = _leaf(rec["params"]); x = rec["x"].clone().requires_grad_(True)
+        y = O.pointwise(O.depthwise_geo(x, P["depthwise.weight"]), P["pointwise.weight"], P["pointwise.bias"])
+        _grad_check(y, x, P, rec)
+    rec = g["channelnorm"]
+    P = _leaf(rec["params"]); x = rec["x"].clone().requires_grad_(True)
+    _grad_check(O.channel_norm(x, P["weight"], P["bias"]), x, P, rec)
+    for tag in ("noproj", "proj"):
+        rec = g[f"globalbias_{tag}"]
+        P = _leaf(rec["params"]); x = rec["x"].clone().requires_grad_(True)
+        y = x + O.global_bias_map(P["A"], P["U"], P["V"], P.get("projection.weight")).unsqueeze(0)
+        _grad_check(y, x, P, rec)
+    for key, rec in g.items():
+        if key.startswith("downsample"):
+            s = int(key.split("_s")[1])
+            x = rec["x"].clone().requires_grad_(True)
+            _grad_check(O.avgpool_geo(x, s), x, {}, rec)
+        if key.startswith("upsample"):
+            nlat, nlon = map(int, key.split("_")[1].split("x"))
+            x = rec["x"].clone().requires_grad_(True)
+            _grad_check(O.upsample_lon_periodic(x, nlat, nlon), x, {}, rec)
+
+
+def test_downsample_stride1_is_not_identity_and_upsample_stride1_is():
+    x = torch.randn(1, 2, 8, 16)
+    assert not torch.allclose(O.avgpool_geo(x, 1), x)
+    assert torch.equal(O.upsample_lon_periodic(x, 8, 16), x)
+
+
+def test_gmblock_plan_and_run():
+    rec = load_golden("g3_blocks.pt")["gmblock"]
+    plan = O.plan_gmblock(["CLinear", "SepConv", "CLinear"], 10, 6, hidden_dim=12, act="GELU",
+                          bias_channels=4, pre_normalize=True)
+    names = [n for k, n, _ in plan.steps]
+    assert names == ["0-ChannelNorm", "0-CLinear", "0-GlobalBias", "0-GELU", "1-SepConv", "1-GELU", "2-CLinear"]
+    P = _leaf({"blk." + k: v for k, v in rec["params"].items()})
+    x = rec["x"].clone().requires_grad_(True)
+    y = O.run_block(P, "blk", plan, x)
+    y.backward(rec["cot"])
+    assert max_rel(y, rec["y"]) < 2e-5
+    assert max_rel(x.grad, rec["gx"]) < 2e-5
+    assert set(k[4:] for k in P) == set(rec["keys"])
+
+
+# ------------------------------------------------------------------ G4 / G5
+@pytest.mark.parametrize("variant", ["a", "b", "c"])
+def test_reduced_model_forward_backward(variant):
+    rec = load_golden(f"g4_model_{variant}.pt")
+    v = rec["variant"]
+    cfg = reduced_config(activation=v["activation"], adv_interpolation=v["adv_interpolation"],
+                         coarsening_factor=v["coarsening_factor"])
+    lay = feature_layout(cfg)
+    spec = O.spec_from_cfg(cfg, v["nlat"], v["nlon"], lay.num_in_dyn_features,
+                           lay.num_in_static_features, lay.num_out_features)
+    lg, og = rec["lat_grid"], rec["lon_grid"]
+    x = seeded(rec["x_seed"], rec["B"], 186, v["nlat"], v["nlon"])
+    x[:, -2] = lg
+    x[:, -1] = og
+    tgt = seeded(rec["target_seed"], rec["B"], 97, v["nlat"], v["nlon"])
+    assert_chk([x, tgt], rec["chk"])
+    P = _leaf(rec["state"])
+    x.requires_grad_(True)
+    y = O.paradis_forward(P, spec, x, lg, og)
+    assert max_rel(y, rec["y"]) < 1e-5
+    cfg_full = default_config()
+    fw = O.feature_weights(torch.tensor([1.0] * 83 + [0.1] * 13 + [1.0]),
+                           torch.tensor(cfg_full.features.pressure_levels), 97, 6)
+    loss = O.paradis_loss(y, tgt, fw, O.latitude_weights(rec["lat_deg"]))
+    assert abs(float(loss) - float(rec["loss"])) < 1e-6 * abs(float(rec["loss"])) + 1e-7
+    loss.backward()
+    assert max_rel(x.grad[:, ::9], rec["gx_sub"]) < 2e-4
+    worst = max(max_rel(P[k].grad, gref) for k, gref in rec["grads"].items()
+                if float(gref.abs().max()) > 0)
+    assert worst < 5e-4, worst
+
+
+def test_default_manifest_spec():
+    with open(os.path.join(GOLDEN, "default_manifest.json")) as f:
+        man = json.load(f)
+    assert man["num_parameters"] == 60038475 and len(man["entries"]) == 335
+    cfg = default_config()
+    lay = feature_layout(cfg)
+    assert (lay.num_in_dyn_features, lay.num_in_static_features, lay.num_common_features,
+            lay.num_out_features) == (176, 10, 83, 97)
+    spec = O.spec_from_cfg(cfg, 32, 64, 176, 10, 97)
+    assert abs(spec.dt - man["dt"]) < 1e-12
+
+
+# ------------------------------------------------------------------ G6
+def test_loss_weights_and_values():
+    g = load_golden("g6_loss.pt")
+    cfg = default_config()
+    for key, rec in g.items():
+        nlat = int(key.split("x")[0]); nlon = int(key.split("x")[1].split("_")[0])
+        kind = key.split("_", 1)[1]
+        lw = O.latitude_weights(rec["lat_deg"])
+        assert max_rel(lw, rec["lat_weights"]) < 1e-6
+        fw = O.feature_weights(rec["var_weights"], torch.tensor(cfg.features.pressure_levels), 97, 6)
+        assert torch.equal(fw, rec["feature_weights"])
+        assert rec["order"] == feature_layout(cfg).output_name_order
+        if "loss" in rec:
+            p = seeded(rec["pred_seed"], 2, 97, nlat, nlon, scale=1.5).requires_grad_(True)
+            t = seeded(rec["target_seed"], 2, 97, nlat, nlon)
+            l = O.paradis_loss(p, t, fw, lw, kind)
+            l.backward()
+            assert abs(float(l) - float(rec["loss"])) < 2e-6 * abs(float(rec["loss"]))
+            assert max_rel(p.grad[:, ::8, ::2, ::4], rec["gpred_sub"]) < 1e-5
+
+
+# ------------------------------------------------------------------ c2 rollout
+def test_two_step_rollout_matches_reference():
+    rec = load_golden("c2_rollout.pt")
+    cfg = reduced_config()
+    lay = feature_layout(cfg)
+    H, W = rec["lat_grid"].shape
+    spec = O.spec_from_cfg(cfg, H, W, lay.num_in_dyn_features, lay.num_in_static_features,
+                           lay.num_out_features)
+    B, S = rec["B"], rec["S"]
+    s = rec["seeds"]
+    inp = seeded(s[0], B, 1, 166, H, W)
+    tgt = seeded(s[1], B, S, 97, H, W)
+    forc = seeded(s[2], B, S, H, W, 10, kind="rand")
+    const = seeded(s[3], B, 1, H, W, 10)
+    assert_chk([inp, tgt, forc, const], rec["chk"])
+    P = _leaf(rec["state"])
+    fw = O.feature_weights(torch.tensor([1.0] * 83 + [0.1] * 13 + [1.0]),
+                           torch.tensor(cfg.features.pressure_levels), 97, 6)
+    lw = O.latitude_weights(rec["lat_deg"])
+    constants = const[:, :1].permute(0, 1, 4, 2, 3)
+    forcings = forc.permute(0, 1, 4, 2, 3)
+    cur, total = inp, 0.0
+    for step in range(S):
+        mi = torch.cat([cur, forcings[:, step].unsqueeze(1), constants], dim=2).squeeze(1)
+        y = O.paradis_forward(P, spec, mi, rec["lat_grid"], rec["lon_grid"])
+        assert max_rel(y, rec["outputs"][step]) < 2e-5
+        total = total + O.paradis_loss(y, tgt[:, step], fw, lw) / S
+        cur = torch.cat([mi[:, 83:166], y[:, :83]], dim=1).unsqueeze(1)
+    total.backward()
+    assert abs(float(total) - float(rec["loss"])) < 2e-6 * abs(float(rec["loss"]))
+    assert max_rel(P["alpha_adv"].grad, rec["grad_alpha"]) < 5e-4
+    for k, gn in rec["grad_norms"].items():
+        assert abs(float(P[k].grad.norm()) - gn) <= 1e-3 * gn + 1e-9, k
