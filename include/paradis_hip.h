@@ -1,0 +1,146 @@
+/*
+ * paradis_hip.h -- C ABI of libparadis_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the PARADIS advection-diffusion-reaction hot path.
+ * The reference has no FFI layer (it is pure Python on ATen); each entry point
+ * below replaces the ATen call sequence of the cited reference lines and is
+ * what a ctypes binding in the reference's model/ package would call (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (unless noted), NCHW, planes
+ *     (H*W) contiguous; `*_bs` arguments are batch strides in ELEMENTS so that
+ *     channel slices of a larger tensor can be read/written without copies;
+ *   - inputs are borrowed, outputs are caller-allocated, no global mutable
+ *     state, no host synchronisation; kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*), so calls are graph-capturable;
+ *   - return 0 on success; non-zero = rejected arguments (1) or HIP launch
+ *     failure (2); paradis_last_error() returns a thread-local message;
+ *   - `act`: 0 none, 1 SiLU, 2 GELU(erf).  `mode`: 1 bilinear, 2 bicubic.
+ */
+#ifndef PARADIS_HIP_H
+#define PARADIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARADIS_ACT_NONE 0
+#define PARADIS_ACT_SILU 1
+#define PARADIS_ACT_GELU 2
+#define PARADIS_INTERP_BILINEAR 1
+#define PARADIS_INTERP_BICUBIC 2
+
+int paradis_abi_version(void);
+const char* paradis_last_error(void);
+
+/* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
+ * x [planes,H,W] -> y [planes,H+2p,W+2p];  gx[src(i,j)] += gy[i,j]. Integer index map, bit-exact. */
+int paradis_geocyclic_pad_fwd(const float* x, float* y, int64_t planes, int H, int W, int p, void* stream);
+int paradis_geocyclic_pad_bwd(const float* gy, float* gx, int64_t planes, int H, int W, int p, void* stream);
+
+/* ---- a3-a5: fused core of NeuralSemiLagrangian.forward (reference model/advection.py:129-169):
+ * pole mean -> departure point (advection.py:74-98) -> virtual geocyclic index map ->
+ * bilinear/bicubic gather (ATen grid_sampler_2d semantics, align_corners, zeros) -> pole mean.
+ * field/out [B,K,H,W]; u,v [B,K,H,W] with batch stride uv_bs; sin_lat/cos_lat/lon tables [H*W]. */
+int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, float* out,
+                          const float* sin_lat, const float* cos_lat, const float* lon,
+                          int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs, int64_t o_bs,
+                          float dt, float min_lat, float min_lon, float d_lat, float d_lon,
+                          int mode, void* workspace, void* stream);
+/* gfield [B,K,H,W] (batch stride gf_bs), gu/gv with batch stride guv_bs.
+ * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes. */
+size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
+int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u, const float* v,
+                          float* gfield, float* gu, float* gv,
+                          const float* sin_lat, const float* cos_lat, const float* lon,
+                          int B, int K, int H, int W, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
+                          int64_t gf_bs, int64_t guv_bs,
+                          float dt, float min_lat, float min_lon, float d_lat, float d_lon,
+                          int mode, void* workspace, void* stream);
+
+/* ---- a7 (depthwise half of SepConv, reference model/blocks.py:101-113) and the static
+ * encoder's GeoCyclicPadding(3)+Conv2d(groups=C) (reference model/paradis.py:189-190):
+ * k x k per-channel stencil on the virtual geocyclic halo. w [C,k,k]; bias [C] or NULL; k in {3,5,7}. */
+int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int B, int C, int H, int W, int k, void* stream);
+int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx,
+                             int B, int C, int H, int W, int k, void* stream);
+size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k);
+int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* gw, float* gbias,
+                             int B, int C, int H, int W, int k, void* workspace, void* stream);
+
+/* ---- a11: PhysicalDownsample (reference model/blocks.py:57-71): geocyclic 5x5 box mean, stride s */
+int paradis_avgpool_geo_fwd(const float* x, float* y, int64_t planes, int H, int W, int stride, void* stream);
+int paradis_avgpool_geo_bwd(const float* gy, float* gx, int64_t planes, int H, int W, int stride, void* stream);
+
+/* ---- a14: Paradis.upsample (reference model/paradis.py:208-220): lon-periodic bilinear, align_corners */
+int paradis_upsample_lonp_fwd(const float* x, float* y, int64_t planes, int Hc, int Wc, int H, int W, void* stream);
+int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc, int Wc, int H, int W, void* stream);
+
+/* ---- a6: CLinear / pointwise half of SepConv (reference model/blocks.py:86,110): per-sample GEMM
+ * on FP32 MFMA.  Y[b] = epi( W[M,K] * X[b][K,N] ),  epi(v) = res + act(v + bias[m] + map[m,n]).
+ * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value. */
+int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float* bias, const float* map,
+                        const float* res, float* Y, float* zpre,
+                        int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
+                        int act, void* stream);
+/* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend) */
+int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const float* zpre, const float* addend,
+                          float* dX, int B, int M, int K, int N, int64_t dy_bs, int64_t z_bs,
+                          int64_t add_bs, int64_t dx_bs, int act, void* stream);
+/* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; workspace >= paradis_pw_gemm_wgrad_ws_bytes */
+size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N);
+int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
+                          int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs,
+                          void* workspace, void* stream);
+
+/* ---- a8: ChannelNorm (reference model/blocks.py:118-134): per-pixel, unbiased variance.
+ * x may be the virtual concatenation [x1 (C1 ch, batch stride x1_bs) ; x2 (C2 ch)] (paradis.py:249). */
+int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w, const float* b,
+                             float* y, float* mean, float* rstd,
+                             int B, int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs,
+                             float eps, void* stream);
+size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P);
+/* gx1/gx2 receive the slices of the input gradient (gx2 may be NULL); gw,gb [C]. */
+int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2, const float* w,
+                             const float* mean, const float* rstd, float* gx1, float* gx2,
+                             float* gw, float* gb, int B, int C1, int C2, int P,
+                             int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs, int64_t gx2_bs,
+                             void* workspace, void* stream);
+
+/* ---- a9: GlobalBias map (reference model/blocks.py:188-196).
+ * m8[Cin,H,W] = sum_r A[c,r] U[r,h] V[r,w];  map[Co,H,W] = Pw[Co,Cin] m8 (or map = m8 if Pw NULL). */
+int paradis_global_bias_map_fwd(const float* A, const float* U, const float* V, const float* Pw,
+                                float* m8, float* map, int Cin, int Co, int R, int H, int W, void* stream);
+size_t paradis_global_bias_map_bwd_ws_bytes(int Cin, int Co, int R, int H, int W);
+int paradis_global_bias_map_bwd(const float* gmap, const float* A, const float* U, const float* V,
+                                const float* Pw, const float* m8, float* gA, float* gU, float* gV,
+                                float* gPw, int Cin, int Co, int R, int H, int W,
+                                void* workspace, void* stream);
+
+/* ---- elementwise / reductions used by the blocks */
+int paradis_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
+int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act, void* stream);
+/* out = h + sigmoid(alpha[c]) * (adv - h)          (reference model/paradis.py:239,243) */
+int paradis_gated_blend_fwd(const float* h, const float* adv, const float* alpha, float* out,
+                            int B, int C, int P, void* stream);
+size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P);
+int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv, const float* alpha,
+                            float* gh, float* gadv, float* galpha, int B, int C, int P,
+                            void* workspace, void* stream);
+/* gmap[C,P] = sum_b dz[b,C,P] (NULL to skip), gbias[C] = sum_{b,p} dz (NULL to skip) */
+int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
+                       int64_t dz_bs, void* stream);
+/* y = a + b (n elements) */
+int paradis_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* y[b,i] = x[b,i] + m[i], i < per_sample  (standalone GlobalBias.forward, reference model/blocks.py:196) */
+int paradis_add_bcast(const float* x, const float* m, float* y, int64_t per_sample, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARADIS_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of the C-ABI library ``libparadis_hip.so`` (include/paradis_hip.h).
+
+There is NO fallback: if the library is missing the import fails loudly, and every
+op requires CUDA(HIP) fp32 tensors.  PyTorch is only used for device memory and
+the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparadis_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension is not built. Run "
+        "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C paradis_model_amd/csrc`). "
+        "paradis_model_amd has no CPU/eager fallback by design.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+P, I, L, F, S = c_void_p, c_int, c_int64, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/paradis_hip.h one to one
+SIGNATURES = {
+    "paradis_abi_version": (I, []),
+    "paradis_last_error": (c_char_p, []),
+    "paradis_geocyclic_pad_fwd": (I, [P, P, L, I, I, I, P]),
+    "paradis_geocyclic_pad_bwd": (I, [P, P, L, I, I, I, P]),
+    "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, P, P]),
+    "paradis_sl_advect_ws_bytes": (S, [I, I, I, I]),
+    "paradis_sl_advect_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L,
+                                  F, F, F, F, F, I, P, P]),
+    "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "paradis_dwconv_geo_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
+    "paradis_dwconv_geo_wgrad_ws_bytes": (S, [I, I, I, I, I]),
+    "paradis_dwconv_geo_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, P]),
+    "paradis_avgpool_geo_fwd": (I, [P, P, L, I, I, I, P]),
+    "paradis_avgpool_geo_bwd": (I, [P, P, L, I, I, I, P]),
+    "paradis_upsample_lonp_fwd": (I, [P, P, L, I, I, I, I, P]),
+    "paradis_upsample_lonp_bwd": (I, [P, P, L, I, I, I, I, P]),
+    "paradis_pw_gemm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, I, P]),
+    "paradis_pw_gemm_dgrad": (I, [P, P, P, P, P, I, I, I, I, L, L, L, L, I, P]),
+    "paradis_pw_gemm_wgrad_ws_bytes": (S, [I, I, I, I]),
+    "paradis_pw_gemm_wgrad": (I, [P, P, P, I, I, I, I, L, L, P, P]),
+    "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
+    "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),
+    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, P]),
+    "paradis_global_bias_map_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "paradis_global_bias_map_bwd_ws_bytes": (S, [I, I, I, I, I]),
+    "paradis_global_bias_map_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
+    "paradis_act_fwd": (I, [P, P, L, I, P]),
+    "paradis_act_bwd": (I, [P, P, P, L, I, P]),
+    "paradis_gated_blend_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "paradis_gated_blend_bwd_ws_bytes": (S, [I, I, I]),
+    "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
+    "paradis_bias_grads": (I, [P, P, P, I, I, I, L, P]),
+    "paradis_add": (I, [P, P, P, L, P]),
+    "paradis_add_bcast": (I, [P, P, P, L, I, P]),
+}
+
+_missing = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        _missing.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+if _missing and os.environ.get("PARADIS_DEV_PARTIAL") != "1":
+    raise ImportError(f"{LIB_PATH} lacks symbols {_missing}; rebuild the HIP extension")
+
+
+def last_error() -> str:
+    msg = lib.paradis_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, name: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {last_error()}")
+
+
+def dptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_hip(*tensors) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("paradis_model_amd ops run on the MI355X only: got a CPU tensor "
+                               "(there is no CPU fallback; use oracle/ for CPU checks)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"paradis_model_amd ops are fp32; got {t.dtype}")

@@ -1,0 +1,111 @@
+// Shared device helpers for libparadis_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/paradis_hip.h"
+
+#define WAVE 64
+
+void paradis_set_error(const char* fmt, ...);
+
+#define PD_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      paradis_set_error(__VA_ARGS__);         \
+      return 1;                               \
+    }                                         \
+  } while (0)
+
+#define PD_CHECK_LAUNCH(name)                                               \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      paradis_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return 2;                                                             \
+    }                                                                       \
+  } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// Geocyclic index map (reference model/padding.py:11-39).
+// (ii, jj) are IMAGE coordinates of a padded cell: ii in [-p, H+p), jj in [-p, W+p).
+// Rows beyond a pole mirror about the pole row and shift by W/2; longitude wraps.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int geo_wrap_col(int jj, int W) {
+  return jj < 0 ? jj + W : (jj >= W ? jj - W : jj);
+}
+
+__device__ __forceinline__ void geo_src(int ii, int jj, int H, int W, int& r, int& c) {
+  int j = geo_wrap_col(jj, W);
+  if (ii < 0) {
+    r = -ii;
+    c = j + (W >> 1);
+    if (c >= W) c -= W;
+  } else if (ii >= H) {
+    r = 2 * (H - 1) - ii;
+    c = j + (W >> 1);
+    if (c >= W) c -= W;
+  } else {
+    r = ii;
+    c = j;
+  }
+}
+
+// Enumerate every padded cell (image coords) that aliases source cell (y, x): f(ii, jj).
+template <class F>
+__device__ __forceinline__ void geo_for_each_alias(int y, int x, int H, int W, int p, F f) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    int ii;
+    bool mirror;
+    if (t == 0) {
+      ii = y;
+      mirror = false;
+    } else if (t == 1) {
+      if (!(y >= 1 && y <= p)) continue;
+      ii = -y;
+      mirror = true;
+    } else {
+      if (!(y >= H - 1 - p && y <= H - 2)) continue;
+      ii = 2 * (H - 1) - y;
+      mirror = true;
+    }
+    int jb = x;
+    if (mirror) {
+      jb = x + (W >> 1);
+      if (jb >= W) jb -= W;
+    }
+    f(ii, jb);
+    if (jb >= W - p) f(ii, jb - W);
+    if (jb < p) f(ii, jb + W);
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  if (act == PARADIS_ACT_SILU) {
+    return z / (1.0f + expf(-z));
+  } else if (act == PARADIS_ACT_GELU) {
+    return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+  }
+  return z;
+}
+
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == PARADIS_ACT_SILU) {
+    float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+  } else if (act == PARADIS_ACT_GELU) {
+    float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+    return cdf + z * pdf;
+  }
+  return 1.0f;
+}

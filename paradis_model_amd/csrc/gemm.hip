@@ -1,0 +1,296 @@
+// a6: pointwise (1x1) channel mixing as a batched GEMM on FP32 MFMA (v_mfma_f32_32x32x2_f32).
+// Reference call sites: model/blocks.py:86 (CLinear), :110 (SepConv pointwise).
+//
+//   fwd   : Y[b][Co,P] = epi( W[Co,Ci] . X[b][Ci,P] )      A = W  (k-contiguous), B = X  (n-contiguous)
+//   dgrad : dX[b][Ci,P] = epi( W^T . dY[b][Co,P] )         A = W^T(m-contiguous), B = dY (n-contiguous)
+//   wgrad : dW[Co,Ci]   = sum_b dY[b] . X[b]^T             A = dY (k-contiguous), B = X^T(k-contiguous)
+//
+// Exact fp32: the f32 MFMA is a k-ordered fmaf chain (no TF32/xf32 on gfx950), so results differ
+// from the CPU's blocked SGEMM only by summation order.
+//
+// Tile: 128x128x16 per 256-thread workgroup; wave (wm,wn) owns 64x64 = 2x2 MFMA 32x32 tiles
+// (64 accumulator VGPRs).  Both operands are staged through registers into LDS as [k][m|n] images
+// (+4 padding) so that fragment reads are conflict-free ds_read_b32; two LDS stages, one barrier
+// per k-tile, global loads for tile t+1 in flight during the MFMAs of tile t.  Work-group ids are
+// remapped so that the M-tiles that share one X tile run on the same XCD (L2 reuse of X).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_LD = BM + 4;  // floats per k-row of the LDS image
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int64_t a_bs, b_bs, c_bs;   // stride between grid batches (fwd/dgrad: sample; wgrad: split slab)
+  int nbatch;                 // grid batches
+  int inner, inner_step;      // wgrad: samples reduced inside one workgroup: ib = batch; ib < inner; ib += inner_step
+  int64_t a_is, b_is;         // strides between inner samples
+  // epilogue:  v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v); v += res
+  const float* bias; const float* map; const float* res; const float* zmul; float* zout;
+  int64_t res_bs, zmul_bs, zout_bs;
+  int act;
+};
+
+// ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
+// KC: element (row=m|n, k) at base[row*ld + k]   (k contiguous)
+// MC: element (row=m|n, k) at base[k*ld + row]   (row contiguous)
+template <bool KC>
+__device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_t ld, int row0,
+                                          int k0, int rows, int K, bool vec_ok, float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (KC) {
+      const int row = row0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
+      const float* p = base + (int64_t)row * ld + k;
+      if (vec_ok && row < rows && k + 3 < K) {
+        r[i] = *reinterpret_cast<const float4*>(p);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (row < rows && k + j < K) ? p[j] : 0.f;
+        r[i] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    } else {
+      const int k = k0 + (tid >> 5) + 8 * i, row = row0 + (tid & 31) * 4;
+      const float* p = base + (int64_t)k * ld + row;
+      if (vec_ok && k < K && row + 3 < rows) {
+        r[i] = *reinterpret_cast<const float4*>(p);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (k < K && row + j < rows) ? p[j] : 0.f;
+        r[i] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void slab_store(float* __restrict__ img, const float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (KC) {
+      const int m = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+      img[(k + 0) * LDS_LD + m] = r[i].x;
+      img[(k + 1) * LDS_LD + m] = r[i].y;
+      img[(k + 2) * LDS_LD + m] = r[i].z;
+      img[(k + 3) * LDS_LD + m] = r[i].w;
+    } else {
+      const int k = (tid >> 5) + 8 * i, m = (tid & 31) * 4;
+      *reinterpret_cast<float4*>(img + k * LDS_LD + m) = r[i];
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256, 2)
+pw_gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDS_LD];  // [stage][A|B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- XCD-aware decode: consecutive logical ids (same X tile, different M tiles) share an XCD
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int KT = (g.K + BK - 1) / BK;
+  const int n_inner = g.inner > 0 ? (g.inner - bz + g.inner_step - 1) / g.inner_step : 1;
+  const int T = KT * n_inner;
+
+  const float* Ab = g.A + (g.inner > 0 ? 0 : (int64_t)bz * g.a_bs);
+  const float* Bb = g.B + (g.inner > 0 ? 0 : (int64_t)bz * g.b_bs);
+  const int first_inner = g.inner > 0 ? bz : 0;
+
+  const bool a_vec = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+                     ((g.a_bs & 3) == 0) && ((g.a_is & 3) == 0);
+  const bool b_vec = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
+                     ((g.b_bs & 3) == 0) && ((g.b_is & 3) == 0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  auto fetch = [&](int t) {
+    const int ib = t / KT, kt = t - ib * KT;
+    const int64_t isamp = first_inner + (int64_t)ib * g.inner_step;
+    const float* Ap = Ab + (g.inner > 0 ? isamp * g.a_is : 0);
+    const float* Bp = Bb + (g.inner > 0 ? isamp * g.b_is : 0);
+    slab_load<A_KC>(Ap, g.lda, m0, kt * BK, g.M, g.K, a_vec, ra);
+    slab_load<B_KC>(Bp, g.ldb, n0, kt * BK, g.N, g.K, b_vec, rb);
+  };
+
+  if (T > 0) {
+    fetch(0);
+    slab_store<A_KC>(lds[0][0], ra);
+    slab_store<B_KC>(lds[0][1], rb);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < T) fetch(t + 1);
+    const float* As = lds[cur][0] + wm * 64 + li;
+    const float* Bs = lds[cur][1] + wn * 64 + li;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int krow = (2 * kk + lh) * LDS_LD;
+      const float a0 = As[krow], a1 = As[krow + 32];
+      const float b0 = Bs[krow], b1 = Bs[krow + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (t + 1 < T) {
+      slab_store<A_KC>(lds[cur ^ 1][0], ra);
+      slab_store<B_KC>(lds[cur ^ 1][1], rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  float* Cb = g.C + (int64_t)bz * g.c_bs;
+  const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
+  const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
+  float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      const float bv = g.bias ? g.bias[m] : 0.f;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = n0 + wn * 64 + tn * 32 + li;
+        if (n >= g.N) continue;
+        const int64_t off = (int64_t)m * g.ldc + n;
+        float v = acc[tm][tn][r] + bv;
+        if (g.map) v += g.map[off];
+        if (zoutb) zoutb[off] = v;
+        if (zmulb) v *= act_grad(zmulb[off], g.act);
+        else if (g.act) v = act_apply(v, g.act);
+        if (resb) v += resb[off];
+        Cb[off] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
+    out[i] = s;
+  }
+}
+
+int wgrad_splits(int B, int M, int K) {
+  const int tiles = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
+  int s = (1024 + tiles - 1) / tiles;
+  return std::max(1, std::min(s, B));
+}
+
+int check_gemm(const char* name, int B, int M, int K, int N) {
+  PD_REQUIRE(B >= 0 && M >= 1 && K >= 1 && N >= 1, "%s: bad shape B=%d M=%d K=%d N=%d", name, B, M, K, N);
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * std::max(B, 1);
+  PD_REQUIRE(tiles < (1ll << 31), "%s: too many tiles", name);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float* bias,
+                                   const float* map, const float* res, float* Y, float* zpre, int B,
+                                   int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
+                                   int act, void* stream) {
+  if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
+  PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
+  if (B == 0) return 0;
+  GemmArgs g{};
+  g.A = Wt; g.B = X; g.C = Y; g.M = M; g.N = N; g.K = K;
+  g.lda = K; g.ldb = N; g.ldc = N;
+  g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0; g.inner_step = 1;
+  g.bias = bias; g.map = map; g.res = res; g.res_bs = res_bs; g.zmul = nullptr; g.zout = zpre;
+  g.zout_bs = (int64_t)M * N; g.act = act;
+  const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  hipLaunchKernelGGL((pw_gemm_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+  PD_CHECK_LAUNCH("pw_gemm_fwd");
+  return 0;
+}
+
+extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const float* zpre,
+                                     const float* addend, float* dX, int B, int M, int K, int N,
+                                     int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
+                                     int act, void* stream) {
+  // W is [M,K] (M = Co, K = Ci); result dX is [K,N] per sample: GEMM with M' = K, K' = M.
+  if (int e = check_gemm("pw_gemm_dgrad", B, K, M, N)) return e;
+  PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_dgrad: unknown activation code %d", act);
+  if (B == 0) return 0;
+  GemmArgs g{};
+  g.A = Wt; g.B = dY; g.C = dX; g.M = K; g.N = N; g.K = M;
+  g.lda = K; g.ldb = N; g.ldc = N;
+  g.a_bs = 0; g.b_bs = dy_bs; g.c_bs = dx_bs; g.nbatch = B; g.inner = 0; g.inner_step = 1;
+  g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
+  const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  hipLaunchKernelGGL((pw_gemm_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+  PD_CHECK_LAUNCH("pw_gemm_dgrad");
+  return 0;
+}
+
+extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
+  (void)N;
+  const int S = wgrad_splits(std::max(B, 1), M, K);
+  return S > 1 ? (size_t)S * M * K * sizeof(float) + 256 : 256;
+}
+
+extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, int B, int M, int K,
+                                     int N, int64_t dy_bs, int64_t x_bs, void* workspace,
+                                     void* stream) {
+  // dW[M,K] = sum_b dY[b][M,N] . X[b][K,N]^T : GEMM with M'=M, N'=K, K'=N, reduced over samples.
+  if (int e = check_gemm("pw_gemm_wgrad", 1, M, N, K)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
+    return 0;
+  }
+  const int S = wgrad_splits(B, M, K);
+  PD_REQUIRE(S == 1 || workspace != nullptr, "pw_gemm_wgrad: workspace required");
+  GemmArgs g{};
+  g.A = dY; g.B = X; g.C = S > 1 ? (float*)workspace : dW;
+  g.M = M; g.N = K; g.K = N;
+  g.lda = N; g.ldb = N; g.ldc = K;
+  g.a_bs = 0; g.b_bs = 0; g.c_bs = (int64_t)M * K; g.nbatch = S;
+  g.inner = B; g.inner_step = S; g.a_is = dy_bs; g.b_is = x_bs;
+  const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
+  hipLaunchKernelGGL((pw_gemm_kernel<true, true>), dim3(grid), dim3(256), 0, st, g);
+  if (S > 1) {
+    const int64_t n = (int64_t)M * K;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, S);
+  }
+  PD_CHECK_LAUNCH("pw_gemm_wgrad");
+  return 0;
+}

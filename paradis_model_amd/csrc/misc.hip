@@ -1,0 +1,371 @@
+// a9 GlobalBias map (reference model/blocks.py:188-196) and the elementwise / reduction glue of
+// the ADR layer step (reference model/paradis.py:239-253): activation, gated blend, bias grads.
+// All HBM-bound streaming kernels (float4 where alignment allows).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+inline int stream_blocks(int64_t n_items) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>((n_items + 255) / 256, 256 * 16));
+}
+
+// ------------------------------------------------------------------ global bias map, forward
+__global__ void __launch_bounds__(256)
+gbias_m8_kernel(const float* __restrict__ A, const float* __restrict__ U, const float* __restrict__ V,
+                float* __restrict__ m8, int Cin, int R, int H, int W) {
+  const int64_t total = (int64_t)Cin * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int w = (int)(idx % W), h = (int)((idx / W) % H), c = (int)(idx / ((int64_t)W * H));
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
+    m8[idx] = acc;
+  }
+}
+
+// out[o,p] = sum_c Wm[o*ldo + c*ldc] * in[c,p]      (projection and its transpose)
+__global__ void __launch_bounds__(256)
+small_mix_kernel(const float* __restrict__ Wm, int ldo, int ldc, const float* __restrict__ in,
+                 float* __restrict__ out, int Cout, int Cin, int64_t P) {
+  const int64_t total = (int64_t)Cout * P;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t p = idx % P;
+    const int o = (int)(idx / P);
+    float acc = 0.f;
+    for (int c = 0; c < Cin; ++c) acc += Wm[(int64_t)o * ldo + (int64_t)c * ldc] * in[(int64_t)c * P + p];
+    out[idx] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ global bias map, backward
+// gPw[o,c] = sum_p gmap[o,p] * m8[c,p]; one workgroup per (o,c)
+__global__ void __launch_bounds__(256)
+gbias_gpw_kernel(const float* __restrict__ gmap, const float* __restrict__ m8,
+                 float* __restrict__ gPw, int Cin, int64_t P) {
+  __shared__ float red[4];
+  const int o = blockIdx.x / Cin, c = blockIdx.x - o * Cin;
+  float acc = 0.f;
+  for (int64_t p = threadIdx.x; p < P; p += 256) acc += gmap[(int64_t)o * P + p] * m8[(int64_t)c * P + p];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) gPw[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// T1[c,r,h] = sum_w gm8[c,h,w] V[r,w]   (one wave per output)
+__global__ void __launch_bounds__(256)
+gbias_t1_kernel(const float* __restrict__ gm8, const float* __restrict__ V, float* __restrict__ T1,
+                int Cin, int R, int H, int W) {
+  const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (wid >= (int64_t)Cin * R * H) return;
+  const int h = (int)(wid % H), r = (int)((wid / H) % R), c = (int)(wid / ((int64_t)H * R));
+  float acc = 0.f;
+  for (int w = threadIdx.x & 63; w < W; w += 64) acc += gm8[((int64_t)c * H + h) * W + w] * V[r * W + w];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) T1[wid] = acc;
+}
+
+// T2[c,r,w] = sum_h gm8[c,h,w] U[r,h]
+__global__ void __launch_bounds__(256)
+gbias_t2_kernel(const float* __restrict__ gm8, const float* __restrict__ U, float* __restrict__ T2,
+                int Cin, int R, int H, int W) {
+  const int64_t total = (int64_t)Cin * R * W;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int w = (int)(idx % W), r = (int)((idx / W) % R), c = (int)(idx / ((int64_t)W * R));
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc += gm8[((int64_t)c * H + h) * W + w] * U[r * H + h];
+    T2[idx] = acc;
+  }
+}
+
+// gA[c,r] = sum_h T1[c,r,h] U[r,h];  gU[r,h] = sum_c T1[c,r,h] A[c,r];  gV[r,w] = sum_c T2[c,r,w] A[c,r]
+__global__ void __launch_bounds__(256)
+gbias_finish_kernel(const float* __restrict__ T1, const float* __restrict__ T2,
+                    const float* __restrict__ A, const float* __restrict__ U,
+                    float* __restrict__ gA, float* __restrict__ gU, float* __restrict__ gV, int Cin,
+                    int R, int H, int W) {
+  const int nA = Cin * R, nU = R * H, nV = R * W;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < nA) {
+    const int c = idx / R, r = idx - c * R;
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc += T1[((int64_t)c * R + r) * H + h] * U[r * H + h];
+    gA[idx] = acc;
+  } else if (idx < nA + nU) {
+    const int j = idx - nA, r = j / H, h = j - r * H;
+    float acc = 0.f;
+    for (int c = 0; c < Cin; ++c) acc += T1[((int64_t)c * R + r) * H + h] * A[c * R + r];
+    gU[j] = acc;
+  } else if (idx < nA + nU + nV) {
+    const int j = idx - nA - nU, r = j / W, w = j - r * W;
+    float acc = 0.f;
+    for (int c = 0; c < Cin; ++c) acc += T2[((int64_t)c * R + r) * W + w] * A[c * R + r];
+    gV[j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ activation
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+act_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ out,
+           int64_t n, int act, bool vec) {
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 o;
+      if (BWD) {
+        const float4 g = reinterpret_cast<const float4*>(gy)[i];
+        o = make_float4(g.x * act_grad(v.x, act), g.y * act_grad(v.y, act), g.z * act_grad(v.z, act),
+                        g.w * act_grad(v.w, act));
+      } else {
+        o = make_float4(act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act));
+      }
+      reinterpret_cast<float4*>(out)[i] = o;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+      out[i] = BWD ? gy[i] * act_grad(x[i], act) : act_apply(x[i], act);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n,
+           bool vec) {
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+      reinterpret_cast<float4*>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+      y[i] = a[i] + b[i];
+  }
+}
+
+// y[b, i] = x[b, i] + m[i]   (standalone GlobalBias.forward, reference model/blocks.py:196)
+__global__ void __launch_bounds__(256)
+add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y,
+                 int64_t per, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    y[i] = x[i] + m[i % per];
+}
+
+// ------------------------------------------------------------------ gated blend
+__global__ void __launch_bounds__(256)
+gated_blend_fwd_kernel(const float* __restrict__ h, const float* __restrict__ adv,
+                       const float* __restrict__ alpha, float* __restrict__ out, int C, int P) {
+  // one workgroup per (b,c) plane
+  const int c = blockIdx.x % C;
+  const float g = 1.0f / (1.0f + expf(-alpha[c]));
+  const int64_t base = (int64_t)blockIdx.x * P;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float hv = h[base + p];
+    out[base + p] = hv + g * (adv[base + p] - hv);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gated_blend_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ h,
+                       const float* __restrict__ adv, const float* __restrict__ alpha,
+                       float* __restrict__ gh, float* __restrict__ gadv, float* __restrict__ partial,
+                       int C, int P) {
+  __shared__ float red[4];
+  const int c = blockIdx.x % C;
+  const float g = 1.0f / (1.0f + expf(-alpha[c]));
+  const int64_t base = (int64_t)blockIdx.x * P;
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float go = gout[base + p];
+    gh[base + p] = (1.0f - g) * go;
+    gadv[base + p] = g * go;
+    acc += go * (adv[base + p] - h[base + p]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256)
+gated_blend_finish(const float* __restrict__ partial, const float* __restrict__ alpha,
+                   float* __restrict__ galpha, int B, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += partial[(int64_t)b * C + c];
+  const float g = 1.0f / (1.0f + expf(-alpha[c]));
+  galpha[c] = s * g * (1.0f - g);
+}
+
+// ------------------------------------------------------------------ bias / bias-map gradients
+// grid (C, pchunks): gmap[c,p] = sum_b dz[b,c,p];  gbias[c] += sum over the chunk
+__global__ void __launch_bounds__(256)
+bias_grads_kernel(const float* __restrict__ dz, float* __restrict__ gmap, float* __restrict__ gbias,
+                  int B, int C, int P, int64_t bs, int pchunks) {
+  __shared__ float red[4];
+  const int c = blockIdx.x / pchunks, chunk = blockIdx.x - c * pchunks;
+  float acc = 0.f;
+  for (int p = chunk * 256 + threadIdx.x; p < P; p += pchunks * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dz[(int64_t)b * bs + (int64_t)c * P + p];
+    if (gmap) gmap[(int64_t)c * P + p] = s;
+    acc += s;
+  }
+  if (!gbias) return;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&gbias[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int paradis_global_bias_map_fwd(const float* A, const float* U, const float* V,
+                                           const float* Pw, float* m8, float* map, int Cin, int Co,
+                                           int R, int H, int W, void* stream) {
+  PD_REQUIRE(Cin >= 1 && Co >= 1 && R >= 1 && H >= 1 && W >= 1, "global_bias_map_fwd: bad shape");
+  PD_REQUIRE(Pw != nullptr || Cin == Co, "global_bias_map_fwd: projection required when Cin != Co");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t P = (int64_t)H * W;
+  float* m8_dst = Pw ? m8 : map;
+  hipLaunchKernelGGL(gbias_m8_kernel, dim3(stream_blocks(Cin * P)), dim3(256), 0, st, A, U, V, m8_dst, Cin,
+                     R, H, W);
+  if (Pw)
+    hipLaunchKernelGGL(small_mix_kernel, dim3(stream_blocks(Co * P)), dim3(256), 0, st, Pw, Cin, 1, m8, map,
+                       Co, Cin, P);
+  PD_CHECK_LAUNCH("global_bias_map_fwd");
+  return 0;
+}
+
+extern "C" size_t paradis_global_bias_map_bwd_ws_bytes(int Cin, int Co, int R, int H, int W) {
+  (void)Co;
+  return ((size_t)Cin * H * W + (size_t)Cin * R * H + (size_t)Cin * R * W) * sizeof(float) + 256;
+}
+
+extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, const float* U,
+                                           const float* V, const float* Pw, const float* m8, float* gA,
+                                           float* gU, float* gV, float* gPw, int Cin, int Co, int R,
+                                           int H, int W, void* workspace, void* stream) {
+  PD_REQUIRE(Cin >= 1 && Co >= 1 && R >= 1 && H >= 1 && W >= 1, "global_bias_map_bwd: bad shape");
+  PD_REQUIRE(workspace != nullptr, "global_bias_map_bwd: workspace required");
+  PD_REQUIRE(Pw != nullptr || Cin == Co, "global_bias_map_bwd: projection required when Cin != Co");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t P = (int64_t)H * W;
+  float* gm8 = (float*)workspace;
+  float* T1 = gm8 + (size_t)Cin * P;
+  float* T2 = T1 + (size_t)Cin * R * H;
+  const float* gm8_src = gmap;
+  if (Pw) {
+    PD_REQUIRE(m8 != nullptr && gPw != nullptr, "global_bias_map_bwd: m8/gPw required with projection");
+    hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
+    // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
+    hipLaunchKernelGGL(small_mix_kernel, dim3(stream_blocks(Cin * P)), dim3(256), 0, st, Pw, 1, Cin, gmap,
+                       gm8, Cin, Co, P);
+    gm8_src = gm8;
+  }
+  const int64_t nwaves = (int64_t)Cin * R * H;
+  hipLaunchKernelGGL(gbias_t1_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, st,
+                     gm8_src, V, T1, Cin, R, H, W);
+  hipLaunchKernelGGL(gbias_t2_kernel, dim3(stream_blocks((int64_t)Cin * R * W)), dim3(256), 0, st, gm8_src,
+                     U, T2, Cin, R, H, W);
+  const int nfin = Cin * R + R * H + R * W;
+  hipLaunchKernelGGL(gbias_finish_kernel, dim3((nfin + 255) / 256), dim3(256), 0, st, T1, T2, A, U, gA, gU,
+                     gV, Cin, R, H, W);
+  PD_CHECK_LAUNCH("global_bias_map_bwd");
+  return 0;
+}
+
+extern "C" int paradis_act_fwd(const float* x, float* y, int64_t n, int act, void* stream) {
+  PD_REQUIRE(n >= 0 && act >= 0 && act <= 2, "act_fwd: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(y);
+  hipLaunchKernelGGL(act_kernel<false>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
+                     (hipStream_t)stream, nullptr, x, y, n, act, vec);
+  PD_CHECK_LAUNCH("act_fwd");
+  return 0;
+}
+
+extern "C" int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act,
+                               void* stream) {
+  PD_REQUIRE(n >= 0 && act >= 0 && act <= 2, "act_bwd: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
+  hipLaunchKernelGGL(act_kernel<true>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
+                     (hipStream_t)stream, gy, x, gx, n, act, vec);
+  PD_CHECK_LAUNCH("act_bwd");
+  return 0;
+}
+
+extern "C" int paradis_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  PD_REQUIRE(n >= 0, "add: bad arguments");
+  if (n == 0) return 0;
+  const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(b) && aligned16(y);
+  hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0, (hipStream_t)stream,
+                     a, b, y, n, vec);
+  PD_CHECK_LAUNCH("add");
+  return 0;
+}
+
+extern "C" int paradis_gated_blend_fwd(const float* h, const float* adv, const float* alpha,
+                                       float* out, int B, int C, int P, void* stream) {
+  PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "gated_blend_fwd: bad shape");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(gated_blend_fwd_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0,
+                     (hipStream_t)stream, h, adv, alpha, out, C, P);
+  PD_CHECK_LAUNCH("gated_blend_fwd");
+  return 0;
+}
+
+extern "C" size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P) {
+  (void)P;
+  return (size_t)std::max(B, 1) * C * sizeof(float) + 256;
+}
+
+extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv,
+                                       const float* alpha, float* gh, float* gadv, float* galpha, int B,
+                                       int C, int P, void* workspace, void* stream) {
+  PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "gated_blend_bwd: bad shape");
+  PD_REQUIRE(workspace != nullptr, "gated_blend_bwd: workspace required");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  if (B > 0)
+    hipLaunchKernelGGL(gated_blend_bwd_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0, st, gout, h,
+                       adv, alpha, gh, gadv, partial, C, P);
+  hipLaunchKernelGGL(gated_blend_finish, dim3((C + 255) / 256), dim3(256), 0, st, partial, alpha, galpha, B, C);
+  PD_CHECK_LAUNCH("gated_blend_bwd");
+  return 0;
+}
+
+extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
+                                  int64_t dz_bs, void* stream) {
+  PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "bias_grads: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (gbias && hipMemsetAsync(gbias, 0, (size_t)C * sizeof(float), st) != hipSuccess) {
+    paradis_set_error("bias_grads: memset failed");
+    return 2;
+  }
+  if (!gmap && !gbias) return 0;
+  int pchunks = std::max(1, std::min((P + 255) / 256, std::max(1, 2048 / C)));
+  hipLaunchKernelGGL(bias_grads_kernel, dim3((unsigned)((int64_t)C * pchunks)), dim3(256), 0, st, dz, gmap,
+                     gbias, B, C, P, dz_bs, pchunks);
+  PD_CHECK_LAUNCH("bias_grads");
+  return 0;
+}
+
+extern "C" int paradis_add_bcast(const float* x, const float* m, float* y, int64_t per_sample, int B,
+                                 void* stream) {
+  PD_REQUIRE(per_sample >= 1 && B >= 0, "add_bcast: bad arguments");
+  if (B == 0) return 0;
+  const int64_t total = per_sample * B;
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, m,
+                     y, per_sample, total);
+  PD_CHECK_LAUNCH("add_bcast");
+  return 0;
+}

@@ -1,0 +1,260 @@
+// a8: ChannelNorm (reference model/blocks.py:118-134): per-pixel normalisation over channels with
+// the unbiased variance, y = (x - mean) * (var + eps)^-1/2 * w[c] + b[c].
+// Layout [B, C, P]: the reduction runs over C with stride P, so lanes are laid along the pixel
+// axis (coalesced 256-B rows) and waves split the channel axis.  HBM-bound: 8 B per (c, pixel)
+// forward.  The input may be the virtual concatenation of two tensors (reference
+// model/paradis.py:249, cat([hidden, hidden_static])) so the cat is never materialised.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+constexpr int NPX = 64;  // pixels per workgroup (one wave width)
+
+struct CatSrc {
+  const float* x1; const float* x2;
+  int C1, C2;
+  int64_t bs1, bs2;
+  __device__ __forceinline__ const float* row(int b, int c, int P) const {
+    return c < C1 ? x1 + (int64_t)b * bs1 + (int64_t)c * P : x2 + (int64_t)b * bs2 + (int64_t)(c - C1) * P;
+  }
+};
+
+// 1024 threads = 16 waves; wave g owns channels c = g + 16*i.  MAXV values per thread are kept
+// in registers so x is read from HBM exactly once (MAXV = 0: three passes, any C).
+template <int MAXV>
+__global__ void __launch_bounds__(1024)
+channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
+                        float* __restrict__ y, float* __restrict__ mean_out,
+                        float* __restrict__ rstd_out, int P, int tiles, float eps) {
+  __shared__ float red[16][NPX];
+  __shared__ float stat[2][NPX];
+  const int C = s.C1 + s.C2;
+  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPX;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = p0 + lane;
+  const bool live = p < P;
+  float vals[MAXV > 0 ? MAXV : 1];
+
+  float sum = 0.f;
+  if (MAXV > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = grp + 16 * i;
+      vals[i] = (live && c < C) ? s.row(b, c, P)[p] : 0.f;
+      sum += vals[i];
+    }
+  } else {
+    for (int c = grp; c < C; c += 16) sum += live ? s.row(b, c, P)[p] : 0.f;
+  }
+  red[grp][lane] = sum;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    stat[0][lane] = t / (float)C;
+  }
+  __syncthreads();
+  const float mean = stat[0][lane];
+  float sq = 0.f;
+  if (MAXV > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = grp + 16 * i;
+      const float d = (c < C) ? vals[i] - mean : 0.f;
+      sq += d * d;
+    }
+  } else {
+    for (int c = grp; c < C; c += 16) {
+      const float d = live ? s.row(b, c, P)[p] - mean : 0.f;
+      sq += d * d;
+    }
+  }
+  __syncthreads();
+  red[grp][lane] = sq;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    const float var = t / (float)(C - 1);
+    const float r = 1.0f / sqrtf(var + eps);
+    stat[1][lane] = r;
+    if (live) {
+      mean_out[(int64_t)b * P + p] = mean;
+      rstd_out[(int64_t)b * P + p] = r;
+    }
+  }
+  __syncthreads();
+  const float rstd = stat[1][lane];
+  if (!live) return;
+  float* yb = y + (int64_t)b * C * P + p;
+  if (MAXV > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = grp + 16 * i;
+      if (c < C) yb[(int64_t)c * P] = (vals[i] - mean) * rstd * w[c] + bias[c];
+    }
+  } else {
+    for (int c = grp; c < C; c += 16)
+      yb[(int64_t)c * P] = (s.row(b, c, P)[p] - mean) * rstd * w[c] + bias[c];
+  }
+}
+
+// gx = rstd * ( g*w - mean_c(g*w) - xhat * sum_c(g*w*xhat)/(C-1) )
+__global__ void __launch_bounds__(1024)
+channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
+                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                           float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
+                           int64_t gbs2, int P, int tiles) {
+  __shared__ float red[2][16][NPX];
+  __shared__ float stat[2][NPX];
+  const int C = s.C1 + s.C2;
+  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPX;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = p0 + lane;
+  const bool live = p < P;
+  const float mean = live ? mean_in[(int64_t)b * P + p] : 0.f;
+  const float rstd = live ? rstd_in[(int64_t)b * P + p] : 0.f;
+  const float* gyb = gy + (int64_t)b * C * P + p;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = grp; c < C; c += 16) {
+    if (live) {
+      const float gh = gyb[(int64_t)c * P] * w[c];
+      const float xh = (s.row(b, c, P)[p] - mean) * rstd;
+      s1 += gh;
+      s2 += gh * xh;
+    }
+  }
+  red[0][grp][lane] = s1;
+  red[1][grp][lane] = s2;
+  __syncthreads();
+  if (grp < 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[grp][k][lane];
+    stat[grp][lane] = t;
+  }
+  __syncthreads();
+  if (!live) return;
+  const float m1 = stat[0][lane] / (float)C, m2 = stat[1][lane] / (float)(C - 1);
+  for (int c = grp; c < C; c += 16) {
+    const float gh = gyb[(int64_t)c * P] * w[c];
+    const float xh = (s.row(b, c, P)[p] - mean) * rstd;
+    const float v = rstd * (gh - m1 - xh * m2);
+    if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v;
+    else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
+  }
+}
+
+// gw[c] = sum_{b,p} gy * xhat ; gb[c] = sum_{b,p} gy.  grid (C, chunks): partial[c][chunk][2]
+__global__ void __launch_bounds__(256)
+channel_norm_bwd_dw_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ mean_in,
+                           const float* __restrict__ rstd_in, float* __restrict__ partial, int B,
+                           int P, int chunks) {
+  __shared__ float red[2][4];
+  const int C = s.C1 + s.C2;
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x - c * chunks;
+  const int64_t total = (int64_t)B * P;
+  float aw = 0.f, ab = 0.f;
+  for (int64_t i = (int64_t)chunk * 256 + threadIdx.x; i < total; i += (int64_t)chunks * 256) {
+    const int b = (int)(i / P), p = (int)(i - (int64_t)b * P);
+    const float g = gy[((int64_t)b * C + c) * P + p];
+    const float xh = (s.row(b, c, P)[p] - mean_in[i]) * rstd_in[i];
+    aw += g * xh;
+    ab += g;
+  }
+  aw = wave_sum(aw);
+  ab = wave_sum(ab);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = aw; red[1][wave] = ab; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    partial[((int64_t)c * chunks + chunk) * 2 + threadIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+channel_norm_bwd_finish(const float* __restrict__ partial, float* __restrict__ gw,
+                        float* __restrict__ gb, int C, int chunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    a += partial[((int64_t)c * chunks + k) * 2];
+    b += partial[((int64_t)c * chunks + k) * 2 + 1];
+  }
+  gw[c] = a;
+  gb[c] = b;
+}
+
+int dw_chunks(int B, int C, int P) {
+  const int64_t total = (int64_t)B * P;
+  int chunks = (2048 + C - 1) / C;
+  chunks = (int)std::min<int64_t>(chunks, (total + 255) / 256);
+  return std::max(chunks, 1);
+}
+
+int check_norm(const char* name, int B, int C1, int C2, int P) {
+  PD_REQUIRE(B >= 0 && C1 >= 1 && C2 >= 0 && P >= 1, "%s: bad shape", name);
+  PD_REQUIRE(C1 + C2 >= 2, "%s: needs at least two channels (unbiased variance)", name);
+  PD_REQUIRE((int64_t)B * ((P + NPX - 1) / NPX) < (1ll << 31), "%s: too large", name);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
+                                        const float* b, float* y, float* mean, float* rstd, int B,
+                                        int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps,
+                                        void* stream) {
+  if (int e = check_norm("channel_norm_fwd", B, C1, C2, P)) return e;
+  PD_REQUIRE(C2 == 0 || x2 != nullptr, "channel_norm_fwd: x2 missing");
+  if (B == 0) return 0;
+  CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
+  const int tiles = (P + NPX - 1) / NPX, C = C1 + C2;
+  const dim3 grid((unsigned)((int64_t)B * tiles)), block(1024);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 16 * 8)
+    hipLaunchKernelGGL(channel_norm_fwd_kernel<8>, grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+  else if (C <= 16 * 72)
+    hipLaunchKernelGGL(channel_norm_fwd_kernel<72>, grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+  else
+    hipLaunchKernelGGL(channel_norm_fwd_kernel<0>, grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+  PD_CHECK_LAUNCH("channel_norm_fwd");
+  return 0;
+}
+
+extern "C" size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P) {
+  return (size_t)C * dw_chunks(std::max(B, 1), C, P) * 2 * sizeof(float) + 256;
+}
+
+extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2,
+                                        const float* w, const float* mean, const float* rstd,
+                                        float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
+                                        int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
+                                        int64_t gx2_bs, void* workspace, void* stream) {
+  if (int e = check_norm("channel_norm_bwd", B, C1, C2, P)) return e;
+  PD_REQUIRE(workspace != nullptr, "channel_norm_bwd: workspace required");
+  const int C = C1 + C2;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    hipMemsetAsync(gw, 0, C * sizeof(float), st);
+    hipMemsetAsync(gb, 0, C * sizeof(float), st);
+    return 0;
+  }
+  CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
+  const int tiles = (P + NPX - 1) / NPX;
+  hipLaunchKernelGGL(channel_norm_bwd_dx_kernel, dim3((unsigned)((int64_t)B * tiles)), dim3(1024), 0, st,
+                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, P, tiles);
+  const int chunks = dw_chunks(B, C, P);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(channel_norm_bwd_dw_kernel, dim3(C * chunks), dim3(256), 0, st, gy, s, mean, rstd,
+                     partial, B, P, chunks);
+  hipLaunchKernelGGL(channel_norm_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, st, partial, gw, gb, C,
+                     chunks);
+  PD_CHECK_LAUNCH("channel_norm_bwd");
+  return 0;
+}

@@ -1,0 +1,427 @@
+// a7 / a11 / a14: stencils on the virtual geocyclic halo (no padded tensor is materialised).
+//
+//   dwconv_geo   : depthwise k x k (reference model/blocks.py:101-113, model/paradis.py:189-190)
+//   avgpool_geo  : 5x5 box mean with stride (reference model/blocks.py:57-71)
+//   upsample_lonp: lon-periodic bilinear, align_corners=True (reference model/paradis.py:208-220)
+//
+// All HBM-bound: depthwise reads 4 B + writes 4 B per (channel, point) (+ halo re-reads served
+// by L2); tiles of 32x64 outputs are staged once in LDS including the halo.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 32, TW = 64;  // output tile; 256 threads: lane -> column, wave -> 8-row strip
+constexpr int RPT = 8;           // rows per thread
+
+template <int K, bool GEO>
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int H, int W,
+                                           int ty0, int tx0) {
+  constexpr int P = (K - 1) / 2, LW = TW + K - 1, LH = TH + K - 1;
+  for (int i = threadIdx.x; i < LH * LW; i += 256) {
+    const int lr = i / LW, lc = i - lr * LW;
+    const int ii = ty0 + lr - P, jj = tx0 + lc - P;
+    float val = 0.f;
+    if (GEO) {
+      if (ii < H + P && jj < W + P) {
+        int r, c;
+        geo_src(ii, jj, H, W, r, c);
+        val = src[(int64_t)r * W + c];
+      }
+    } else {
+      if (ii >= 0 && ii < H && jj >= 0 && jj < W) val = src[(int64_t)ii * W + jj];
+    }
+    tile[i] = val;
+  }
+}
+
+// FLIP=false: y = w (*) geo-padded x  (+bias).   FLIP=true: self-alias part of the data gradient.
+template <int K, bool FLIP>
+__device__ __forceinline__ void tile_stencil(const float* tile, const float* __restrict__ wc,
+                                             float (&acc)[RPT]) {
+  constexpr int LW = TW + K - 1;
+  const int x = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RPT;
+  float w[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) w[i] = wc[FLIP ? (K * K - 1 - i) : i];
+#pragma unroll
+  for (int o = 0; o < RPT; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < RPT + K - 1; ++rr) {
+    float val[K];
+#pragma unroll
+    for (int b = 0; b < K; ++b) val[b] = tile[(r0 + rr) * LW + x + b];
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      const int o = rr - a;
+      if (o >= 0 && o < RPT) {
+#pragma unroll
+        for (int b = 0; b < K; ++b) acc[o] += w[a * K + b] * val[b];
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                      const float* __restrict__ bias, float* __restrict__ y, int C, int H, int W,
+                      int tiles_x, int tiles) {
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  const int64_t plane = blockIdx.x / tiles;
+  const int t = blockIdx.x - plane * tiles;
+  const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+  const int c = plane % C;
+  stage_tile<K, true>(tile, x + plane * (int64_t)H * W, H, W, ty0, tx0);
+  __syncthreads();
+  float acc[RPT];
+  tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
+  const float bv = bias ? bias[c] : 0.f;
+  const int xx = tx0 + (threadIdx.x & 63), r0 = ty0 + (threadIdx.x >> 6) * RPT;
+  if (xx < W) {
+    float* yp = y + plane * (int64_t)H * W;
+#pragma unroll
+    for (int o = 0; o < RPT; ++o)
+      if (r0 + o < H) yp[(int64_t)(r0 + o) * W + xx] = acc[o] + bv;
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                        float* __restrict__ gx, int C, int H, int W, int tiles_x, int tiles) {
+  constexpr int P = (K - 1) / 2;
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  const int64_t plane = blockIdx.x / tiles;
+  const int t = blockIdx.x - plane * tiles;
+  const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+  const int c = plane % C;
+  const float* g = gy + plane * (int64_t)H * W;
+  const float* wc = w + (int64_t)c * K * K;
+  stage_tile<K, false>(tile, g, H, W, ty0, tx0);
+  __syncthreads();
+  float acc[RPT];
+  tile_stencil<K, true>(tile, wc, acc);
+  const int xx = tx0 + (threadIdx.x & 63), r0 = ty0 + (threadIdx.x >> 6) * RPT;
+  if (xx >= W) return;
+  float* gp = gx + plane * (int64_t)H * W;
+#pragma unroll
+  for (int o = 0; o < RPT; ++o) {
+    const int yy = r0 + o;
+    if (yy >= H) break;
+    float extra = 0.f;
+    const bool border = (yy >= 1 && yy <= P) || (yy >= H - 1 - P && yy <= H - 2) || xx < P || xx >= W - P;
+    if (border) {
+      // halo aliases of (yy,xx): transposed stencil of the zero-extended cotangent at each alias
+      geo_for_each_alias(yy, xx, H, W, P, [&](int ii, int jj) {
+        if (ii == yy && jj == xx) return;
+        for (int a = 0; a < K; ++a) {
+          const int sy = ii + P - a;
+          if (sy < 0 || sy >= H) continue;
+          for (int b = 0; b < K; ++b) {
+            const int sx = jj + P - b;
+            if (sx >= 0 && sx < W) extra += wc[a * K + b] * g[(int64_t)sy * W + sx];
+          }
+        }
+      });
+    }
+    gp[(int64_t)yy * W + xx] = acc[o] + extra;
+  }
+}
+
+// partial[c][chunk][K*K (+1 for bias)] ; items of a channel = (batch n, tile t)
+template <int K>
+__global__ void __launch_bounds__(256)
+dwconv_geo_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                        float* __restrict__ partial, int B, int C, int H, int W, int tiles_x,
+                        int tiles, int chunks) {
+  constexpr int LW = TW + K - 1, NW = K * K + 1;
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  __shared__ float red[4][NW];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x - c * chunks;
+  const int items = B * tiles;
+  const int xl = threadIdx.x & 63, wave = threadIdx.x >> 6, r0l = wave * RPT;
+  float acc[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+  float gsum = 0.f;
+  for (int item = chunk; item < items; item += chunks) {
+    const int n = item / tiles, t = item - n * tiles;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+    const int64_t plane = (int64_t)n * C + c;
+    __syncthreads();
+    stage_tile<K, true>(tile, x + plane * (int64_t)H * W, H, W, ty0, tx0);
+    __syncthreads();
+    float g[RPT];
+    const int xx = tx0 + xl;
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) {
+      const int yy = ty0 + r0l + o;
+      g[o] = (xx < W && yy < H) ? gy[plane * (int64_t)H * W + (int64_t)yy * W + xx] : 0.f;
+      gsum += g[o];
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT + K - 1; ++rr) {
+      float val[K];
+#pragma unroll
+      for (int b = 0; b < K; ++b) val[b] = tile[(r0l + rr) * LW + xl + b];
+#pragma unroll
+      for (int a = 0; a < K; ++a) {
+        const int o = rr - a;
+        if (o >= 0 && o < RPT) {
+#pragma unroll
+          for (int b = 0; b < K; ++b) acc[a * K + b] += g[o] * val[b];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) {
+    float s = wave_sum(acc[i]);
+    if (xl == 0) red[wave][i] = s;
+  }
+  {
+    float s = wave_sum(gsum);
+    if (xl == 0) red[wave][K * K] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NW) {
+    float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    partial[((int64_t)c * chunks + chunk) * NW + threadIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+dwconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ gw,
+                    float* __restrict__ gbias, int C, int KK, int chunks) {
+  const int NW = KK + 1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= C * NW) return;
+  const int c = idx / NW, i = idx - c * NW;
+  float s = 0.f;
+  for (int ch = 0; ch < chunks; ++ch) s += partial[((int64_t)c * chunks + ch) * NW + i];
+  if (i < KK) gw[(int64_t)c * KK + i] = s;
+  else if (gbias) gbias[c] = s;
+}
+
+// ---------------------------------------------------------------------------- avgpool
+__global__ void __launch_bounds__(256)
+avgpool_geo_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t planes, int H,
+                       int W, int Ho, int Wo, int s) {
+  const int64_t per = (int64_t)Ho * Wo, total = planes * per;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t plane = idx / per;
+    const int rem = (int)(idx - plane * per);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float* xp = x + plane * (int64_t)H * W;
+    float sum = 0.f;
+    for (int a = 0; a < 5; ++a)
+      for (int b = 0; b < 5; ++b) {
+        int r, c;
+        geo_src(oy * s + a - 2, ox * s + b - 2, H, W, r, c);
+        sum += xp[(int64_t)r * W + c];
+      }
+    y[idx] = sum / 25.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+avgpool_geo_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int64_t planes, int H,
+                       int W, int Ho, int Wo, int s) {
+  const int64_t per = (int64_t)H * W, total = planes * per;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t plane = idx / per;
+    const int rem = (int)(idx - plane * per);
+    const int yy = rem / W, xx = rem - yy * W;
+    const float* g = gy + plane * (int64_t)Ho * Wo;
+    float acc = 0.f;
+    geo_for_each_alias(yy, xx, H, W, 2, [&](int ii, int jj) {
+      const int r = ii + 2, c = jj + 2;  // padded coordinates
+      // windows [o*s, o*s+4] covering r / c
+      int oy_lo = (r - 4 + s - 1) / s; if (r - 4 < 0) oy_lo = 0;
+      int ox_lo = (c - 4 + s - 1) / s; if (c - 4 < 0) ox_lo = 0;
+      const int oy_hi = min(r / s, Ho - 1), ox_hi = min(c / s, Wo - 1);
+      for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += g[(int64_t)oy * Wo + ox];
+    });
+    gx[idx] = acc / 25.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------- upsample
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_index(int o, int in_size, int out_size) {
+  Lerp L;
+  if (in_size == out_size) { L.i0 = L.i1 = o; L.l0 = 1.f; L.l1 = 0.f; return L; }
+  const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  const float real = scale * (float)o;
+  L.i0 = (int)real;
+  L.i1 = L.i0 + ((L.i0 < in_size - 1) ? 1 : 0);
+  L.l1 = fminf(fmaxf(real - (float)L.i0, 0.f), 1.f);
+  L.l0 = 1.f - L.l1;
+  return L;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+upsample_lonp_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t planes, int Hc,
+                     int Wc, int H, int W) {
+  // forward: src = coarse x, dst = fine y.   backward: src = gy (fine), dst = gx (coarse, zeroed)
+  const int64_t per = (int64_t)H * W, total = planes * per;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t plane = idx / per;
+    const int rem = (int)(idx - plane * per);
+    const int h = rem / W, w = rem - h * W;
+    const Lerp lh = lerp_index(h, Hc, H);
+    const Lerp lw = lerp_index(w, Wc + 1, W + 1);  // periodic column appended on both sides
+    const int c0 = lw.i0 >= Wc ? lw.i0 - Wc : lw.i0, c1 = lw.i1 >= Wc ? lw.i1 - Wc : lw.i1;
+    const int64_t base = plane * (int64_t)Hc * Wc;
+    if (!BWD) {
+      const float* xp = src + base;
+      const float top = lw.l0 * xp[(int64_t)lh.i0 * Wc + c0] + lw.l1 * xp[(int64_t)lh.i0 * Wc + c1];
+      const float bot = lw.l0 * xp[(int64_t)lh.i1 * Wc + c0] + lw.l1 * xp[(int64_t)lh.i1 * Wc + c1];
+      dst[idx] = lh.l0 * top + lh.l1 * bot;
+    } else {
+      const float g = src[idx];
+      float* gp = dst + base;
+      atomicAdd(&gp[(int64_t)lh.i0 * Wc + c0], g * lh.l0 * lw.l0);
+      atomicAdd(&gp[(int64_t)lh.i0 * Wc + c1], g * lh.l0 * lw.l1);
+      atomicAdd(&gp[(int64_t)lh.i1 * Wc + c0], g * lh.l1 * lw.l0);
+      atomicAdd(&gp[(int64_t)lh.i1 * Wc + c1], g * lh.l1 * lw.l1);
+    }
+  }
+}
+
+int check_dw(const char* name, int B, int C, int H, int W, int k) {
+  PD_REQUIRE(B >= 0 && C >= 1 && H >= 2 && W >= 2, "%s: bad shape", name);
+  PD_REQUIRE(k == 3 || k == 5 || k == 7, "%s: kernel size %d not supported (3,5,7)", name, k);
+  PD_REQUIRE(W % 2 == 0, "%s: Number of longitude points must be even", name);
+  PD_REQUIRE((k - 1) / 2 <= H - 2 && (k - 1) <= W, "%s: grid %dx%d too small for k=%d", name, H, W, k);
+  PD_REQUIRE((int64_t)B * C * (((H + TH - 1) / TH) * ((W + TW - 1) / TW)) < (1ll << 31), "%s: too large", name);
+  return 0;
+}
+
+int wgrad_chunks(int B, int C, int tiles) {
+  int items = B * tiles;
+  int chunks = (2048 + C - 1) / C;
+  return std::max(1, std::min(chunks, items));
+}
+
+}  // namespace
+
+#define DISPATCH_K(k, CALL)          \
+  switch (k) {                       \
+    case 3: { constexpr int KK = 3; CALL; } break; \
+    case 5: { constexpr int KK = 5; CALL; } break; \
+    default: { constexpr int KK = 7; CALL; } break; \
+  }
+
+extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
+                                      int B, int C, int H, int W, int k, void* stream) {
+  if (int e = check_dw("dwconv_geo_fwd", B, C, H, W, k)) return e;
+  if (B == 0) return 0;
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
+  const unsigned grid = (unsigned)((int64_t)B * C * tiles);
+  DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_fwd_kernel<KK>, dim3(grid), dim3(256), 0,
+                                   (hipStream_t)stream, x, w, bias, y, C, H, W, tx, tiles));
+  PD_CHECK_LAUNCH("dwconv_geo_fwd");
+  return 0;
+}
+
+extern "C" int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx, int B, int C,
+                                        int H, int W, int k, void* stream) {
+  if (int e = check_dw("dwconv_geo_dgrad", B, C, H, W, k)) return e;
+  if (B == 0) return 0;
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
+  const unsigned grid = (unsigned)((int64_t)B * C * tiles);
+  DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_dgrad_kernel<KK>, dim3(grid), dim3(256), 0,
+                                   (hipStream_t)stream, gy, w, gx, C, H, W, tx, tiles));
+  PD_CHECK_LAUNCH("dwconv_geo_dgrad");
+  return 0;
+}
+
+extern "C" size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k) {
+  const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+  return (size_t)C * wgrad_chunks(B, C, tiles) * (k * k + 1) * sizeof(float) + 256;
+}
+
+extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* gw, float* gbias,
+                                        int B, int C, int H, int W, int k, void* workspace,
+                                        void* stream) {
+  if (int e = check_dw("dwconv_geo_wgrad", B, C, H, W, k)) return e;
+  PD_REQUIRE(workspace != nullptr, "dwconv_geo_wgrad: workspace required");
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
+  const int chunks = B == 0 ? 1 : wgrad_chunks(B, C, tiles);
+  float* partial = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_wgrad_kernel<KK>, dim3(C * chunks), dim3(256), 0, st, gy,
+                                   x, partial, B, C, H, W, tx, tiles, chunks));
+  const int n = C * (k * k + 1);
+  hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias,
+                     C, k * k, chunks);
+  PD_CHECK_LAUNCH("dwconv_geo_wgrad");
+  return 0;
+}
+
+static int check_pool(const char* name, int64_t planes, int H, int W, int s) {
+  PD_REQUIRE(planes >= 0 && H >= 4 && W >= 4 && W % 2 == 0, "%s: bad shape %dx%d", name, H, W);
+  PD_REQUIRE(s >= 1, "%s: Coarsening factor must be >=1", name);
+  return 0;
+}
+
+extern "C" int paradis_avgpool_geo_fwd(const float* x, float* y, int64_t planes, int H, int W,
+                                       int stride, void* stream) {
+  if (int e = check_pool("avgpool_geo_fwd", planes, H, W, stride)) return e;
+  if (planes == 0) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t total = planes * Ho * Wo;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+  hipLaunchKernelGGL(avgpool_geo_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y,
+                     planes, H, W, Ho, Wo, stride);
+  PD_CHECK_LAUNCH("avgpool_geo_fwd");
+  return 0;
+}
+
+extern "C" int paradis_avgpool_geo_bwd(const float* gy, float* gx, int64_t planes, int H, int W,
+                                       int stride, void* stream) {
+  if (int e = check_pool("avgpool_geo_bwd", planes, H, W, stride)) return e;
+  if (planes == 0) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t total = planes * H * W;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+  hipLaunchKernelGGL(avgpool_geo_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gy, gx,
+                     planes, H, W, Ho, Wo, stride);
+  PD_CHECK_LAUNCH("avgpool_geo_bwd");
+  return 0;
+}
+
+extern "C" int paradis_upsample_lonp_fwd(const float* x, float* y, int64_t planes, int Hc, int Wc,
+                                         int H, int W, void* stream) {
+  PD_REQUIRE(planes >= 0 && Hc >= 1 && Wc >= 1 && H >= Hc && W >= Wc, "upsample_lonp_fwd: bad shape");
+  if (planes == 0) return 0;
+  const int64_t total = planes * H * W;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+  hipLaunchKernelGGL(upsample_lonp_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y,
+                     planes, Hc, Wc, H, W);
+  PD_CHECK_LAUNCH("upsample_lonp_fwd");
+  return 0;
+}
+
+extern "C" int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc, int Wc,
+                                         int H, int W, void* stream) {
+  PD_REQUIRE(planes >= 0 && Hc >= 1 && Wc >= 1 && H >= Hc && W >= Wc, "upsample_lonp_bwd: bad shape");
+  if (planes == 0) return 0;
+  if (hipMemsetAsync(gx, 0, (size_t)planes * Hc * Wc * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    paradis_set_error("upsample_lonp_bwd: memset failed");
+    return 2;
+  }
+  const int64_t total = planes * H * W;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+  hipLaunchKernelGGL(upsample_lonp_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gy, gx,
+                     planes, Hc, Wc, H, W);
+  PD_CHECK_LAUNCH("upsample_lonp_bwd");
+  return 0;
+}

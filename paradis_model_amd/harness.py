@@ -1,0 +1,166 @@
+"""Host-side callers of the hot path (e): synthetic ERA5-shaped
+batches, the autoregressive training step of the reference's ``LitParadis.training_step``
+(reference ``trainer.py:498-587`` + ``_autoregression_next_input`` ``:710-729``) restated without
+Lightning, and the data-parallel wrapper (one process per GPU, RCCL all-reduce overlapped with
+backward through ``torch.nn.parallel.DistributedDataParallel``).
+
+Everything here is device agnostic plumbing (tensor concatenation, optimiser, collectives); the
+compute is inside the model that is passed in.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+# ---------------------------------------------------------------------------------- grids / data
+GRID_PRESETS = {
+    "5.625deg": (32, 64, False),    # WeatherBench2 64x32 equiangular, no pole rows
+    "1.40625deg": (128, 256, False),
+    "0.25deg": (721, 1440, True),   # with pole rows
+}
+
+
+def make_grids(nlat: int, nlon: int, poles: bool):
+    """(lat_deg[H], lat_grid[H,W], lon_grid[H,W]) in fp32 radians, latitude ascending
+    (reference data/era5_dataset.py:77-81,178-182)."""
+    if poles:
+        lat = torch.linspace(-90.0, 90.0, nlat, dtype=torch.float64)
+    else:
+        d = 180.0 / nlat
+        lat = -90.0 + d / 2 + d * torch.arange(nlat, dtype=torch.float64)
+    lon = torch.arange(nlon, dtype=torch.float64) * (360.0 / nlon)
+    lat32, lon32 = lat.to(torch.float32), lon.to(torch.float32)
+    lg, og = torch.meshgrid(torch.deg2rad(lat32), torch.deg2rad(lon32), indexing="ij")
+    return lat32, lg.contiguous(), og.contiguous()
+
+
+def synthetic_batch(nlat: int, nlon: int, poles: bool, batch: int, steps: int, *, seed: int = 1234,
+                    device="cpu", n_dyn: int = 166, n_out: int = 97, n_forc: int = 10):
+    """ERA5-shaped batch tuple exactly as the reference dataset yields it after collation
+    (reference data/era5_dataset.py:379-382): input [B,1,166,H,W] ~ N(0,1), target [B,S,97,H,W] ~
+    N(0,1), forcings [B,S,H,W,10] ~ U(-1,1), constants [B,1,H,W,10] = 4 random fields, z-scored
+    inverse lon spacing, cos(lat), cos(lon), sin(lon), lat, lon."""
+    g = torch.Generator().manual_seed(seed)
+    _, lg, og = make_grids(nlat, nlon, poles)
+    inp = torch.randn(batch, 1, n_dyn, nlat, nlon, generator=g)
+    tgt = torch.randn(batch, steps, n_out, nlat, nlon, generator=g)
+    forc = torch.rand(batch, steps, nlat, nlon, n_forc, generator=g) * 2 - 1
+    rnd = torch.randn(4, nlat, nlon, generator=g)
+    dlon = math.radians(360.0 / nlon)
+    inv = 1.0 / (2 * torch.arcsin(torch.cos(lg) ** 2 * math.sin(dlon / 2)).clamp_min(1e-12) * 6371)
+    inv = (inv - inv.mean()) / inv.std()
+    const = torch.stack([*rnd, inv, torch.cos(lg), torch.cos(og), torch.sin(og), lg, og])
+    const = const.permute(1, 2, 0).unsqueeze(0).unsqueeze(0).expand(batch, 1, -1, -1, -1).contiguous()
+    return tuple(t.to(device) for t in (inp, tgt, forc, const))
+
+
+# ---------------------------------------------------------------------------------- rollout
+def assemble_model_input(input_data, forcings_step, constants):
+    """cat([input[B,1,166,H,W], forcings[B,1,10,H,W], constants[B,1,10,H,W]], 2).squeeze(1)
+    (reference trainer.py:534-538)."""
+    return torch.cat([input_data, forcings_step, constants], dim=2).squeeze(1)
+
+
+def next_input(model_input, output, num_common: int, n_inputs: int):
+    """Autoregressive channel stack update (reference trainer.py:710-729)."""
+    common = output[:, :num_common]
+    if n_inputs == 1:
+        return common
+    return torch.cat([model_input[:, num_common:num_common * n_inputs], common], dim=1)
+
+
+def rollout_loss(model, loss_fn, batch, *, num_common: int, n_inputs: int, accum: int = 1,
+                 detach_every: Optional[int] = None, keep_outputs: bool = False,
+                 backward: bool = True):
+    """The autoregressive hot loop of ``training_step`` (reference trainer.py:508-576): per step
+    assemble the input, run the model, accumulate ``loss/(S*accum)``, feed the prediction back;
+    ``backward`` at chunk ends (every ``detach_every`` steps and at the last step), detaching the
+    carried input.  Returns (sum of chunk losses as a detached tensor, outputs if requested)."""
+    input_data, true_data, forcings, constant_data = batch
+    constants = constant_data[:, :1].permute(0, 1, 4, 2, 3)
+    forcings = forcings.permute(0, 1, 4, 2, 3)
+    S = true_data.size(1)
+    total = torch.zeros((), device=input_data.device)
+    chunk = 0.0
+    outs = []
+    for step in range(S):
+        mi = assemble_model_input(input_data, forcings[:, step].unsqueeze(1), constants)
+        out = model(mi)
+        if keep_outputs:
+            outs.append(out.detach())
+        chunk = chunk + loss_fn(out, true_data[:, step]) / (S * accum)
+        input_data = next_input(mi, out, num_common, n_inputs).unsqueeze(1)
+        if (detach_every is not None and (step + 1) % detach_every == 0) or step == S - 1:
+            if backward:
+                chunk.backward()
+            total = total + chunk.detach()
+            input_data = input_data.detach()
+            chunk = 0.0
+    return total, outs
+
+
+class TrainStep:
+    """forward(S rollout steps) + ParadisLoss + backward + AdamW, the unit the benchmark times
+    (SURVEY.md section 8d).  AdamW hyper-parameters follow reference trainer.py:327-335."""
+
+    def __init__(self, model, loss_fn, cfg, *, num_common: int = 83, n_inputs: int = 2, fused=None):
+        self.model, self.loss_fn = model, loss_fn
+        self.num_common, self.n_inputs = num_common, n_inputs
+        o = cfg.training.optimizer
+        params = [p for p in model.parameters() if p.requires_grad]
+        use_fused = fused if fused is not None else bool(params and params[0].is_cuda)
+        self.opt = torch.optim.AdamW(params, lr=o.lr, weight_decay=o.weight_decay,
+                                     betas=(o.beta1, o.beta2), fused=use_fused)
+        self.detach_every = o.get("detach_gradient_every", None)
+
+    def __call__(self, batch):
+        self.opt.zero_grad(set_to_none=True)
+        loss, _ = rollout_loss(self.model, self.loss_fn, batch, num_common=self.num_common,
+                               n_inputs=self.n_inputs, detach_every=self.detach_every)
+        self.opt.step()
+        return loss
+
+
+# ---------------------------------------------------------------------------------- data parallel
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def wrap_ddp(model, *, bucket_cap_mb: int = 32, device_ids: Optional[Sequence[int]] = None):
+    """Batch-sharded data parallelism (the reference's only strategy, ``train.py:49``): full replica
+    per GPU, bucketed gradient all-reduce (RCCL over xGMI) overlapped with backward.  Geometry
+    buffers are deterministic functions of the grid, so buffer broadcast is disabled; the graph is
+    static, gradients alias the buckets."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return model
+    return torch.nn.parallel.DistributedDataParallel(
+        model, device_ids=list(device_ids) if device_ids is not None else None,
+        broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
+        static_graph=False)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,179 @@
+"""PARADIS physically inspired ADR model (drop-in for reference ``model/paradis.py``).
+
+``Paradis(datamodule, cfg, lat_grid, lon_grid).forward(fields[B,Cin,H,W]) -> [B,Cout,H,W]`` with
+the reference's sub-module names (``input_proj``, ``velocity_nets``, ``advection``, ``diffusion``,
+``reaction``, ``output_proj``, ``alpha_adv``, ``downsample``, ``static_encoder``) and state-dict
+keys, so checkpoints and the Lightning trainer work unchanged.  Every tensor op on the path is a
+gfx950 HIP kernel from ``paradis_model_amd.ops`` (no ATen convolutions / grid_sample).
+"""
+import torch
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+from .. import ops
+from .advection import NeuralSemiLagrangian
+from .blocks import GMBlock, PhysicalDownsample, SepConv
+from .padding import GeoCyclicPadding
+
+EARTH_ROTATION_RATE = 7.29212e-5  # rad/s
+
+
+def get_scaled_timestep(original_timestep_seconds: float) -> float:
+    """Non-dimensional time step (reference model/paradis.py:13-14)."""
+    return original_timestep_seconds * EARTH_ROTATION_RATE
+
+
+_ACTIVATIONS = {"SiLU": nn.SiLU, "GELU": nn.GELU}
+
+
+def _get_activation_cls(name: str):
+    if name not in _ACTIVATIONS:
+        raise ValueError(f"Unknown activation_fn '{name}'. Allowed: {list(_ACTIVATIONS.keys())}")
+    return _ACTIVATIONS[name]
+
+
+class StaticEncoder(nn.Sequential):
+    """Encoder of the constant fields; child indices 0..5 match the reference's ``nn.Sequential``
+    (reference model/paradis.py:186-193) so the keys ``static_encoder.{0,3,5}.*`` are unchanged.
+    Always SiLU.  The GeoCyclicPadding(3) + depthwise Conv2d pair runs as one virtual-halo stencil."""
+
+    def __init__(self, n_static: int, static_dim: int, mesh_size):
+        super().__init__(
+            SepConv(n_static, 64, mesh_size, kernel_size=7),
+            nn.SiLU(),
+            GeoCyclicPadding(3),
+            nn.Conv2d(64, 64, groups=64, kernel_size=7),
+            nn.SiLU(),
+            SepConv(64, static_dim, mesh_size, kernel_size=5),
+        )
+
+    def forward(self, x):
+        x = self[0](x, act="SiLU")
+        x = ops.dwconv_geo(x, self[3].weight, self[3].bias)
+        x = ops.activation(x, "SiLU")
+        return self[5](x)
+
+
+class Paradis(nn.Module):
+    """Advection-diffusion-reaction forecast model on a lat-lon grid."""
+
+    def __init__(self, datamodule, cfg, lat_grid, lon_grid):
+        super().__init__()
+        self.nlat, self.nlon = lat_grid.shape[0], lat_grid.shape[1]
+        mesh_size = (self.nlat, self.nlon)
+
+        hidden_dim = cfg.model.get("latent_size")
+        self.num_vels = cfg.model.get("velocity_vectors")
+        adv_interpolation = cfg.model.get("adv_interpolation")
+        bias_channels = cfg.model.get("bias_channels", 4)
+        self.num_layers = max(1, cfg.model.num_layers)
+        self.dt = get_scaled_timestep(cfg.model.get("base_dt")) / self.num_layers
+        self.activation_function = _get_activation_cls(cfg.model.activation)
+
+        input_dim = (datamodule.dataset.num_in_dyn_features
+                     + datamodule.dataset.num_in_static_features)
+        self.num_common_features = datamodule.num_common_features
+        self.n_inputs = cfg.dataset.n_time_inputs
+
+        self.step_fn = self._layer_step
+        self.gradient_checkpoint = cfg.compute.get("gradient_checkpointing", False)
+        if self.gradient_checkpoint:
+            self.step_fn = self._checkpointed_step
+
+        pb = cfg.model.physblock
+        static_dim = 128
+        stride = cfg.model.get("coarsening_factor", 1)
+        if stride < 1:
+            raise ValueError("Coarsening factor must be >=1")
+        self.nlat_coarse = (self.nlat - 1) // stride + 1
+        self.nlon_coarse = self.nlon // stride
+        mesh_coarse = (self.nlat_coarse, self.nlon_coarse)
+        act = self.activation_function
+
+        # construction order = the reference's, so a fixed seed yields identical initial weights
+        self.input_proj = GMBlock(layers=pb.input_proj.layers, input_dim=input_dim,
+                                  output_dim=hidden_dim, hidden_dim=pb.input_proj.hidden_dim,
+                                  mesh_size=mesh_size, activation=True, activation_fn=act,
+                                  pre_normalize=False, bias_channels=0)
+        self.velocity_nets = nn.ModuleList([
+            GMBlock(layers=pb.velocity_net.layers, input_dim=hidden_dim,
+                    output_dim=2 * self.num_vels, hidden_dim=pb.velocity_net.hidden_dim,
+                    mesh_size=mesh_coarse, bias_channels=bias_channels, activation_fn=act,
+                    pre_normalize=True)
+            for _ in range(self.num_layers)])
+        self.advection = nn.ModuleList([
+            NeuralSemiLagrangian(cfg, hidden_dim, mesh_coarse, num_vels=self.num_vels,
+                                 lat_grid=lat_grid[::stride, ::stride],
+                                 lon_grid=lon_grid[::stride, ::stride],
+                                 interpolation=adv_interpolation)
+            for _ in range(self.num_layers)])
+        self.diffusion = nn.ModuleList([
+            GMBlock(layers=pb.diffusion.layers, input_dim=hidden_dim, output_dim=hidden_dim,
+                    hidden_dim=pb.diffusion.hidden_dim, mesh_size=mesh_coarse, pre_normalize=True,
+                    activation_fn=act, bias_channels=bias_channels)
+            for _ in range(self.num_layers)])
+        self.reaction = nn.ModuleList([
+            GMBlock(layers=pb.reaction.layers, input_dim=hidden_dim + static_dim,
+                    output_dim=hidden_dim, hidden_dim=pb.reaction.hidden_dim, mesh_size=mesh_coarse,
+                    pre_normalize=True, activation_fn=act, bias_channels=bias_channels)
+            for _ in range(self.num_layers)])
+        self.output_proj = GMBlock(pre_normalize=True, layers=pb.output_proj.layers,
+                                   input_dim=hidden_dim, output_dim=datamodule.num_out_features,
+                                   hidden_dim=pb.output_proj.hidden_dim, mesh_size=mesh_size,
+                                   activation=False, activation_fn=act, bias_channels=bias_channels)
+
+        self.alpha_adv = nn.Parameter(torch.full((self.num_layers, hidden_dim), -1.0))
+        self.downsample = PhysicalDownsample(stride=stride)
+        self.n_static = len(cfg.features.input.constants)
+        self.static_encoder = StaticEncoder(self.n_static, static_dim, mesh_size)
+
+    # ------------------------------------------------------------------ helpers
+    def _checkpointed_step(self, i, h, hs):
+        return checkpoint(self._layer_step, i, h, hs, use_reentrant=False)
+
+    def _compile(self):
+        """The reference wraps sub-modules in ``torch.compile`` here (model/paradis.py:195-206).
+        The HIP path is already fused by hand and uses no tracing compiler: keep eager modules and
+        only re-bind the step function."""
+        self.step_fn = self._checkpointed_step if self.gradient_checkpoint else self._layer_step
+
+    def upsample(self, x: torch.Tensor) -> torch.Tensor:
+        """Longitude-periodic bilinear interpolation to (nlat, nlon), align_corners=True."""
+        return ops.upsample_lonp(x, self.nlat, self.nlon)
+
+    def _apply_checkpoint(self, func, *args):
+        if self.gradient_checkpoint:
+            return checkpoint(func, *args, use_reentrant=False)
+        return func(*args)
+
+    # ------------------------------------------------------------------ one ADR update
+    def _layer_step(self, i: int, hidden: torch.Tensor, hidden_static: torch.Tensor) -> torch.Tensor:
+        K = self.num_vels
+        # velocities: channels [0,K) = u, [K,2K) = v  (reference: .view(B,2,K,H,W))
+        velocities = self.velocity_nets[i](hidden)
+        u, v = velocities[:, :K], velocities[:, K:]
+
+        # transport, gated per latent channel:  h + sigmoid(alpha_i) * (A(h) - h)
+        advected = self.advection[i](hidden, u, v, self.dt)
+        hidden = ops.gated_blend(hidden, advected, self.alpha_adv[i])
+
+        # mixing: h + D(h)      (residual add fused in the last GEMM epilogue)
+        hidden = self.diffusion[i](hidden, residual=hidden)
+
+        # forcing: h + R([h, h_static])  (concat is virtual inside the leading ChannelNorm)
+        hidden = self.reaction[i](hidden, residual=hidden, x_extra=hidden_static)
+        return hidden
+
+    def forward(self, fields):
+        hidden = self._apply_checkpoint(self.input_proj, fields)
+        hidden_static = self._apply_checkpoint(self.static_encoder, fields[:, -self.n_static:])
+
+        skip = hidden
+        hidden = self.downsample(hidden)
+        hidden_static = self.downsample(hidden_static)
+
+        for i in range(self.num_layers):
+            hidden = self.step_fn(i, hidden, hidden_static)
+
+        hidden = ops.add(self.upsample(hidden), skip)
+        return self._apply_checkpoint(self.output_proj, hidden)

@@ -1,0 +1,534 @@
+"""Autograd-aware Python entry points over the C-ABI HIP kernels.
+
+Every function launches hand-written gfx950 kernels from ``libparadis_hip.so`` on
+the current HIP stream (no host sync).  Inputs must be fp32 HIP tensors; there is
+no CPU path (``_lib.require_hip`` raises).  Reference call sites are cited per op.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, lib, require_hip, stream_ptr
+
+ACT_CODES = {None: 0, "none": 0, "SiLU": 1, "GELU": 2}
+MODE_CODES = {"bilinear": 1, "bicubic": 2}
+
+
+def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
+    if nbytes <= 0:
+        return None
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def _planes_hw(x: torch.Tensor) -> Tuple[int, int, int]:
+    H, W = x.shape[-2:]
+    return x.numel() // (H * W), H, W
+
+
+# ---------------------------------------------------------------------------
+# a1 geocyclic padding (reference model/padding.py:11-39)
+# ---------------------------------------------------------------------------
+class _GeoPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        require_hip(x)
+        x = x.contiguous()
+        planes, H, W = _planes_hw(x)
+        y = torch.empty(*x.shape[:-2], H + 2 * p, W + 2 * p, dtype=x.dtype, device=x.device)
+        check(lib.paradis_geocyclic_pad_fwd(dptr(x), dptr(y), planes, H, W, p, stream_ptr()),
+              "geocyclic_pad_fwd")
+        ctx.p = p
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        gx = torch.empty(ctx.shape, dtype=gy.dtype, device=gy.device)
+        planes, H, W = _planes_hw(gx)
+        check(lib.paradis_geocyclic_pad_bwd(dptr(gy), dptr(gx), planes, H, W, ctx.p, stream_ptr()),
+              "geocyclic_pad_bwd")
+        return gx, None
+
+
+def geocyclic_pad(x: torch.Tensor, p: int) -> torch.Tensor:
+    if p == 0:
+        return x
+    assert x.dim() == 4, "Input must be 4-dimensional [batch, channels, lat, lon]"
+    assert x.shape[-1] % 2 == 0, "Number of longitude points must be even"
+    return _GeoPad.apply(x, p)
+
+
+# ---------------------------------------------------------------------------
+# a3-a5 semi-Lagrangian advection core (reference model/advection.py:129-169)
+# ---------------------------------------------------------------------------
+class AdvectGeometry:
+    """Device tables + scalars derived from the lat/lon grids once per module
+    (the reference's non-persistent buffers, model/advection.py:58-72)."""
+
+    def __init__(self, lat_grid: torch.Tensor, lon_grid: torch.Tensor):
+        lat = lat_grid.detach().to(torch.float32).cpu().contiguous()
+        lon = lon_grid.detach().to(torch.float32).cpu().contiguous()
+        self.H, self.W = lat.shape
+        # tables are evaluated once on the host in fp32, as the reference's CPU path would
+        self.sin_lat = torch.sin(lat).contiguous()
+        self.cos_lat = torch.cos(lat).contiguous()
+        self.lon = lon
+        self.min_lat = float(lat.min())
+        self.min_lon = float(lon.min())
+        self.d_lat = float(lat.max() - lat.min())
+        self.d_lon = float(lon.max() - lon.min())
+        self._dev = {}
+
+    def tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(t.to(device) for t in (self.sin_lat, self.cos_lat, self.lon))
+        return self._dev[key]
+
+
+def _bstride_view(t: torch.Tensor, K: int, H: int, W: int) -> Tuple[torch.Tensor, int]:
+    """Accept [B,K,H,W] views whose planes are contiguous (e.g. a channel slice); return
+    (tensor, batch stride in elements)."""
+    if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W:
+        return t, t.stride(0) if t.shape[0] > 1 else K * H * W
+    t = t.contiguous()
+    return t, K * H * W
+
+
+class _SLAdvect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, field, u, v, geom: AdvectGeometry, dt: float, mode: str):
+        require_hip(field, u, v)
+        B, K, H, W = field.shape
+        assert (H, W) == (geom.H, geom.W) and u.shape == field.shape and v.shape == field.shape
+        field, f_bs = _bstride_view(field, K, H, W)
+        u, u_bs = _bstride_view(u, K, H, W)
+        v, v_bs = _bstride_view(v, K, H, W)
+        if u_bs != v_bs:
+            u, v = u.contiguous(), v.contiguous()
+            u_bs = v_bs = K * H * W
+        out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
+        sl, cl, lo = geom.tables(field.device)
+        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+        check(lib.paradis_sl_advect_fwd(dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl),
+                                        dptr(lo), B, K, H, W, f_bs, u_bs, K * H * W, dt, geom.min_lat,
+                                        geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode],
+                                        dptr(ws), stream_ptr()), "sl_advect_fwd")
+        ctx.save_for_backward(field, u, v)
+        ctx.meta = (geom, dt, mode, f_bs, u_bs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        field, u, v = ctx.saved_tensors
+        geom, dt, mode, f_bs, u_bs = ctx.meta
+        B, K, H, W = gout.shape
+        gout = gout.contiguous()
+        gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
+        guv = torch.empty(B, 2 * K, H, W, dtype=gout.dtype, device=gout.device)
+        gu, gv = guv[:, :K], guv[:, K:]
+        sl, cl, lo = geom.tables(gout.device)
+        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+        P = K * H * W
+        check(lib.paradis_sl_advect_bwd(dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield),
+                                        dptr(gu), dptr(gv), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
+                                        P, f_bs, u_bs, P, 2 * P, dt, geom.min_lat, geom.min_lon,
+                                        geom.d_lat, geom.d_lon, MODE_CODES[mode], dptr(ws),
+                                        stream_ptr()), "sl_advect_bwd")
+        return gfield, gu, gv, None, None, None
+
+
+def sl_advect(field, u, v, geom: AdvectGeometry, dt: float, mode: str = "bicubic"):
+    """[B,K,H,W] x3 -> [B,K,H,W]; fused pole-mean / departure / gather / pole-mean."""
+    if mode not in MODE_CODES:
+        raise ValueError(f"interpolation must be one of {list(MODE_CODES)}")
+    return _SLAdvect.apply(field, u, v, geom, float(dt), mode)
+
+
+# ---------------------------------------------------------------------------
+# helpers for [B,C,H,W] tensors whose (H,W) planes are contiguous
+# ---------------------------------------------------------------------------
+def _plane_view(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """Return (tensor, batch stride in elements); channel slices of a larger contiguous tensor are
+    accepted as they are, anything else is made contiguous."""
+    B, C, H, W = t.shape
+    if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W:
+        return t, (t.stride(0) if B > 1 else C * H * W)
+    return t.contiguous(), C * H * W
+
+
+# ---------------------------------------------------------------------------
+# a7 depthwise stencil on the virtual geocyclic halo (reference model/blocks.py:101-113)
+# ---------------------------------------------------------------------------
+class _DwConvGeo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_hip(x, weight, bias)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        k = weight.shape[-1]
+        assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
+        w = weight.contiguous()
+        y = torch.empty_like(x)
+        check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k,
+                                         stream_ptr()), "dwconv_geo_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, C, H, W = x.shape
+        k = w.shape[-1]
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(lib.paradis_dwconv_geo_dgrad(dptr(gy), dptr(w), dptr(gx), B, C, H, W, k, stream_ptr()),
+                  "dwconv_geo_dgrad")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(w)
+            gb = torch.empty(C, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+            ws = _ws(lib.paradis_dwconv_geo_wgrad_ws_bytes(B, C, H, W, k), x.device)
+            check(lib.paradis_dwconv_geo_wgrad(dptr(gy), dptr(x), dptr(gw), dptr(gb), B, C, H, W, k,
+                                               dptr(ws), stream_ptr()), "dwconv_geo_wgrad")
+        return gx, gw, gb
+
+
+def dwconv_geo(x, weight, bias=None):
+    return _DwConvGeo.apply(x, weight, bias)
+
+
+# ---------------------------------------------------------------------------
+# a11 / a14 resampling
+# ---------------------------------------------------------------------------
+class _AvgPoolGeo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        require_hip(x)
+        x = x.contiguous()
+        planes, H, W = _planes_hw(x)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(*x.shape[:-2], Ho, Wo, dtype=x.dtype, device=x.device)
+        check(lib.paradis_avgpool_geo_fwd(dptr(x), dptr(y), planes, H, W, stride, stream_ptr()),
+              "avgpool_geo_fwd")
+        ctx.meta = (x.shape, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, stride = ctx.meta
+        gy = gy.contiguous()
+        gx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        planes, H, W = _planes_hw(gx)
+        check(lib.paradis_avgpool_geo_bwd(dptr(gy), dptr(gx), planes, H, W, stride, stream_ptr()),
+              "avgpool_geo_bwd")
+        return gx, None
+
+
+def avgpool_geo(x, stride: int):
+    if stride < 1:
+        raise ValueError("Coarsening factor must be >=1")
+    return _AvgPoolGeo.apply(x, int(stride))
+
+
+class _UpsampleLonP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nlat, nlon):
+        require_hip(x)
+        x = x.contiguous()
+        planes, Hc, Wc = _planes_hw(x)
+        y = torch.empty(*x.shape[:-2], nlat, nlon, dtype=x.dtype, device=x.device)
+        check(lib.paradis_upsample_lonp_fwd(dptr(x), dptr(y), planes, Hc, Wc, nlat, nlon, stream_ptr()),
+              "upsample_lonp_fwd")
+        ctx.meta = (x.shape, nlat, nlon)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, nlat, nlon = ctx.meta
+        gy = gy.contiguous()
+        gx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        planes, Hc, Wc = _planes_hw(gx)
+        check(lib.paradis_upsample_lonp_bwd(dptr(gy), dptr(gx), planes, Hc, Wc, nlat, nlon, stream_ptr()),
+              "upsample_lonp_bwd")
+        return gx, None, None
+
+
+def upsample_lonp(x, nlat: int, nlon: int):
+    return _UpsampleLonP.apply(x, int(nlat), int(nlon))
+
+
+# ---------------------------------------------------------------------------
+# a8 ChannelNorm (reference model/blocks.py:118-134), optionally over a virtual concat
+# ---------------------------------------------------------------------------
+class _ChannelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, eps):
+        require_hip(x1, x2, weight, bias)
+        x1, bs1 = _plane_view(x1)
+        B, C1, H, W = x1.shape
+        C2, bs2 = 0, 0
+        if x2 is not None:
+            x2, bs2 = _plane_view(x2)
+            C2 = x2.shape[1]
+        P = H * W
+        C = C1 + C2
+        y = torch.empty(B, C, H, W, dtype=x1.dtype, device=x1.device)
+        mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
+        rstd = torch.empty_like(mean)
+        check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y),
+                                           dptr(mean), dptr(rstd), B, C1, C2, P, bs1, bs2, eps,
+                                           stream_ptr()), "channel_norm_fwd")
+        ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight, mean, rstd)
+        ctx.meta = (C1, C2, bs1, bs2, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, weight, mean, rstd = ctx.saved_tensors
+        C1, C2, bs1, bs2, H, W = ctx.meta
+        B, P, C = x1.shape[0], H * W, C1 + C2
+        gy = gy.contiguous()
+        gx1 = torch.empty(B, C1, H, W, dtype=gy.dtype, device=gy.device)
+        gx2 = torch.empty(B, C2, H, W, dtype=gy.dtype, device=gy.device) if C2 else None
+        gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
+        gb = torch.empty_like(gw)
+        ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
+        check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight),
+                                           dptr(mean), dptr(rstd), dptr(gx1), dptr(gx2), dptr(gw),
+                                           dptr(gb), B, C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(ws),
+                                           stream_ptr()), "channel_norm_bwd")
+        return gx1, gx2, gw, gb, None
+
+
+def channel_norm(x, weight, bias, eps: float = 1e-5, x_extra=None):
+    """ChannelNorm over channels of ``x`` (and, virtually concatenated after them, ``x_extra``)."""
+    return _ChannelNorm.apply(x, x_extra, weight, bias, float(eps))
+
+
+# ---------------------------------------------------------------------------
+# a9 GlobalBias map (reference model/blocks.py:188-196)
+# ---------------------------------------------------------------------------
+class _GlobalBiasMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, U, V, Pw):
+        require_hip(A, U, V, Pw)
+        A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
+        Cin, R = A.shape
+        H, W = U.shape[1], V.shape[1]
+        if Pw is not None:
+            Pw = Pw.contiguous()
+            Co = Pw.shape[0]
+            m8 = torch.empty(Cin, H, W, dtype=A.dtype, device=A.device)
+        else:
+            Co, m8 = Cin, None
+        out = torch.empty(Co, H, W, dtype=A.dtype, device=A.device)
+        check(lib.paradis_global_bias_map_fwd(dptr(A), dptr(U), dptr(V), dptr(Pw), dptr(m8), dptr(out),
+                                              Cin, Co, R, H, W, stream_ptr()), "global_bias_map_fwd")
+        ctx.save_for_backward(A, U, V, Pw if Pw is not None else A.new_empty(0),
+                              m8 if m8 is not None else A.new_empty(0))
+        ctx.has_proj = Pw is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gmap):
+        A, U, V, Pw, m8 = ctx.saved_tensors
+        Cin, R = A.shape
+        H, W = U.shape[1], V.shape[1]
+        gmap = gmap.contiguous()
+        Co = gmap.shape[0]
+        gA, gU, gV = torch.empty_like(A), torch.empty_like(U), torch.empty_like(V)
+        gPw = torch.empty_like(Pw) if ctx.has_proj else None
+        ws = _ws(lib.paradis_global_bias_map_bwd_ws_bytes(Cin, Co, R, H, W), A.device)
+        check(lib.paradis_global_bias_map_bwd(dptr(gmap), dptr(A), dptr(U), dptr(V),
+                                              dptr(Pw) if ctx.has_proj else None,
+                                              dptr(m8) if ctx.has_proj else None, dptr(gA), dptr(gU),
+                                              dptr(gV), dptr(gPw), Cin, Co, R, H, W, dptr(ws),
+                                              stream_ptr()), "global_bias_map_bwd")
+        return gA, gU, gV, gPw
+
+
+def global_bias_map(A, U, V, Pw=None):
+    return _GlobalBiasMap.apply(A, U, V, Pw)
+
+
+# ---------------------------------------------------------------------------
+# a6 pointwise channel mixing on FP32 MFMA with fused epilogue
+#     y = residual + act(W x + bias + bias_map)
+# (reference model/blocks.py:86,110 + :196 + activation + the residual adds of paradis.py:246,253)
+# ---------------------------------------------------------------------------
+class _Pointwise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bmap, residual, act):
+        require_hip(x, weight, bias, bmap, residual)
+        x, x_bs = _plane_view(x)
+        B, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        P = H * W
+        w2 = weight.reshape(Co, -1)
+        assert w2.shape[1] == Ci, "weight/in-channel mismatch"
+        w2 = w2.contiguous()
+        res_bs = 0
+        if residual is not None:
+            residual, res_bs = _plane_view(residual)
+        if bmap is not None:
+            bmap = bmap.contiguous()
+        y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
+        need_z = act != 0 and any(ctx.needs_input_grad[:4])
+        z = torch.empty_like(y) if need_z else None
+        check(lib.paradis_pw_gemm_fwd(dptr(w2), dptr(x), dptr(bias), dptr(bmap), dptr(residual), dptr(y),
+                                      dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr()),
+              "pw_gemm_fwd")
+        ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0))
+        ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w2, z = ctx.saved_tensors
+        x_bs, act, has_bias, has_map, has_res, wshape = ctx.meta
+        B, Ci, H, W = x.shape
+        Co, P = w2.shape[0], H * W
+        gy = gy.contiguous()
+        st = stream_ptr()
+        gres = gy if has_res else None
+        if act != 0:
+            dz = torch.empty_like(gy)
+            check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, st), "act_bwd")
+        else:
+            dz = gy
+        gx = gw = gb = gmap = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, Ci, H, W, dtype=gy.dtype, device=gy.device)
+            check(lib.paradis_pw_gemm_dgrad(dptr(w2), dptr(dz), None, None, dptr(gx), B, Co, Ci, P,
+                                            Co * P, 0, 0, Ci * P, 0, st), "pw_gemm_dgrad")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(Co, Ci, dtype=gy.dtype, device=gy.device)
+            ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), gy.device)
+            check(lib.paradis_pw_gemm_wgrad(dptr(dz), dptr(x), dptr(gw), B, Co, Ci, P, Co * P, x_bs,
+                                            dptr(ws), st), "pw_gemm_wgrad")
+            gw = gw.reshape(wshape)
+        want_b = has_bias and ctx.needs_input_grad[2]
+        want_m = has_map and ctx.needs_input_grad[3]
+        if want_b or want_m:
+            gb = torch.empty(Co, dtype=gy.dtype, device=gy.device) if want_b else None
+            gmap = torch.empty(Co, H, W, dtype=gy.dtype, device=gy.device) if want_m else None
+            check(lib.paradis_bias_grads(dptr(dz), dptr(gmap), dptr(gb), B, Co, P, Co * P, st), "bias_grads")
+        return gx, gw, gb, gmap, gres, None
+
+
+def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None):
+    """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1]."""
+    return _Pointwise.apply(x, weight, bias, bias_map, residual, ACT_CODES[act])
+
+
+# ---------------------------------------------------------------------------
+# elementwise glue
+# ---------------------------------------------------------------------------
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        require_hip(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.paradis_act_fwd(dptr(x), dptr(y), x.numel(), act, stream_ptr()), "act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        check(lib.paradis_act_bwd(dptr(gy), dptr(x), dptr(gx), x.numel(), ctx.act, stream_ptr()), "act_bwd")
+        return gx, None
+
+
+def activation(x, name: str):
+    if name not in ("SiLU", "GELU"):
+        raise ValueError(f"Unknown activation_fn '{name}'. Allowed: ['SiLU', 'GELU']")
+    return _Activation.apply(x, ACT_CODES[name])
+
+
+class _GatedBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, adv, alpha):
+        require_hip(h, adv, alpha)
+        h, adv, alpha = h.contiguous(), adv.contiguous(), alpha.contiguous()
+        B, C, H, W = h.shape
+        out = torch.empty_like(h)
+        check(lib.paradis_gated_blend_fwd(dptr(h), dptr(adv), dptr(alpha), dptr(out), B, C, H * W,
+                                          stream_ptr()), "gated_blend_fwd")
+        ctx.save_for_backward(h, adv, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, adv, alpha = ctx.saved_tensors
+        B, C, H, W = h.shape
+        gout = gout.contiguous()
+        gh, gadv, galpha = torch.empty_like(h), torch.empty_like(h), torch.empty_like(alpha)
+        ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
+        check(lib.paradis_gated_blend_bwd(dptr(gout), dptr(h), dptr(adv), dptr(alpha), dptr(gh),
+                                          dptr(gadv), dptr(galpha), B, C, H * W, dptr(ws), stream_ptr()),
+              "gated_blend_bwd")
+        return gh, gadv, galpha
+
+
+def gated_blend(h, adv, alpha):
+    """h + sigmoid(alpha)[None,:,None,None] * (adv - h)   (reference model/paradis.py:239-243)"""
+    return _GatedBlend.apply(h, adv, alpha)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_hip(a, b)
+        assert a.shape == b.shape
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        check(lib.paradis_add(dptr(a), dptr(b), dptr(y), a.numel(), stream_ptr()), "add")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, gy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _AddBiasMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bmap):
+        require_hip(x, bmap)
+        x, bmap = x.contiguous(), bmap.contiguous()
+        B = x.shape[0]
+        assert x.shape[1:] == bmap.shape
+        y = torch.empty_like(x)
+        check(lib.paradis_add_bcast(dptr(x), dptr(bmap), dptr(y), bmap.numel(), B, stream_ptr()), "add_bcast")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B, C, H, W = gy.shape
+        gmap = None
+        if ctx.needs_input_grad[1]:
+            gmap = torch.empty(C, H, W, dtype=gy.dtype, device=gy.device)
+            check(lib.paradis_bias_grads(dptr(gy), dptr(gmap), None, B, C, H * W, C * H * W, stream_ptr()),
+                  "bias_grads")
+        return gy, gmap
+
+
+def add_bias_map(x, bmap):
+    """x[B,C,H,W] + bmap[C,H,W] (standalone GlobalBias, reference model/blocks.py:196)"""
+    return _AddBiasMap.apply(x, bmap)

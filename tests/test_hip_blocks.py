@@ -1,0 +1,229 @@
+"""GPU parity of every block-level HIP op against the CPU oracle and the reference goldens (G3).
+Tolerance (SURVEY.md 8c ii): max-abs(diff)/max-abs(ref) <= 1e-5 forward; gradients <= 1e-4."""
+import pytest
+import torch
+
+from oracle import paradis_oracle as O
+from tests._util import load_golden, max_rel, seeded
+
+pytestmark = pytest.mark.gpu
+FWD, BWD = 1e-5, 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from paradis_model_amd import ops as _ops
+    return _ops
+
+
+def _dev(t):
+    return t.detach().clone().cuda().requires_grad_(True)
+
+
+def _cmp(got, want, tol, what):
+    e = max_rel(got.detach().cpu(), want.detach())
+    assert e <= tol, (what, e)
+    return e
+
+
+# ----------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 10, 7, 12, 16), (2, 186, 64, 16, 32), (3, 128, 97, 32, 64),
+                                         (1, 256, 384, 17, 32), (2, 130, 258, 32, 64)])
+@pytest.mark.parametrize("act", [None, "SiLU", "GELU"])
+def test_pointwise_gemm(ops, B, Ci, Co, H, W, act):
+    x = seeded(1, B, Ci, H, W)
+    w = seeded(2, Co, Ci, 1, 1, scale=Ci ** -0.5)
+    b = seeded(3, Co, scale=0.1)
+    bm = seeded(4, Co, H, W, scale=0.2)
+    res = seeded(5, B, Co, H, W)
+    ct = seeded(6, B, Co, H, W)
+    ts = [t.clone().requires_grad_(True) for t in (x, w, b, bm, res)]
+    y = O.pointwise(ts[0], ts[1], ts[2]) + ts[3].unsqueeze(0)
+    if act:
+        y = O.activation(y, act)
+    y = y + ts[4]
+    y.backward(ct)
+    ds = [_dev(t) for t in (x, w, b, bm, res)]
+    yd = ops.pointwise(ds[0], ds[1], ds[2], ds[3], ds[4], act)
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "y")
+    for name, d, t in zip(("gx", "gw", "gb", "gmap", "gres"), ds, ts):
+        _cmp(d.grad, t.grad, BWD, name)
+
+
+def test_pointwise_channel_slice_input(ops):
+    big = seeded(1, 2, 40, 16, 32)
+    w = seeded(2, 24, 16, 1, 1, scale=0.25)
+    want = O.pointwise(big[:, 8:24], w, None)
+    got = ops.pointwise(big.cuda()[:, 8:24], w.cuda())
+    _cmp(got, want, FWD, "slice")
+
+
+def test_clinear_golden(ops):
+    rec = load_golden("g3_blocks.pt")["clinear"]
+    x, w, b = _dev(rec["x"]), _dev(rec["params"]["conv.weight"]), _dev(rec["params"]["conv.bias"])
+    y = ops.pointwise(x, w, b)
+    y.backward(rec["cot"].cuda())
+    _cmp(y, rec["y"], FWD, "y")
+    _cmp(x.grad, rec["gx"], BWD, "gx")
+    _cmp(w.grad, rec["grads"]["conv.weight"], BWD, "gw")
+    _cmp(b.grad, rec["grads"]["conv.bias"], BWD, "gb")
+
+
+# ----------------------------------------------------------------------------------- depthwise
+@pytest.mark.parametrize("k", [3, 5, 7])
+@pytest.mark.parametrize("B,C,H,W", [(2, 6, 12, 16), (2, 5, 33, 64), (1, 3, 70, 130), (2, 4, 9, 8)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_dwconv_geo(ops, k, B, C, H, W, bias):
+    if (k - 1) // 2 > H - 2 or k - 1 > W:
+        pytest.skip("grid too small")
+    x = seeded(1, B, C, H, W)
+    w = seeded(2, C, 1, k, k, scale=1.0 / k)
+    b = seeded(3, C) if bias else None
+    ct = seeded(4, B, C, H, W)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    y = O.depthwise_geo(xr, wr, br)
+    y.backward(ct)
+    xd, wd = _dev(x), _dev(w)
+    bd = _dev(b) if bias else None
+    yd = ops.dwconv_geo(xd, wd, bd)
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "y")
+    _cmp(xd.grad, xr.grad, BWD, "gx")
+    _cmp(wd.grad, wr.grad, BWD, "gw")
+    if bias:
+        _cmp(bd.grad, br.grad, BWD, "gb")
+
+
+def test_sepconv_golden(ops):
+    g = load_golden("g3_blocks.pt")
+    for k in (5, 7):
+        rec = g[f"sepconv_k{k}"]
+        P = {n: _dev(v) for n, v in rec["params"].items()}
+        x = _dev(rec["x"])
+        y = ops.pointwise(ops.dwconv_geo(x, P["depthwise.weight"]), P["pointwise.weight"], P["pointwise.bias"])
+        y.backward(rec["cot"].cuda())
+        _cmp(y, rec["y"], FWD, "y")
+        _cmp(x.grad, rec["gx"], BWD, "gx")
+        for n in P:
+            _cmp(P[n].grad, rec["grads"][n], BWD, n)
+
+
+# ----------------------------------------------------------------------------------- norm / bias
+@pytest.mark.parametrize("B,C,H,W", [(2, 20, 12, 16), (2, 1024, 8, 16), (1, 1152, 9, 16), (1, 1300, 4, 8)])
+def test_channel_norm(ops, B, C, H, W):
+    x = seeded(1, B, C, H, W, scale=3.0) + 1.0
+    w = 1.0 + seeded(2, C, scale=0.2)
+    b = seeded(3, C, scale=0.2)
+    ct = seeded(4, B, C, H, W)
+    ts = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    y = O.channel_norm(*ts)
+    y.backward(ct)
+    ds = [_dev(t) for t in (x, w, b)]
+    yd = ops.channel_norm(*ds)
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "y")
+    for n, d, t in zip(("gx", "gw", "gb"), ds, ts):
+        _cmp(d.grad, t.grad, BWD, n)
+
+
+def test_channel_norm_virtual_concat_and_golden(ops):
+    x1, x2 = seeded(1, 2, 24, 8, 16), seeded(2, 2, 8, 8, 16, scale=2.0)
+    w, b = 1.0 + seeded(3, 32, scale=0.1), seeded(4, 32, scale=0.1)
+    ct = seeded(5, 2, 32, 8, 16)
+    r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    y = O.channel_norm(torch.cat([r1, r2], 1), w, b)
+    y.backward(ct)
+    d1, d2 = _dev(x1), _dev(x2)
+    yd = ops.channel_norm(d1, w.cuda(), b.cuda(), 1e-5, d2)
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "y")
+    _cmp(d1.grad, r1.grad, BWD, "gx1")
+    _cmp(d2.grad, r2.grad, BWD, "gx2")
+    rec = load_golden("g3_blocks.pt")["channelnorm"]
+    x, wp, bp = _dev(rec["x"]), _dev(rec["params"]["weight"]), _dev(rec["params"]["bias"])
+    yd = ops.channel_norm(x, wp, bp)
+    yd.backward(rec["cot"].cuda())
+    _cmp(yd, rec["y"], FWD, "gold y")
+    _cmp(x.grad, rec["gx"], BWD, "gold gx")
+    _cmp(wp.grad, rec["grads"]["weight"], BWD, "gold gw")
+
+
+def test_global_bias_golden(ops):
+    g = load_golden("g3_blocks.pt")
+    for tag in ("noproj", "proj"):
+        rec = g[f"globalbias_{tag}"]
+        P = {n: _dev(v) for n, v in rec["params"].items()}
+        x = _dev(rec["x"])
+        bm = ops.global_bias_map(P["A"], P["U"], P["V"], P.get("projection.weight"))
+        y = ops.add_bias_map(x, bm)
+        y.backward(rec["cot"].cuda())
+        _cmp(y, rec["y"], FWD, "y")
+        _cmp(x.grad, rec["gx"], BWD, "gx")
+        for n in P:
+            _cmp(P[n].grad, rec["grads"][n], BWD, n)
+
+
+# ----------------------------------------------------------------------------------- resampling
+def test_downsample_upsample_golden(ops):
+    g = load_golden("g3_blocks.pt")
+    for key, rec in g.items():
+        if key.startswith("downsample"):
+            s = int(key.split("_s")[1])
+            x = _dev(rec["x"])
+            y = ops.avgpool_geo(x, s)
+        elif key.startswith("upsample"):
+            nlat, nlon = map(int, key.split("_")[1].split("x"))
+            x = _dev(rec["x"])
+            y = ops.upsample_lonp(x, nlat, nlon)
+        else:
+            continue
+        y.backward(rec["cot"].cuda())
+        _cmp(y, rec["y"], FWD, key)
+        _cmp(x.grad, rec["gx"], BWD, key + " gx")
+    x = torch.randn(1, 2, 8, 16)
+    assert torch.equal(ops.upsample_lonp(x.cuda(), 8, 16).cpu(), x)   # identity at stride 1
+
+
+# ----------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("act", ["SiLU", "GELU"])
+def test_activation_and_blend(ops, act):
+    x = seeded(1, 2, 5, 7, 10, scale=3.0)
+    ct = seeded(2, 2, 5, 7, 10)
+    xr = x.clone().requires_grad_(True)
+    O.activation(xr, act).backward(ct)
+    xd = _dev(x)
+    yd = ops.activation(xd, act)
+    yd.backward(ct.cuda())
+    _cmp(yd, O.activation(x, act), FWD, "act")
+    _cmp(xd.grad, xr.grad, BWD, "act grad")
+    h, adv, al = seeded(3, 2, 5, 8, 16), seeded(4, 2, 5, 8, 16), seeded(5, 5)
+    ct = seeded(6, 2, 5, 8, 16)
+    ts = [t.clone().requires_grad_(True) for t in (h, adv, al)]
+    y = ts[0] + torch.sigmoid(ts[2]).view(1, -1, 1, 1) * (ts[1] - ts[0])
+    y.backward(ct)
+    ds = [_dev(t) for t in (h, adv, al)]
+    yd = ops.gated_blend(*ds)
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "blend")
+    for n, d, t in zip(("gh", "gadv", "galpha"), ds, ts):
+        _cmp(d.grad, t.grad, BWD, n)
+
+
+def test_gmblock_golden():
+    from paradis_model_amd.model import GMBlock
+    rec = load_golden("g3_blocks.pt")["gmblock"]
+    blk = GMBlock(layers=["CLinear", "SepConv", "CLinear"], input_dim=10, output_dim=6,
+                  mesh_size=(12, 16), hidden_dim=12, bias_channels=4, pre_normalize=True,
+                  activation_fn=torch.nn.GELU)
+    assert list(blk.state_dict().keys()) == rec["keys"]
+    blk.load_state_dict(rec["params"], strict=True)
+    blk.cuda()
+    x = _dev(rec["x"])
+    y = blk(x)
+    y.backward(rec["cot"].cuda())
+    _cmp(y, rec["y"], 2e-5, "y")
+    _cmp(x.grad, rec["gx"], BWD, "gx")
+    for n, p in blk.named_parameters():
+        _cmp(p.grad, rec["grads"][n], 2e-4, n)

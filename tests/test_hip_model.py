@@ -1,0 +1,115 @@
+"""GPU parity of the full drop-in model against reference goldens (G4, c2) and the CPU oracle."""
+import pytest
+import torch
+
+from oracle import paradis_oracle as O
+from paradis_model_amd.config import default_config, feature_layout, reduced_config, stub_datamodule
+from tests._util import assert_chk, load_golden, make_grid, max_rel, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cfg, lg, og, state=None):
+    from paradis_model_amd.model import Paradis
+    torch.manual_seed(42)
+    m = Paradis(stub_datamodule(cfg), cfg, lg, og)
+    if state is not None:
+        m.load_state_dict(state, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("variant", ["a", "b", "c"])
+def test_reduced_model_vs_reference_golden(variant):
+    from paradis_model_amd.loss import build_loss
+    rec = load_golden(f"g4_model_{variant}.pt")
+    v = rec["variant"]
+    cfg = reduced_config(activation=v["activation"], adv_interpolation=v["adv_interpolation"],
+                         coarsening_factor=v["coarsening_factor"])
+    lg, og = rec["lat_grid"], rec["lon_grid"]
+    model = _build(cfg, lg, og, rec["state"])
+    x = seeded(rec["x_seed"], rec["B"], 186, v["nlat"], v["nlon"])
+    x[:, -2] = lg
+    x[:, -1] = og
+    tgt = seeded(rec["target_seed"], rec["B"], 97, v["nlat"], v["nlon"])
+    assert_chk([x, tgt], rec["chk"])
+    xd = x.cuda().requires_grad_(True)
+    y = model(xd)
+    e = max_rel(y.detach().cpu(), rec["y"])
+    assert e <= 1e-5, e                                   # north_star: 1e-5 relative
+    loss_fn = build_loss(cfg, rec["lat_deg"]).cuda()
+    loss = loss_fn(y, tgt.cuda())
+    assert abs(float(loss) - float(rec["loss"])) <= 2e-6 * abs(float(rec["loss"]))
+    loss.backward()
+    assert max_rel(xd.grad.cpu()[:, ::9], rec["gx_sub"]) <= 5e-4
+    worst = ("", 0.0)
+    for n, p in model.named_parameters():
+        gref = rec["grads"][n]
+        if float(gref.abs().max()) == 0:
+            continue
+        err = max_rel(p.grad.cpu(), gref)
+        if err > worst[1]:
+            worst = (n, err)
+    print("worst grad", worst)
+    assert worst[1] <= 1e-3, worst
+
+
+def test_two_step_rollout_vs_reference_golden():
+    from paradis_model_amd.loss import build_loss
+    rec = load_golden("c2_rollout.pt")
+    cfg = reduced_config()
+    model = _build(cfg, rec["lat_grid"], rec["lon_grid"], rec["state"])
+    H, W = rec["lat_grid"].shape
+    B, S = rec["B"], rec["S"]
+    s = rec["seeds"]
+    inp = seeded(s[0], B, 1, 166, H, W).cuda()
+    tgt = seeded(s[1], B, S, 97, H, W).cuda()
+    forc = seeded(s[2], B, S, H, W, 10, kind="rand").cuda()
+    const = seeded(s[3], B, 1, H, W, 10).cuda()
+    loss_fn = build_loss(cfg, rec["lat_deg"]).cuda()
+    from paradis_model_amd.harness import rollout_loss
+    total, outs = rollout_loss(model, loss_fn, (inp, tgt, forc, const), num_common=83, n_inputs=2,
+                               keep_outputs=True)
+    for got, want in zip(outs, rec["outputs"]):
+        assert max_rel(got.detach().cpu(), want) <= 2e-5
+    assert abs(float(total) - float(rec["loss"])) <= 2e-6 * abs(float(rec["loss"]))
+    assert max_rel(model.alpha_adv.grad.cpu(), rec["grad_alpha"]) <= 1e-3
+    for n, p in model.named_parameters():
+        gn = rec["grad_norms"][n]
+        assert abs(float(p.grad.norm()) - gn) <= 2e-3 * gn + 1e-9, n
+
+
+def test_default_config_forward_vs_oracle():
+    """Full-size (60 M parameter) model at reference init, 32x64, B=1: HIP vs CPU oracle."""
+    cfg = default_config()
+    _, lg, og = make_grid(32, 64, False)
+    model = _build(cfg, lg, og)
+    with torch.no_grad():  # make the bias maps / gates non-trivial
+        g = torch.Generator().manual_seed(7)
+        for n, p in model.named_parameters():
+            if n.endswith((".A", ".U", ".V")):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    lay = feature_layout(cfg)
+    spec = O.spec_from_cfg(cfg, 32, 64, lay.num_in_dyn_features, lay.num_in_static_features,
+                           lay.num_out_features)
+    x = seeded(5, 1, 186, 32, 64)
+    x[:, -2], x[:, -1] = lg, og
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.paradis_forward(params, spec, x, lg, og, interp_impl="aten_ref")
+        got = model(x.cuda()).cpu()
+    e = max_rel(got, want)
+    print("default-config forward max-rel", e)
+    assert e <= 1e-5, e
+
+
+def test_gradient_checkpointing_matches():
+    cfg = reduced_config()
+    _, lg, og = make_grid(16, 32, False)
+    x = seeded(3, 2, 186, 16, 32).cuda()
+    grads = []
+    for ck in (False, True):
+        cfg.compute.gradient_checkpointing = ck
+        m = _build(cfg, lg, og)
+        m(x).square().mean().backward()
+        grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu())
+    assert max_rel(grads[1], grads[0]) <= 1e-5

@@ -1,0 +1,124 @@
+"""GPU parity: geocyclic padding (bit-exact) and the fused advection core vs the CPU oracle.
+Calls go through the C-ABI library (paradis_model_amd._lib / ops)."""
+import pytest
+import torch
+
+from oracle import paradis_oracle as O
+from tests._util import load_golden, make_grid, max_rel, rms_rel, seeded, assert_chk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from paradis_model_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("H,W,p", [(7, 8, 1), (7, 8, 3), (32, 64, 2), (33, 64, 3), (721, 1440, 2)])
+def test_pad_forward_bit_exact_and_adjoint(ops, H, W, p):
+    planes = 3 if H < 100 else 1
+    x = torch.randn(1, planes, H, W)
+    y = ops.geocyclic_pad(x.cuda(), p).cpu()
+    assert torch.equal(y, O.geocyclic_pad(x, p))
+    # golden index arrays straight from the reference
+    g = load_golden("g1_pad.pt")
+    key = f"{H}x{W}_p{p}"
+    if key in g:
+        ar = torch.arange(H * W, dtype=torch.float32).reshape(1, 1, H, W)
+        assert torch.equal(ops.geocyclic_pad(ar.cuda(), p).cpu()[0, 0].to(torch.int32), g[key])
+    # adjoint: integer-valued cotangent => exact sums
+    gy = torch.randint(-8, 8, y.shape).float()
+    xr = x.clone().requires_grad_(True)
+    O.geocyclic_pad(xr, p).backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    ops.geocyclic_pad(xg, p).backward(gy.cuda())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+def test_pad_rejects_bad_input(ops):
+    with pytest.raises(AssertionError):
+        ops.geocyclic_pad(torch.randn(1, 1, 8, 7).cuda(), 1)
+    with pytest.raises(RuntimeError):
+        ops.geocyclic_pad(torch.randn(1, 1, 8, 8), 1)  # CPU tensor: no fallback
+
+
+def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem):
+    from paradis_model_amd._lib import lib
+    lib.paradis_debug_set_advect_gmem(1 if force_gmem else 0)
+    try:
+        geom = ops.AdvectGeometry(lg, og)
+        fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
+        y = ops.sl_advect(fd, ud, vd, geom, dt, mode)
+        y.backward(ct.cuda())
+        torch.cuda.synchronize()
+        return y.detach().cpu(), fd.grad.cpu(), ud.grad.cpu(), vd.grad.cpu()
+    finally:
+        lib.paradis_debug_set_advect_gmem(-1)
+
+
+@pytest.mark.parametrize("force_gmem", [False, True])
+def test_advect_core_vs_golden_and_fp64(ops, force_gmem):
+    """Tolerance protocol of SURVEY.md 8c(iii): rms-rel vs CPU fp32 <= 1e-5 and error vs the fp64
+    golden <= 1.5x the CPU-fp32 golden's own error vs fp64 (+ a small absolute floor)."""
+    g = load_golden("g2_advect.pt")
+    report = []
+    for key, rec in g.items():
+        H, W, K, B = rec["H"], rec["W"], rec["K"], rec["B"]
+        _, lg, og = make_grid(H, W, rec["poles"])
+        s = rec["seed"]
+        f = seeded(s, B, K, H, W)
+        u = seeded(s + 1, B, K, H, W, scale=rec["scale"])
+        v = seeded(s + 2, B, K, H, W, scale=rec["scale"])
+        ct = seeded(s + 3, B, K, H, W)
+        assert_chk([f, u, v, ct], rec["chk"])
+        y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, rec["dt"], rec["mode"], force_gmem)
+        e_cpu = rms_rel(rec["out_f32"], rec["out_f64"])
+        e_gpu = rms_rel(y, rec["out_f64"])
+        r32 = rms_rel(y, rec["out_f32"])
+        report.append((key, r32, e_gpu, e_cpu, max_rel(gf, rec["gfield_f32"]),
+                       rms_rel(gu, rec["gu_f32"]), rms_rel(gv, rec["gv_f32"])))
+        assert r32 <= 1e-5, (key, r32)
+        assert e_gpu <= 1.5 * e_cpu + 2e-7, (key, e_gpu, e_cpu)
+        assert max_rel(gf, rec["gfield_f32"]) < 5e-5, key
+        assert rms_rel(gu, rec["gu_f32"]) < 2e-3, key
+        assert rms_rel(gv, rec["gv_f32"]) < 2e-3, key
+    print("\nadvect parity (key, rms32, err_gpu_vs64, err_cpu_vs64, gfield, gu, gv):")
+    for r in report:
+        print("  %-24s %.2e %.2e %.2e %.2e %.2e %.2e" % r)
+
+
+@pytest.mark.parametrize("H,W,poles,mode", [(32, 64, False, "bicubic"), (33, 64, True, "bilinear"),
+                                            (128, 256, False, "bicubic")])
+def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode):
+    """Gradients against fp64 autograd through the oracle (the formula check)."""
+    B, K = 2, 4
+    _, lg, og = make_grid(H, W, poles)
+    f, u, v, ct = (seeded(50 + i, B, K, H, W) for i in range(4))
+    geo = O.GridGeometry(lg.double(), og.double())
+    fd, ud, vd = (t.double().requires_grad_(True) for t in (f, u, v))
+    yr = O.sl_advect_core(fd, ud, vd, 0.196887, geo, mode)
+    yr.backward(ct.double())
+    y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, 0.196887, mode, False)
+    # fp32 coordinate rounding is amplified by the grid size: judge against the CPU fp32 oracle's
+    # own distance to fp64 (SURVEY.md 8c iii)
+    f32, u32, v32 = (t.clone().requires_grad_(True) for t in (f, u, v))
+    y32 = O.sl_advect_core(f32, u32, v32, 0.196887, O.GridGeometry(lg, og), mode)
+    y32.backward(ct)
+    assert rms_rel(y, yr.detach()) <= 1.5 * rms_rel(y32.detach(), yr.detach()) + 2e-7
+    assert rms_rel(gf, fd.grad) <= 1.5 * rms_rel(f32.grad, fd.grad) + 1e-6
+    assert rms_rel(gu, ud.grad) <= 1.5 * rms_rel(u32.grad, ud.grad) + 1e-5
+    assert rms_rel(gv, vd.grad) <= 1.5 * rms_rel(v32.grad, vd.grad) + 1e-5
+
+
+def test_advect_channel_slice_inputs(ops):
+    """u, v as channel slices of one [B,2K,H,W] tensor (reference model/paradis.py:236-237)."""
+    B, K, H, W = 2, 5, 16, 32
+    _, lg, og = make_grid(H, W, False)
+    f = seeded(1, B, K, H, W)
+    vel = seeded(2, B, 2 * K, H, W)
+    geo = O.GridGeometry(lg, og)
+    want = O.sl_advect_core(f, vel[:, :K], vel[:, K:], 0.2, geo, "bicubic")
+    veld = vel.cuda()
+    got = ops.sl_advect(f.cuda(), veld[:, :K], veld[:, K:], ops.AdvectGeometry(lg, og), 0.2, "bicubic")
+    assert rms_rel(got.cpu(), want) < 1e-5
