@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the PARADIS ADR hot path on MI355X (contract: see the task description).
+
+Metric (BASELINE.json): training samples/sec (whole node) on the 5.625 deg ERA5 grid.
+One "step" = forward (S=1 rollout step) + ParadisLoss + backward + AdamW on one synthetic
+ERA5-shaped batch of 32 samples per GPU (configs[1]: 32x64 grid, default 60 M-parameter model,
+fp32).  N>1: one process per GPU (torchrun), batch-sharded DDP over RCCL, weak scaling.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = FP32-MFMA pointwise GEMM, timed
+live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the
+reference path, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (no xf32 on gfx950)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+WORKLOADS = {
+    # name: (nlat, nlon, poles, per-GPU batch, rollout steps)
+    "era5_5.625deg_32x64_S1_B32": (32, 64, False, 32, 1),
+    "era5_5.625deg_32x64_S6_B32": (32, 64, False, 32, 6),
+    "era5_1.4deg_128x256_S1_B8": (128, 256, False, 8, 1),
+}
+
+
+def usable_cores() -> int:
+    """CPU cores this process may really use: min(affinity mask, cgroup cpu.max quota).  The GPU
+    boxes expose 256 logical CPUs but cap the container at 16 via cgroup; using more threads than
+    the quota oversubscribes and slows the oracle >10x (measured, tools/cpu_threads.py)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(cfg, nlat, nlon, poles, batch, steps_timed=2):
+    """Oracle (CPU restatement of the reference path: same ATen/oneDNN operators) training step
+    on the host cores: fwd + loss + bwd + AdamW, fp32."""
+    torch.set_num_threads(usable_cores())
+    from oracle import paradis_oracle as O
+    from paradis_model_amd.config import feature_layout, stub_datamodule
+    from paradis_model_amd.harness import make_grids, synthetic_batch, assemble_model_input
+    from paradis_model_amd.model import Paradis
+
+    lay = feature_layout(cfg)
+    lat_deg, lg, og = make_grids(nlat, nlon, poles)
+    torch.manual_seed(42)
+    holder = Paradis(stub_datamodule(cfg), cfg, lg, og)          # parameters only (CPU), never run
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in holder.state_dict().items()}
+    del holder
+    spec = O.spec_from_cfg(cfg, nlat, nlon, lay.num_in_dyn_features, lay.num_in_static_features,
+                           lay.num_out_features)
+    fw = O.feature_weights(torch.tensor([1.0] * 83 + [0.1] * 13 + [1.0]),
+                           torch.tensor(cfg.features.pressure_levels), 97, 6)
+    lw = O.latitude_weights(lat_deg)
+    o = cfg.training.optimizer
+    opt = torch.optim.AdamW(list(params.values()), lr=o.lr, weight_decay=o.weight_decay,
+                            betas=(o.beta1, o.beta2))
+    inp, tgt, forc, const = synthetic_batch(nlat, nlon, poles, batch, 1)
+    mi = assemble_model_input(inp, forc.permute(0, 1, 4, 2, 3)[:, 0].unsqueeze(1),
+                              const[:, :1].permute(0, 1, 4, 2, 3))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y = O.paradis_forward(params, spec, mi, lg, og, interp_impl="aten_ref")
+        O.paradis_loss(y, tgt[:, 0], fw, lw).backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps_timed):
+        step()
+    dt = (time.perf_counter() - t0) / steps_timed
+    return {"value": batch / dt, "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps_timed} train steps at batch {batch} on the same "
+                                      f"{nlat}x{nlon} S=1 workload (1 warm-up), {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="era5_5.625deg_32x64_S1_B32", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="skip the HIP-event timing of the GEMM/advection launches")
+    args = ap.parse_args()
+
+    from paradis_model_amd import _lib
+    from paradis_model_amd.config import default_config, feature_layout, stub_datamodule
+    from paradis_model_amd.harness import (TrainStep, barrier, init_distributed, make_grids,
+                                           max_over_ranks, synthetic_batch, wrap_ddp)
+    from paradis_model_amd.loss import build_loss
+    from paradis_model_amd.model import Paradis
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    nlat, nlon, poles, B, S = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    cfg = default_config()
+    lay = feature_layout(cfg)
+    lat_deg, lg, og = make_grids(nlat, nlon, poles)
+    torch.manual_seed(cfg.init.seed)
+    model = Paradis(stub_datamodule(cfg), cfg, lg, og).to(dev)
+    loss_fn = build_loss(cfg, lat_deg).to(dev)
+    ddp = wrap_ddp(model, device_ids=[local])
+    step = TrainStep(ddp, loss_fn, cfg, num_common=lay.num_common_features,
+                     n_inputs=cfg.dataset.n_time_inputs)
+    batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234 + rank, device=dev)
+
+    for _ in range(args.warmup):
+        step(batch)
+    torch.cuda.synchronize()
+
+    prof = None if args.no_kernel_events else _lib.LaunchProfiler()
+    _lib.PROFILER = prof
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.PROFILER = None
+    elapsed = max_over_ranks(elapsed, dev)
+
+    out = {
+        "metric": "training samples/sec (whole node) on 5.625deg ERA5 grid",
+        "value": world * B * args.steps / elapsed,
+        "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
+                   "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
+                   "optimizer": "adamw", "parallelism": f"dp{world}",
+                   "final_loss": float(loss)},
+    }
+    if prof is not None and rank == 0:
+        s = prof.summary()
+        gem = [s[k] for k in ("pw_gemm_fwd", "pw_gemm_dgrad", "pw_gemm_wgrad") if k in s]
+        if gem:
+            flops = sum(g["work"] for g in gem)
+            ms = sum(g["ms"] for g in gem)
+            n = sum(g["launches"] for g in gem)
+            ach = flops / (ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)",
+                               "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                               "launches": n, "avg_launch_ms": ms / n,
+                               "flops_per_launch": flops / n,
+                               "share_of_step": ms / (1e3 * elapsed)}
+        for key, name in (("sl_advect_fwd", "roofline_advect_fwd"), ("sl_advect_bwd", "roofline_advect_bwd")):
+            if key in s:
+                r = s[key]
+                ach = r["work"] / (r["ms"] * 1e-3) / 1e9
+                out[name] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                             "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
+                             "bytes_per_launch": r["work"] / r["launches"]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=3)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,3 +106,43 @@ def require_hip(*tensors) -> None:
                                "(there is no CPU fallback; use oracle/ for CPU checks)")
         if t.dtype != torch.float32:
             raise RuntimeError(f"paradis_model_amd ops are fp32; got {t.dtype}")
+
+
+class LaunchProfiler:
+    """Optional HIP-event timing of selected C-ABI calls on the current stream (used by bench.py
+    for the roofline lines).  ``work`` is the algorithmic FLOP or byte count of the call."""
+
+    def __init__(self):
+        self.records = {}     # name -> [work_sum, [(ev0, ev1), ...]]
+
+    def add(self, name, work, ev0, ev1):
+        rec = self.records.setdefault(name, [0.0, []])
+        rec[0] += work
+        rec[1].append((ev0, ev1))
+
+    def summary(self):
+        """name -> dict(launches, work, ms) ; call after torch.cuda.synchronize()"""
+        out = {}
+        for name, (work, evs) in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            out[name] = {"launches": len(evs), "work": work, "ms": ms}
+        return out
+
+
+PROFILER = None
+
+
+def call(name: str, work: float, *args) -> None:
+    """Invoke ``paradis_<name>`` and raise on a non-zero return code; time it when profiling."""
+    fn = getattr(lib, "paradis_" + name)
+    prof = PROFILER
+    if prof is None:
+        check(fn(*args), name)
+        return
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    rc = fn(*args)
+    ev1.record()
+    check(rc, name)
+    prof.add(name, work, ev0, ev1)

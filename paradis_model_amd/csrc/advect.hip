@@ -24,6 +24,8 @@
 
 #pragma clang fp contract(off)
 
+// Diagnostic ablation switches (tools/advect_variants.py builds side libraries with them; the
+// shipped library defines none):  ADV_NO_ATOMIC, ADV_NO_TRIG
 namespace {
 
 constexpr float TWO_PI_F = 6.283185307179586f;
@@ -41,6 +43,11 @@ struct DepState {  // intermediates needed by the backward chain
 
 __device__ __forceinline__ void departure(float u, float v, float sa, float ca, float lon_a,
                                           const AdvGeom& g, float& ix, float& iy, DepState* st) {
+#ifdef ADV_NO_TRIG
+  ix = lon_a * 3.0f + u + (float)g.p; iy = sa * 5.0f + 7.0f + v + (float)g.p;
+  if (st) { st->sp = u; st->cp = v; st->sl = sa; st->cl = ca; st->s = 0.5f; st->n = u; st->d = 1.0f + v * v; }
+  return;
+#endif
   const float lam = -u * g.dt;
   const float phi = -v * g.dt;
   float sp, cp, sl, cl;
@@ -212,6 +219,13 @@ sl_advect_fwd_lds(const float* __restrict__ field, const float* __restrict__ u,
 
 // ======================================================================================
 // LDS schedule, backward
+//
+// The field gradient is a scatter-add of 4x4 (2x2) weighted cotangents per point.  Measured on
+// MI355X (tools/lds_atomic_bench.hip): ds_add_f32 costs ~195 cycles per wave-instruction (lanes are
+// serialised) while ds_add_u64/u32 cost ~6-10.  The scatter therefore accumulates in 64-bit fixed
+// point: every term is scaled by an exact power of two chosen from the plane's max |cotangent|
+// (term < 2^41, resolution max|g| * 2^-41, far below fp32 epsilon), added with integer LDS atomics
+// (associative => bitwise reproducible), and converted back once.
 // ======================================================================================
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -223,9 +237,9 @@ sl_advect_bwd_lds(const float* __restrict__ gout, const float* __restrict__ fiel
                   int64_t uv_bs, int64_t gf_bs, int64_t guv_bs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = g.H, W = g.W, P = H * W;
-  float* Ft = smem;        // [P]
-  float* gFt = smem + P;   // [P]
-  float* gmean = smem + 2 * P;  // [2]
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);  // [P] fixed-point sums
+  float* Ft = smem + 2 * P;        // [P]
+  float* misc = Ft + P;            // [0..1] pole means of gout, [2..5] per-wave max, [6] scale, [7] 1/scale
   const int tid = threadIdx.x, wave = tid >> 6;
   const int b = blockIdx.x / K, k = blockIdx.x - b * K;
   const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
@@ -236,10 +250,15 @@ sl_advect_bwd_lds(const float* __restrict__ gout, const float* __restrict__ fiel
   float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
   float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
 
+  float gmax = 0.f;
   for (int i = tid; i < P; i += 256) {
     Ft[i] = F[i];
-    gFt[i] = 0.f;
+    acc[i] = 0ull;
+    gmax = fmaxf(gmax, fabsf(GO[i]));
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+  if ((tid & 63) == 0) misc[2 + wave] = gmax;
   __syncthreads();
   if (wave < 2) {
     float* row = Ft + (wave == 0 ? 0 : (H - 1) * W);
@@ -249,9 +268,25 @@ sl_advect_bwd_lds(const float* __restrict__ gout, const float* __restrict__ fiel
     // adjoint of the final pole mean: the cotangent of a pole row is its own row mean
     const float* row = GO + (wave == 2 ? 0 : (int64_t)(H - 1) * W);
     float m = wave_row_mean(row, W);
-    if ((tid & 63) == 0) gmean[wave - 2] = m;
+    if ((tid & 63) == 0) misc[wave - 2] = m;
+  }
+  if (tid == 0) {
+    const float mx = fmaxf(fmaxf(misc[2], misc[3]), fmaxf(misc[4], misc[5]));
+    int e = 0;
+    float scale = 0.f, inv = 0.f;
+    if (mx > 0.f && mx < INFINITY) {
+      frexpf(mx, &e);                       // mx < 2^e
+      e = e < -80 ? -80 : (e > 80 ? 80 : e);
+      scale = ldexpf(1.0f, 40 - e);
+      inv = ldexpf(1.0f, e - 40);
+    } else if (!(mx < INFINITY)) {
+      inv = NAN;                            // non-finite cotangent: propagate NaN like float adds would
+    }
+    misc[6] = scale;
+    misc[7] = inv;
   }
   __syncthreads();
+  const float scale = misc[6];
 
   const float kx = ((float)W - 1.0f) / g.d_lon, ky = ((float)H - 1.0f) / g.d_lat;
   for (int idx = tid; idx < P; idx += 256) {
@@ -266,17 +301,24 @@ sl_advect_bwd_lds(const float* __restrict__ gout, const float* __restrict__ fiel
     float dwx[NT], dwy[NT];
     TapSet<MODE>::dweights(tx, dwx);
     TapSet<MODE>::dweights(ty, dwy);
-    const float gval = (y == 0) ? gmean[0] : ((y == H - 1) ? gmean[1] : GO[idx]);
+    const float gval = (y == 0) ? misc[0] : ((y == H - 1) ? misc[1] : GO[idx]);
+    const float gs_ = gval * scale;
     float gix = 0.f, giy = 0.f;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
       float sx = 0.f, sdx = 0.f;
+      const float gwy = gs_ * T.wy[a];
 #pragma unroll
       for (int bb = 0; bb < NT; ++bb) {
         if (T.ok(a, bb)) {
           const int s = T.src(a, bb);
           const float val = Ft[s];
-          atomicAdd(&gFt[s], gval * T.wy[a] * T.wx[bb]);
+#ifndef ADV_NO_ATOMIC
+          const long long q = __float2ll_rn(gwy * T.wx[bb]);
+          atomicAdd(&acc[s], (unsigned long long)q);
+#else
+          sx += gwy * 1e-30f;
+#endif
           sx += val * T.wx[bb];
           sdx += val * dwx[bb];
         }
@@ -301,14 +343,17 @@ sl_advect_bwd_lds(const float* __restrict__ gout, const float* __restrict__ fiel
     GV[idx] = -g.dt * gphi;
   }
   __syncthreads();
-  // adjoint of the first pole mean
+  // fixed point -> float (reuse Ft as the gF~ plane), then the adjoint of the first pole mean
+  const double inv = (double)misc[7];
+  for (int i = tid; i < P; i += 256) Ft[i] = (float)((double)(long long)acc[i] * inv);
+  __syncthreads();
   if (wave < 2) {
-    float* row = gFt + (wave == 0 ? 0 : (H - 1) * W);
+    float* row = Ft + (wave == 0 ? 0 : (H - 1) * W);
     float m = wave_row_mean(row, W);
     for (int x = tid & 63; x < W; x += 64) row[x] = m;
   }
   __syncthreads();
-  for (int i = tid; i < P; i += 256) GF[i] = gFt[i];
+  for (int i = tid; i < P; i += 256) GF[i] = Ft[i];
 }
 
 // ======================================================================================
@@ -534,7 +579,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   AdvGeom g{H, W, p, dt, min_lat, min_lon, d_lat, d_lon};
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * K, P = H * W;
-  const size_t lds = ((size_t)2 * P + 4) * sizeof(float);
+  const size_t lds = ((size_t)3 * P + 8) * sizeof(float);
   if (!use_gmem(lds)) {
     if (mode == PARADIS_INTERP_BICUBIC)
       hipLaunchKernelGGL(sl_advect_bwd_lds<PARADIS_INTERP_BICUBIC>, dim3(planes), dim3(256), lds, st,

@@ -8,11 +8,14 @@
 // Exact fp32: the f32 MFMA is a k-ordered fmaf chain (no TF32/xf32 on gfx950), so results differ
 // from the CPU's blocked SGEMM only by summation order.
 //
-// Tile: 128x128x16 per 256-thread workgroup; wave (wm,wn) owns 64x64 = 2x2 MFMA 32x32 tiles
+// Tile: 128x128x32 per 256-thread workgroup; wave (wm,wn) owns 64x64 = 2x2 MFMA 32x32 tiles
 // (64 accumulator VGPRs).  Both operands are staged through registers into LDS as [k][m|n] images
-// (+4 padding) so that fragment reads are conflict-free ds_read_b32; two LDS stages, one barrier
-// per k-tile, global loads for tile t+1 in flight during the MFMAs of tile t.  Work-group ids are
-// remapped so that the M-tiles that share one X tile run on the same XCD (L2 reuse of X).
+// (row pitch 129 for transposing stores, 132 for vector stores: both conflict-free) so that
+// fragment reads are conflict-free ds_read_b32; two LDS stages (66 KiB => exactly 2 workgroups per
+// CU, which makes every shape of this model an integral number of rounds over the 256 CUs), one
+// barrier per k-tile, global loads for tile t+1 in flight during the 64 MFMAs of tile t, fragment
+// reads for k-step kk+1 issued before the MFMAs of kk.  Work-group ids are remapped so that the
+// M-tiles that share one X tile run on the same XCD (L2 reuse of X).
 #include <algorithm>
 #include "common.h"
 
@@ -20,17 +23,24 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_LD = BM + 4;  // floats per k-row of the LDS image
+constexpr int BM = 128, BN = 128;
+constexpr int ld_of(bool kc) { return kc ? BM + 1 : BM + 4; }  // floats per k-row of the LDS image
+constexpr int stage_floats(int bk) { return bk * (BM + 4); }   // per operand per stage (upper bound)
+constexpr size_t lds_bytes(int bk) { return (size_t)4 * stage_floats(bk) * sizeof(float); }
+constexpr int nv_of(int bk) { return BM * bk / (256 * 4); }    // float4 loads per thread per operand
+
+// Tunables (debug setters below; defaults chosen from tools/gemm_bench.py measurements)
+int g_bk = 16;            // k-tile depth: 16 or 32
+int g_wg_per_cu = 4;      // resident workgroups per CU enforced through the dynamic-LDS request
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
   int M, N, K;
   int64_t lda, ldb, ldc;
   int64_t a_bs, b_bs, c_bs;   // stride between grid batches (fwd/dgrad: sample; wgrad: split slab)
-  int nbatch;                 // grid batches
-  int inner, inner_step;      // wgrad: samples reduced inside one workgroup: ib = batch; ib < inner; ib += inner_step
-  int64_t a_is, b_is;         // strides between inner samples
+  int nbatch;                 // grid batches (fwd/dgrad: samples; wgrad: k-range splits)
+  int inner;                  // wgrad: number of samples reduced (0 for fwd/dgrad)
+  int64_t a_is, b_is;         // wgrad: strides between samples
   // epilogue:  v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v); v += res
   const float* bias; const float* map; const float* res; const float* zmul; float* zout;
   int64_t res_bs, zmul_bs, zout_bs;
@@ -40,14 +50,18 @@ struct GemmArgs {
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
 // KC: element (row=m|n, k) at base[row*ld + k]   (k contiguous)
 // MC: element (row=m|n, k) at base[k*ld + row]   (row contiguous)
-template <bool KC>
+template <bool KC, int BK>
 __device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_t ld, int row0,
-                                          int k0, int rows, int K, bool vec_ok, float4 (&r)[2]) {
+                                          int k0, int rows, int K, bool vec_ok,
+                                          float4 (&r)[nv_of(BK)]) {
+  constexpr int NV = nv_of(BK);
+  constexpr int TPR = BK / 4;       // threads per row (k-contiguous layout)
+  constexpr int RPP = 256 / TPR;    // rows per pass
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (KC) {
-      const int row = row0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
+      const int row = row0 + (tid / TPR) + RPP * i, k = k0 + (tid % TPR) * 4;
       const float* p = base + (int64_t)row * ld + k;
       if (vec_ok && row < rows && k + 3 < K) {
         r[i] = *reinterpret_cast<const float4*>(p);
@@ -72,28 +86,32 @@ __device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void slab_store(float* __restrict__ img, const float4 (&r)[2]) {
+template <bool KC, int BK>
+__device__ __forceinline__ void slab_store(float* __restrict__ img, const float4 (&r)[nv_of(BK)]) {
+  constexpr int LD = ld_of(KC), NV = nv_of(BK);
+  constexpr int TPR = BK / 4, RPP = 256 / TPR;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (KC) {
-      const int m = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
-      img[(k + 0) * LDS_LD + m] = r[i].x;
-      img[(k + 1) * LDS_LD + m] = r[i].y;
-      img[(k + 2) * LDS_LD + m] = r[i].z;
-      img[(k + 3) * LDS_LD + m] = r[i].w;
+      const int m = (tid / TPR) + RPP * i, k = (tid % TPR) * 4;
+      img[(k + 0) * LD + m] = r[i].x;
+      img[(k + 1) * LD + m] = r[i].y;
+      img[(k + 2) * LD + m] = r[i].z;
+      img[(k + 3) * LD + m] = r[i].w;
     } else {
       const int k = (tid >> 5) + 8 * i, m = (tid & 31) * 4;
-      *reinterpret_cast<float4*>(img + k * LDS_LD + m) = r[i];
+      *reinterpret_cast<float4*>(img + k * LD + m) = r[i];
     }
   }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int BK>
 __global__ void __launch_bounds__(256, 2)
 pw_gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDS_LD];  // [stage][A|B]
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [stage][A|B][STAGE_FLOATS]
+  constexpr int LDA = ld_of(A_KC), LDB = ld_of(B_KC);
+  constexpr int NV = nv_of(BK), STAGE_FLOATS = stage_floats(BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -109,13 +127,17 @@ pw_gemm_kernel(GemmArgs g) {
   const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
   const int m0 = mt * BM, n0 = nt * BN;
 
+  // k-tile range of this workgroup.  fwd/dgrad: all KT tiles of sample bz.  wgrad: the flattened
+  // (sample, k-tile) sequence of inner*KT tiles is cut into nbatch equal contiguous ranges.
   const int KT = (g.K + BK - 1) / BK;
-  const int n_inner = g.inner > 0 ? (g.inner - bz + g.inner_step - 1) / g.inner_step : 1;
-  const int T = KT * n_inner;
-
+  int t_begin = 0, T = KT;
+  if (g.inner > 0) {
+    const int64_t total = (int64_t)g.inner * KT;
+    t_begin = (int)(total * bz / g.nbatch);
+    T = (int)(total * (bz + 1) / g.nbatch) - t_begin;
+  }
   const float* Ab = g.A + (g.inner > 0 ? 0 : (int64_t)bz * g.a_bs);
   const float* Bb = g.B + (g.inner > 0 ? 0 : (int64_t)bz * g.b_bs);
-  const int first_inner = g.inner > 0 ? bz : 0;
 
   const bool a_vec = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                      ((g.a_bs & 3) == 0) && ((g.a_is & 3) == 0);
@@ -130,41 +152,47 @@ pw_gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[2];
+  float4 ra[NV], rb[NV];
   auto fetch = [&](int t) {
-    const int ib = t / KT, kt = t - ib * KT;
-    const int64_t isamp = first_inner + (int64_t)ib * g.inner_step;
-    const float* Ap = Ab + (g.inner > 0 ? isamp * g.a_is : 0);
-    const float* Bp = Bb + (g.inner > 0 ? isamp * g.b_is : 0);
-    slab_load<A_KC>(Ap, g.lda, m0, kt * BK, g.M, g.K, a_vec, ra);
-    slab_load<B_KC>(Bp, g.ldb, n0, kt * BK, g.N, g.K, b_vec, rb);
+    const int tt = t_begin + t;
+    const int ib = tt / KT, kt = tt - ib * KT;
+    const float* Ap = Ab + (g.inner > 0 ? (int64_t)ib * g.a_is : 0);
+    const float* Bp = Bb + (g.inner > 0 ? (int64_t)ib * g.b_is : 0);
+    slab_load<A_KC, BK>(Ap, g.lda, m0, kt * BK, g.M, g.K, a_vec, ra);
+    slab_load<B_KC, BK>(Bp, g.ldb, n0, kt * BK, g.N, g.K, b_vec, rb);
   };
+  auto stageA = [&](int st) { return lds + (st * 2 + 0) * STAGE_FLOATS; };
+  auto stageB = [&](int st) { return lds + (st * 2 + 1) * STAGE_FLOATS; };
 
   if (T > 0) {
     fetch(0);
-    slab_store<A_KC>(lds[0][0], ra);
-    slab_store<B_KC>(lds[0][1], rb);
+    slab_store<A_KC, BK>(stageA(0), ra);
+    slab_store<B_KC, BK>(stageB(0), rb);
   }
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     if (t + 1 < T) fetch(t + 1);
-    const float* As = lds[cur][0] + wm * 64 + li;
-    const float* Bs = lds[cur][1] + wn * 64 + li;
+    const float* As = stageA(cur) + wm * 64 + li + lh * LDA;
+    const float* Bs = stageB(cur) + wn * 64 + li + lh * LDB;
+    float a0 = As[0], a1 = As[32], b0 = Bs[0], b1 = Bs[32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int krow = (2 * kk + lh) * LDS_LD;
-      const float a0 = As[krow], a1 = As[krow + 32];
-      const float b0 = Bs[krow], b1 = Bs[krow + 32];
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 1 < BK / 2) {
+        na0 = As[(2 * kk + 2) * LDA]; na1 = As[(2 * kk + 2) * LDA + 32];
+        nb0 = Bs[(2 * kk + 2) * LDB]; nb1 = Bs[(2 * kk + 2) * LDB + 32];
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     if (t + 1 < T) {
-      slab_store<A_KC>(lds[cur ^ 1][0], ra);
-      slab_store<B_KC>(lds[cur ^ 1][1], rb);
+      slab_store<A_KC, BK>(stageA(cur ^ 1), ra);
+      slab_store<B_KC, BK>(stageB(cur ^ 1), rb);
     }
     __syncthreads();
   }
@@ -207,10 +235,37 @@ slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int
   }
 }
 
-int wgrad_splits(int B, int M, int K) {
+int slots() { return 256 * g_wg_per_cu; }
+
+int wgrad_splits(int B, int M, int K, int N) {
   const int tiles = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int s = (1024 + tiles - 1) / tiles;
-  return std::max(1, std::min(s, B));
+  const int64_t total_kt = (int64_t)B * ((N + g_bk - 1) / g_bk);
+  int s = slots() / tiles;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(s, total_kt));
+}
+
+template <bool A_KC, bool B_KC, int BK>
+int launch_gemm_bk(const GemmArgs& g, int grid, hipStream_t st) {
+  // the dynamic-LDS request doubles as the occupancy control: 160 KiB / request = workgroups per CU
+  size_t request = std::max(lds_bytes(BK), (size_t)(160 * 1024 / g_wg_per_cu) & ~(size_t)255);
+  request = std::min(request, (size_t)160 * 1024);
+  static size_t configured = 0;
+  if (configured < request) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<A_KC, B_KC, BK>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess) {
+      paradis_set_error("pw_gemm: cannot reserve LDS");
+      return 2;
+    }
+    configured = 160 * 1024;
+  }
+  hipLaunchKernelGGL((pw_gemm_kernel<A_KC, B_KC, BK>), dim3(grid), dim3(256), request, st, g);
+  return 0;
+}
+
+template <bool A_KC, bool B_KC>
+int launch_gemm(const GemmArgs& g, int grid, hipStream_t st) {
+  return g_bk == 32 ? launch_gemm_bk<A_KC, B_KC, 32>(g, grid, st)
+                    : launch_gemm_bk<A_KC, B_KC, 16>(g, grid, st);
 }
 
 int check_gemm(const char* name, int B, int M, int K, int N) {
@@ -222,6 +277,12 @@ int check_gemm(const char* name, int B, int M, int K, int N) {
 
 }  // namespace
 
+// diagnostic knobs (tools/gemm_bench.py); bk in {16,32}, wg_per_cu in 1..4
+extern "C" void paradis_debug_set_gemm(int bk, int wg_per_cu) {
+  if (bk == 16 || bk == 32) g_bk = bk;
+  if (wg_per_cu >= 1 && wg_per_cu <= 4) g_wg_per_cu = wg_per_cu;
+}
+
 extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float* bias,
                                    const float* map, const float* res, float* Y, float* zpre, int B,
                                    int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
@@ -232,11 +293,11 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float*
   GemmArgs g{};
   g.A = Wt; g.B = X; g.C = Y; g.M = M; g.N = N; g.K = K;
   g.lda = K; g.ldb = N; g.ldc = N;
-  g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0; g.inner_step = 1;
+  g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0;
   g.bias = bias; g.map = map; g.res = res; g.res_bs = res_bs; g.zmul = nullptr; g.zout = zpre;
   g.zout_bs = (int64_t)M * N; g.act = act;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
-  hipLaunchKernelGGL((pw_gemm_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+  if (int e = launch_gemm<true, false>(g, grid, (hipStream_t)stream)) return e;
   PD_CHECK_LAUNCH("pw_gemm_fwd");
   return 0;
 }
@@ -252,17 +313,16 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const flo
   GemmArgs g{};
   g.A = Wt; g.B = dY; g.C = dX; g.M = K; g.N = N; g.K = M;
   g.lda = K; g.ldb = N; g.ldc = N;
-  g.a_bs = 0; g.b_bs = dy_bs; g.c_bs = dx_bs; g.nbatch = B; g.inner = 0; g.inner_step = 1;
+  g.a_bs = 0; g.b_bs = dy_bs; g.c_bs = dx_bs; g.nbatch = B; g.inner = 0;
   g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
   const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
-  hipLaunchKernelGGL((pw_gemm_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+  if (int e = launch_gemm<false, false>(g, grid, (hipStream_t)stream)) return e;
   PD_CHECK_LAUNCH("pw_gemm_dgrad");
   return 0;
 }
 
 extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
-  (void)N;
-  const int S = wgrad_splits(std::max(B, 1), M, K);
+  const int S = wgrad_splits(std::max(B, 1), M, K, N);
   return S > 1 ? (size_t)S * M * K * sizeof(float) + 256 : 256;
 }
 
@@ -276,16 +336,16 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
     if (hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
     return 0;
   }
-  const int S = wgrad_splits(B, M, K);
+  const int S = wgrad_splits(B, M, K, N);
   PD_REQUIRE(S == 1 || workspace != nullptr, "pw_gemm_wgrad: workspace required");
   GemmArgs g{};
   g.A = dY; g.B = X; g.C = S > 1 ? (float*)workspace : dW;
   g.M = M; g.N = K; g.K = N;
   g.lda = N; g.ldb = N; g.ldc = K;
   g.a_bs = 0; g.b_bs = 0; g.c_bs = (int64_t)M * K; g.nbatch = S;
-  g.inner = B; g.inner_step = S; g.a_is = dy_bs; g.b_is = x_bs;
+  g.inner = B; g.a_is = dy_bs; g.b_is = x_bs;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-  hipLaunchKernelGGL((pw_gemm_kernel<true, true>), dim3(grid), dim3(256), 0, st, g);
+  if (int e = launch_gemm<true, true>(g, grid, st)) return e;
   if (S > 1) {
     const int64_t n = (int64_t)M * K;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);

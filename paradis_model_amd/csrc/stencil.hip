@@ -86,11 +86,20 @@ dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
   }
 }
 
+// Data gradient.  With the halo virtual, gx = PadAdjoint(ConvTranspose(gy)).  Folding the halo
+// aliases back analytically gives a stencil on the *geocyclic extension* E of gy itself:
+//   rows of E inside the image : transposed taps        w[p-dr][p-dc]
+//   rows of E beyond a pole    : row index NOT flipped   w[p+dr][p-dc]  (the over-the-pole glide
+//                                reflection reverses the row direction), and they only feed source
+//                                rows 1..p (south) / H-1-p..H-2 (north);
+//   the pole row itself seen through the mirror (dr = -y resp. H-1-y) needs the W/2-shifted pole
+//   row, which differs from E's unshifted row: K extra taps read from global memory.
+// Longitude wrap is implied by E's periodic columns.
 template <int K>
 __global__ void __launch_bounds__(256)
 dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                         float* __restrict__ gx, int C, int H, int W, int tiles_x, int tiles) {
-  constexpr int P = (K - 1) / 2;
+  constexpr int P = (K - 1) / 2, LW = TW + K - 1;
   __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
   const int64_t plane = blockIdx.x / tiles;
   const int t = blockIdx.x - plane * tiles;
@@ -98,32 +107,70 @@ dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
   const int c = plane % C;
   const float* g = gy + plane * (int64_t)H * W;
   const float* wc = w + (int64_t)c * K * K;
-  stage_tile<K, false>(tile, g, H, W, ty0, tx0);
+  stage_tile<K, true>(tile, g, H, W, ty0, tx0);
   __syncthreads();
-  float acc[RPT];
-  tile_stencil<K, true>(tile, wc, acc);
-  const int xx = tx0 + (threadIdx.x & 63), r0 = ty0 + (threadIdx.x >> 6) * RPT;
-  if (xx >= W) return;
-  float* gp = gx + plane * (int64_t)H * W;
+  const int xl = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RPT;
+  float wr[K * K];
 #pragma unroll
-  for (int o = 0; o < RPT; ++o) {
-    const int yy = r0 + o;
-    if (yy >= H) break;
-    float extra = 0.f;
-    const bool border = (yy >= 1 && yy <= P) || (yy >= H - 1 - P && yy <= H - 2) || xx < P || xx >= W - P;
-    if (border) {
-      // halo aliases of (yy,xx): transposed stencil of the zero-extended cotangent at each alias
-      geo_for_each_alias(yy, xx, H, W, P, [&](int ii, int jj) {
-        if (ii == yy && jj == xx) return;
-        for (int a = 0; a < K; ++a) {
-          const int sy = ii + P - a;
-          if (sy < 0 || sy >= H) continue;
-          for (int b = 0; b < K; ++b) {
-            const int sx = jj + P - b;
-            if (sx >= 0 && sx < W) extra += wc[a * K + b] * g[(int64_t)sy * W + sx];
+  for (int i = 0; i < K * K; ++i) wr[i] = wc[i];
+  float acc[RPT];
+#pragma unroll
+  for (int o = 0; o < RPT; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < RPT + K - 1; ++rr) {
+    const int ii = ty0 + r0 + rr - P;   // image row of this tile row (wave-uniform)
+    float val[K];
+#pragma unroll
+    for (int b = 0; b < K; ++b) val[b] = tile[(r0 + rr) * LW + xl + b];
+    if (ii >= 0 && ii < H) {
+#pragma unroll
+      for (int a = 0; a < K; ++a) {       // a = tile row offset of output o: rr = o + a, dr = a - P
+        const int o = rr - a;
+        if (o >= 0 && o < RPT) {
+#pragma unroll
+          for (int b = 0; b < K; ++b) acc[o] += wr[(K - 1 - a) * K + (K - 1 - b)] * val[b];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < K; ++a) {
+        const int o = rr - a;
+        if (o >= 0 && o < RPT) {
+          const int yy = ty0 + r0 + o;
+          const bool feeds = (ii < 0) ? (yy >= 1) : (yy <= H - 2);
+          if (feeds) {
+#pragma unroll
+            for (int b = 0; b < K; ++b) acc[o] += wr[a * K + (K - 1 - b)] * val[b];
           }
         }
-      });
+      }
+    }
+  }
+  const int xx = tx0 + xl;
+  if (xx >= W) return;
+  float* gp = gx + plane * (int64_t)H * W;
+  const int half = W >> 1;
+#pragma unroll
+  for (int o = 0; o < RPT; ++o) {
+    const int yy = ty0 + r0 + o;
+    if (yy >= H) break;
+    float extra = 0.f;
+    // mirrored pole rows: E'[0][jj] = gy[0][jj + W/2], E'[H-1][jj] = gy[H-1][jj + W/2]
+    if (yy >= 1 && yy <= P) {
+      const int a = P - yy;             // dr = -yy
+      for (int b = 0; b < K; ++b) {     // dc = P - b
+        int col = xx + P - b + half;
+        col %= W; if (col < 0) col += W;
+        extra += wc[a * K + b] * g[col];
+      }
+    }
+    if (yy >= H - 1 - P && yy <= H - 2) {
+      const int a = P + (H - 1 - yy);   // dr = H-1-yy
+      for (int b = 0; b < K; ++b) {
+        int col = xx + P - b + half;
+        col %= W; if (col < 0) col += W;
+        extra += wc[a * K + b] * g[(int64_t)(H - 1) * W + col];
+      }
     }
     gp[(int64_t)yy * W + xx] = acc[o] + extra;
   }

@@ -114,10 +114,10 @@ class _SLAdvect(torch.autograd.Function):
         out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
         sl, cl, lo = geom.tables(field.device)
         ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
-        check(lib.paradis_sl_advect_fwd(dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl),
-                                        dptr(lo), B, K, H, W, f_bs, u_bs, K * H * W, dt, geom.min_lat,
-                                        geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode],
-                                        dptr(ws), stream_ptr()), "sl_advect_fwd")
+        _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
+                  dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
+                  f_bs, u_bs, K * H * W, dt, geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon,
+                  MODE_CODES[mode], dptr(ws), stream_ptr())
         ctx.save_for_backward(field, u, v)
         ctx.meta = (geom, dt, mode, f_bs, u_bs)
         return out
@@ -134,11 +134,10 @@ class _SLAdvect(torch.autograd.Function):
         sl, cl, lo = geom.tables(gout.device)
         ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
         P = K * H * W
-        check(lib.paradis_sl_advect_bwd(dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield),
-                                        dptr(gu), dptr(gv), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
-                                        P, f_bs, u_bs, P, 2 * P, dt, geom.min_lat, geom.min_lon,
-                                        geom.d_lat, geom.d_lon, MODE_CODES[mode], dptr(ws),
-                                        stream_ptr()), "sl_advect_bwd")
+        _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
+                  dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
+                  dptr(cl), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, 2 * P, dt, geom.min_lat,
+                  geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode], dptr(ws), stream_ptr())
         return gfield, gu, gv, None, None, None
 
 
@@ -382,9 +381,8 @@ class _Pointwise(torch.autograd.Function):
         y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
         need_z = act != 0 and any(ctx.needs_input_grad[:4])
         z = torch.empty_like(y) if need_z else None
-        check(lib.paradis_pw_gemm_fwd(dptr(w2), dptr(x), dptr(bias), dptr(bmap), dptr(residual), dptr(y),
-                                      dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr()),
-              "pw_gemm_fwd")
+        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(x), dptr(bias), dptr(bmap),
+                  dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
         ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0))
         ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape)
         return y
@@ -406,13 +404,13 @@ class _Pointwise(torch.autograd.Function):
         gx = gw = gb = gmap = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, Ci, H, W, dtype=gy.dtype, device=gy.device)
-            check(lib.paradis_pw_gemm_dgrad(dptr(w2), dptr(dz), None, None, dptr(gx), B, Co, Ci, P,
-                                            Co * P, 0, 0, Ci * P, 0, st), "pw_gemm_dgrad")
+            _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(dz), None, None, dptr(gx),
+                      B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st)
         if ctx.needs_input_grad[1]:
             gw = torch.empty(Co, Ci, dtype=gy.dtype, device=gy.device)
             ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), gy.device)
-            check(lib.paradis_pw_gemm_wgrad(dptr(dz), dptr(x), dptr(gw), B, Co, Ci, P, Co * P, x_bs,
-                                            dptr(ws), st), "pw_gemm_wgrad")
+            _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), B, Co, Ci, P,
+                      Co * P, x_bs, dptr(ws), st)
             gw = gw.reshape(wshape)
         want_b = has_bias and ctx.needs_input_grad[2]
         want_m = has_map and ctx.needs_input_grad[3]

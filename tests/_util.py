@@ -46,9 +46,11 @@ def load_golden(name):
 
 def max_rel(a, b):
     """max-abs(diff) / max-abs(ref): the tolerance metric of SURVEY.md section 8c"""
+    a, b = a.detach(), b.detach()
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
 
 def rms_rel(a, b):
+    a, b = a.detach(), b.detach()
     d = (a.double() - b.double())
     return float(d.pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt().clamp_min(1e-30))

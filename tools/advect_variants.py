@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Diagnostic: time ablated builds of the advection kernels (A/B in one process, HIP events).
+Usage on the GPU box:  python tools/advect_variants.py   (builds side libraries under build/variants)"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "paradis_model_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "variants")
+VARIANTS = {"base": [], "no_atomic": ["-DADV_NO_ATOMIC"], "no_trig": ["-DADV_NO_TRIG"],
+            "no_both": ["-DADV_NO_ATOMIC", "-DADV_NO_TRIG"]}
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        so = os.path.join(OUT, f"libadv_{name}.so")
+        if os.path.exists(so):
+            continue
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
+               "-munsafe-fp-atomics", "-ffp-contract=off", "-shared", *flags,
+               os.path.join(CSRC, "advect.hip"), os.path.join(CSRC, "error.hip"), "-o", so]
+        subprocess.run(cmd, check=True)
+
+
+def main():
+    build()
+    if not torch.cuda.is_available():
+        print("built variants; no GPU here")
+        return
+    from paradis_model_amd import _lib
+    B, K, H, W = 32, 768, 32, 64
+    from paradis_model_amd.harness import make_grids
+    from paradis_model_amd.ops import AdvectGeometry
+    _, lg, og = make_grids(H, W, False)
+    geom = AdvectGeometry(lg, og)
+    sl, cl, lo = geom.tables("cuda")
+    f = torch.randn(B, K, H, W, device="cuda")
+    vel = torch.randn(B, 2 * K, H, W, device="cuda")
+    u, v = vel[:, :K], vel[:, K:]
+    go = torch.randn(B, K, H, W, device="cuda")
+    out = torch.empty_like(f); gf = torch.empty_like(f); guv = torch.empty_like(vel)
+    ws = torch.empty(B * K * 4 + 64, device="cuda")
+    P = K * H * W
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    libs = {}
+    for name in VARIANTS:
+        L = ctypes.CDLL(os.path.join(OUT, f"libadv_{name}.so"))
+        L.paradis_sl_advect_fwd.argtypes = _lib.SIGNATURES["paradis_sl_advect_fwd"][1]
+        L.paradis_sl_advect_bwd.argtypes = _lib.SIGNATURES["paradis_sl_advect_bwd"][1]
+        libs[name] = L
+    def fwd(L):
+        return L.paradis_sl_advect_fwd(p(f), p(u), p(v), p(out), p(sl), p(cl), p(lo), B, K, H, W, P, 2 * P, P,
+                                       0.196887, geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, 2, p(ws), st)
+    def bwd(L):
+        return L.paradis_sl_advect_bwd(p(go), p(f), p(u), p(v), p(gf), p(guv[:, :K]), p(guv[:, K:]), p(sl), p(cl),
+                                       p(lo), B, K, H, W, P, P, 2 * P, P, 2 * P, 0.196887, geom.min_lat,
+                                       geom.min_lon, geom.d_lat, geom.d_lon, 2, p(ws), st)
+    for scale in (1.0, 0.05):
+        vel.normal_().mul_(scale)
+        for kind, fn in (("fwd", fwd), ("bwd", bwd)):
+            for rnd in range(2):
+                for name, L in libs.items():
+                    assert fn(L) == 0
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        fn(L)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd == 1:
+                        print(f"vel_scale={scale} {kind} {name:10s} {e0.elapsed_time(e1) / 5 * 1e3:9.1f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic: A/B the FP32-MFMA pointwise GEMM tunables (k-tile depth, resident workgroups per CU)
+over the GEMM shapes of the default PARADIS layer, interleaved in one process (HIP events)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from paradis_model_amd import _lib  # noqa: E402
+from paradis_model_amd._lib import dptr, lib, stream_ptr  # noqa: E402
+
+B, P = 32, 2048
+SHAPES = [(1024, 186), (384, 1024), (1536, 384), (768, 1024), (1024, 768), (1024, 1024), (896, 1152),
+          (896, 896), (1024, 896), (768, 768), (97, 768)]   # (Co, Ci)
+CONFIGS = [(16, 4), (16, 3), (16, 2), (32, 2), (32, 1)] if len(sys.argv) < 2 else \
+    [tuple(map(int, a.split(","))) for a in sys.argv[1:]]
+lib.paradis_debug_set_gemm.argtypes = [ctypes.c_int, ctypes.c_int]
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    st = stream_ptr()
+    tot = {c: {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0} for c in CONFIGS}
+    for (Co, Ci) in SHAPES:
+        w = torch.randn(Co, Ci, device="cuda") * Ci ** -0.5
+        x = torch.randn(B, Ci, P, device="cuda")
+        dy = torch.randn(B, Co, P, device="cuda")
+        y = torch.empty(B, Co, P, device="cuda")
+        dx = torch.empty(B, Ci, P, device="cuda")
+        dw = torch.empty(Co, Ci, device="cuda")
+        ws = torch.empty(64 << 20, device="cuda")
+        flops = 2.0 * B * Co * Ci * P
+        line = f"Co={Co:5d} Ci={Ci:5d} |"
+        for cfg in CONFIGS:
+            lib.paradis_debug_set_gemm(*cfg)
+            t = {}
+            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(x), None, None, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
+            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
+            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), B, Co, Ci, P, Co * P, Ci * P, dptr(ws), st))
+            for k in t:
+                tot[cfg][k] += t[k]
+            line += "  bk%d/wg%d: " % cfg + " ".join(f"{k[0]}{flops / t[k] / 1e6:6.1f}" for k in ("fwd", "dgrad", "wgrad"))
+        print(line, flush=True)
+    for cfg in CONFIGS:
+        print("total us bk%d/wg%d:" % cfg, {k: round(v) for k, v in tot[cfg].items()}, "sum", round(sum(tot[cfg].values())))
+
+
+if __name__ == "__main__":
+    main()
