@@ -84,7 +84,8 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
 /* ---- a6: CLinear / pointwise half of SepConv (reference model/blocks.py:86,110): per-sample GEMM
  * on FP32 MFMA.  Y[b] = epi( W[M,K] * X[b][K,N] ),  epi(v) = res + act(v + bias[m] + map[m,n]).
  * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value. */
-int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float* bias, const float* map,
+int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
+                        const float* X, const float* bias, const float* map,
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
                         int act, void* stream);
@@ -137,6 +138,8 @@ int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C,
                        int64_t dz_bs, void* stream);
 /* y = a + b (n elements) */
 int paradis_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+/* out[cols,rows] = in[rows,cols]^T (weights for the LDS-DMA forward GEMM) */
+int paradis_transpose(const float* in, float* out, int rows, int cols, void* stream);
 /* y[b,i] = x[b,i] + m[i], i < per_sample  (standalone GlobalBias.forward, reference model/blocks.py:196) */
 int paradis_add_bcast(const float* x, const float* m, float* y, int64_t per_sample, int B, void* stream);
 

@@ -32,6 +32,8 @@ constexpr int nv_of(int bk) { return BM * bk / (256 * 4); }    // float4 loads p
 // Tunables (debug setters below; defaults chosen from tools/gemm_bench.py measurements)
 int g_bk = 16;            // k-tile depth: 16 or 32
 int g_wg_per_cu = 4;      // resident workgroups per CU enforced through the dynamic-LDS request
+int g_stagger = 0;        // see GemmArgs::stagger
+int g_dma_stages = 3;     // LDS-DMA ring depth for row-contiguous operands (0 = never use the DMA kernel)
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -45,6 +47,7 @@ struct GemmArgs {
   const float* bias; const float* map; const float* res; const float* zmul; float* zout;
   int64_t res_bs, zmul_bs, zout_bs;
   int act;
+  int stagger;                // start-up skew between co-resident workgroups, in units of 512 cycles
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -63,7 +66,11 @@ __device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_
     if (KC) {
       const int row = row0 + (tid / TPR) + RPP * i, k = k0 + (tid % TPR) * 4;
       const float* p = base + (int64_t)row * ld + k;
+#ifdef GEMM_UNGUARDED
+      if (true) {
+#else
       if (vec_ok && row < rows && k + 3 < K) {
+#endif
         r[i] = *reinterpret_cast<const float4*>(p);
       } else {
         float t[4];
@@ -74,7 +81,11 @@ __device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_
     } else {
       const int k = k0 + (tid >> 5) + 8 * i, row = row0 + (tid & 31) * 4;
       const float* p = base + (int64_t)k * ld + row;
+#ifdef GEMM_UNGUARDED
+      if (true) {
+#else
       if (vec_ok && k < K && row + 3 < rows) {
+#endif
         r[i] = *reinterpret_cast<const float4*>(p);
       } else {
         float t[4];
@@ -102,6 +113,37 @@ __device__ __forceinline__ void slab_store(float* __restrict__ img, const float4
     } else {
       const int k = (tid >> 5) + 8 * i, m = (tid & 31) * 4;
       *reinterpret_cast<float4*>(img + k * LD + m) = r[i];
+    }
+  }
+}
+
+// ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int bz, int m0,
+                                              int n0, int wm, int wn, int li, int lh) {
+  float* Cb = g.C + (int64_t)bz * g.c_bs;
+  const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
+  const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
+  float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      const float bv = g.bias ? g.bias[m] : 0.f;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = n0 + wn * 64 + tn * 32 + li;
+        if (n >= g.N) continue;
+        const int64_t off = (int64_t)m * g.ldc + n;
+        float v = acc[tm][tn][r] + bv;
+        if (g.map) v += g.map[off];
+        if (zoutb) zoutb[off] = v;
+        if (zmulb) v *= act_grad(zmulb[off], g.act);
+        else if (g.act) v = act_apply(v, g.act);
+        if (resb) v += resb[off];
+        Cb[off] = v;
+      }
     }
   }
 }
@@ -144,6 +186,14 @@ pw_gemm_kernel(GemmArgs g) {
   const bool b_vec = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
                      ((g.b_bs & 3) == 0) && ((g.b_is & 3) == 0);
 
+  // Co-resident workgroups of one CU (dispatch ids 256 apart) run the same program with one
+  // barrier per k-tile and drift into lockstep: their non-MFMA phases (LDS store, barrier, global
+  // issue) then coincide and the matrix pipe idles.  Skew their start by a fraction of a k-tile.
+  if (g.stagger > 0) {
+    const int lag = (blockIdx.x >> 8) & 3;
+    for (int i = 0; i < lag * g.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -171,16 +221,28 @@ pw_gemm_kernel(GemmArgs g) {
   }
   __syncthreads();
 
+  // Diagnostic ablations (tools/gemm_variants.py): GEMM_NO_STAGE, GEMM_NO_BARRIER, GEMM_NO_LDSREAD
   for (int t = 0; t < T; ++t) {
+#ifdef GEMM_NO_STAGE
+    const int cur = 0;
+#else
     const int cur = t & 1;
+#ifndef GEMM_NO_GLOAD
     if (t + 1 < T) fetch(t + 1);
+#endif
+#endif
     const float* As = stageA(cur) + wm * 64 + li + lh * LDA;
     const float* Bs = stageB(cur) + wn * 64 + li + lh * LDB;
     float a0 = As[0], a1 = As[32], b0 = Bs[0], b1 = Bs[32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+#ifdef GEMM_NO_LDSREAD
+      na0 = a0 + 1.0f; na1 = a1; nb0 = b0; nb1 = b1;
+      if (false) {
+#else
       if (kk + 1 < BK / 2) {
+#endif
         na0 = As[(2 * kk + 2) * LDA]; na1 = As[(2 * kk + 2) * LDA + 32];
         nb0 = Bs[(2 * kk + 2) * LDB]; nb1 = Bs[(2 * kk + 2) * LDB + 32];
       }
@@ -190,40 +252,120 @@ pw_gemm_kernel(GemmArgs g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
+#ifndef GEMM_NO_STAGE
     if (t + 1 < T) {
+#ifdef GEMM_NO_LDSSTORE
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { asm volatile("" ::"v"(ra[i].x), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].w)); }
+#else
       slab_store<A_KC, BK>(stageA(cur ^ 1), ra);
       slab_store<B_KC, BK>(stageB(cur ^ 1), rb);
+#endif
     }
+#endif
+#ifndef GEMM_NO_BARRIER
     __syncthreads();
+#endif
   }
 
-  // ---- epilogue -------------------------------------------------------------------------
-  float* Cb = g.C + (int64_t)bz * g.c_bs;
-  const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
-  const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
-  float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
+  gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+}
+
+// ======================================================================================
+// LDS-DMA variant for row-contiguous operands (A(m,k) at A[k*lda+m], B(k,n) at B[k*ldb+n]):
+// fwd with pre-transposed weights, dgrad.  Tiles go global -> LDS with global_load_lds_dwordx4
+// (no VGPR staging, no ds_write), an S-deep LDS ring, counted vmcnt and a raw barrier per k-tile,
+// so that S-1 tiles of loads stay in flight behind the MFMAs (measured on the register-staged
+// kernel: exposed global-load latency costs ~25 % of the matrix pipe).
+// Requirements (checked by the host, else the register-staged kernel is used):
+//   K % 16 == 0, lda/ldb/batch strides multiples of 4 floats, 16-B aligned bases, M % 4 == N % 4 == 0.
+// Out-of-range rows/cols of edge tiles are clamped to valid addresses; they only feed outputs
+// that the epilogue discards.
+// ======================================================================================
+constexpr int DBK = 16;                 // k-tile depth of the DMA kernel
+constexpr int DTILE = DBK * BM;         // floats per operand per stage (pitch 128, unpadded)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int S>
+__global__ void __launch_bounds__(256)
+pw_gemm_dma_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A|B][DTILE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T = g.K / DBK;
+
+  // this lane's source column inside a 2-row piece, clamped to stay inside the matrix
+  const int pr = lane >> 5, pc = (lane & 31) * 4;
+  const int acol = min(m0 + pc, g.M - 4), bcol = min(n0 + pc, g.N - 4);
+  const float* Ap = g.A + (int64_t)bz * g.a_bs + (int64_t)(2 * (2 * wave) + pr) * g.lda + acol;
+  const float* Bp = g.B + (int64_t)bz * g.b_bs + (int64_t)(2 * (2 * wave) + pr) * g.ldb + bcol;
+  const int64_t a_piece = 2 * g.lda, b_piece = 2 * g.ldb;      // next 2-row piece
+  const int64_t a_tile = (int64_t)DBK * g.lda, b_tile = (int64_t)DBK * g.ldb;
+
+  auto issue = [&](int t) {
+    float* st = lds + (t % S) * (2 * DTILE);
+    const float* a = Ap + (int64_t)t * a_tile;
+    const float* b = Bp + (int64_t)t * b_tile;
+    // wave w owns pieces 2w, 2w+1 (k-rows 4w..4w+3) of both operands
+    float* la = st + (2 * wave) * 256;
+    float* lb = st + DTILE + (2 * wave) * 256;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)a, (lds_ptr_t)la, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a + a_piece), (lds_ptr_t)(la + 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)b, (lds_ptr_t)lb, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b + b_piece), (lds_ptr_t)(lb + 256), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= g.M) continue;
-      const float bv = g.bias ? g.bias[m] : 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int n = n0 + wn * 64 + tn * 32 + li;
-        if (n >= g.N) continue;
-        const int64_t off = (int64_t)m * g.ldc + n;
-        float v = acc[tm][tn][r] + bv;
-        if (g.map) v += g.map[off];
-        if (zoutb) zoutb[off] = v;
-        if (zmulb) v *= act_grad(zmulb[off], g.act);
-        else if (g.act) v = act_apply(v, g.act);
-        if (resb) v += resb[off];
-        Cb[off] = v;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (t < T) issue(t);
+
+  for (int t = 0; t < T; ++t) {
+    // tile t must have landed; up to S-2 younger tiles (4 DMAs each per wave) stay in flight
+    const int pending = min(S - 2, T - 1 - t);
+    if (pending >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (pending == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // the stage of tile t-1 is free now (every wave has passed its MFMAs): refill it
+    if (t + S - 1 < T) issue(t + S - 1);
+    const float* As = lds + (t % S) * (2 * DTILE) + wm * 64 + li + lh * BM;
+    const float* Bs = As - wm * 64 + DTILE + wn * 64;
+    float a0 = As[0], a1 = As[32], b0 = Bs[0], b1 = Bs[32];
+#pragma unroll
+    for (int kk = 0; kk < DBK / 2; ++kk) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 1 < DBK / 2) {
+        na0 = As[(2 * kk + 2) * BM]; na1 = As[(2 * kk + 2) * BM + 32];
+        nb0 = Bs[(2 * kk + 2) * BN]; nb1 = Bs[(2 * kk + 2) * BN + 32];
       }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
   }
+  gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
 __global__ void __launch_bounds__(256)
@@ -262,6 +404,23 @@ int launch_gemm_bk(const GemmArgs& g, int grid, hipStream_t st) {
   return 0;
 }
 
+bool dma_eligible(const GemmArgs& g) {
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return g_dma_stages >= 2 && g.inner == 0 && g.K % DBK == 0 && g.M % 4 == 0 && g.N % 4 == 0 &&
+         g.M >= 4 && g.N >= 4 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.a_bs & 3) == 0 &&
+         (g.b_bs & 3) == 0 && a16(g.A) && a16(g.B);
+}
+
+int launch_gemm_dma(const GemmArgs& g, int grid, hipStream_t st) {
+  const size_t bytes = (size_t)g_dma_stages * 2 * DTILE * sizeof(float);
+  switch (g_dma_stages) {
+    case 2: hipLaunchKernelGGL(pw_gemm_dma_kernel<2>, dim3(grid), dim3(256), bytes, st, g); break;
+    case 3: hipLaunchKernelGGL(pw_gemm_dma_kernel<3>, dim3(grid), dim3(256), bytes, st, g); break;
+    default: hipLaunchKernelGGL(pw_gemm_dma_kernel<4>, dim3(grid), dim3(256), (size_t)4 * 2 * DTILE * sizeof(float), st, g); break;
+  }
+  return 0;
+}
+
 template <bool A_KC, bool B_KC>
 int launch_gemm(const GemmArgs& g, int grid, hipStream_t st) {
   return g_bk == 32 ? launch_gemm_bk<A_KC, B_KC, 32>(g, grid, st)
@@ -282,11 +441,13 @@ extern "C" void paradis_debug_set_gemm(int bk, int wg_per_cu) {
   if (bk == 16 || bk == 32) g_bk = bk;
   if (wg_per_cu >= 1 && wg_per_cu <= 4) g_wg_per_cu = wg_per_cu;
 }
+extern "C" void paradis_debug_set_gemm_stagger(int units) { g_stagger = units < 0 ? 0 : units; }
+extern "C" void paradis_debug_set_gemm_dma(int stages) { g_dma_stages = stages < 2 ? 0 : (stages > 4 ? 4 : stages); }
 
-extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float* bias,
-                                   const float* map, const float* res, float* Y, float* zpre, int B,
-                                   int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
-                                   int act, void* stream) {
+extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const float* X,
+                                   const float* bias, const float* map, const float* res, float* Y,
+                                   float* zpre, int B, int M, int K, int N, int64_t x_bs,
+                                   int64_t res_bs, int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
   if (B == 0) return 0;
@@ -296,7 +457,17 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* X, const float*
   g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0;
   g.bias = bias; g.map = map; g.res = res; g.res_bs = res_bs; g.zmul = nullptr; g.zout = zpre;
   g.zout_bs = (int64_t)M * N; g.act = act;
+  g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  if (WtT != nullptr) {   // weights also supplied as [K,M]: row-contiguous A operand -> LDS-DMA kernel
+    GemmArgs d = g;
+    d.A = WtT; d.lda = M;
+    if (dma_eligible(d)) {
+      launch_gemm_dma(d, grid, (hipStream_t)stream);
+      PD_CHECK_LAUNCH("pw_gemm_fwd(dma)");
+      return 0;
+    }
+  }
   if (int e = launch_gemm<true, false>(g, grid, (hipStream_t)stream)) return e;
   PD_CHECK_LAUNCH("pw_gemm_fwd");
   return 0;
@@ -315,7 +486,13 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const flo
   g.lda = K; g.ldb = N; g.ldc = N;
   g.a_bs = 0; g.b_bs = dy_bs; g.c_bs = dx_bs; g.nbatch = B; g.inner = 0;
   g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
+  g.stagger = g_stagger;
   const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  if (dma_eligible(g)) {
+    launch_gemm_dma(g, grid, (hipStream_t)stream);
+    PD_CHECK_LAUNCH("pw_gemm_dgrad(dma)");
+    return 0;
+  }
   if (int e = launch_gemm<false, false>(g, grid, (hipStream_t)stream)) return e;
   PD_CHECK_LAUNCH("pw_gemm_dgrad");
   return 0;
@@ -344,6 +521,7 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.lda = N; g.ldb = N; g.ldc = K;
   g.a_bs = 0; g.b_bs = 0; g.c_bs = (int64_t)M * K; g.nbatch = S;
   g.inner = B; g.a_is = dy_bs; g.b_is = x_bs;
+  g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
   if (int e = launch_gemm<true, true>(g, grid, st)) return e;
   if (S > 1) {

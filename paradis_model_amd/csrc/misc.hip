@@ -155,6 +155,19 @@ add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ m, float
     y[i] = x[i] + m[i % per];
 }
 
+// out[c][r] = in[r][c]  (32x32 tiles through LDS; used once per forward per weight matrix)
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 // ------------------------------------------------------------------ gated blend
 __global__ void __launch_bounds__(256)
 gated_blend_fwd_kernel(const float* __restrict__ h, const float* __restrict__ adv,
@@ -367,5 +380,13 @@ extern "C" int paradis_add_bcast(const float* x, const float* m, float* y, int64
   hipLaunchKernelGGL(add_bcast_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, m,
                      y, per_sample, total);
   PD_CHECK_LAUNCH("add_bcast");
+  return 0;
+}
+
+extern "C" int paradis_transpose(const float* in, float* out, int rows, int cols, void* stream) {
+  PD_REQUIRE(rows >= 1 && cols >= 1, "transpose: bad shape");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                     (hipStream_t)stream, in, out, rows, cols);
+  PD_CHECK_LAUNCH("transpose");
   return 0;
 }

@@ -381,8 +381,14 @@ class _Pointwise(torch.autograd.Function):
         y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
         need_z = act != 0 and any(ctx.needs_input_grad[:4])
         z = torch.empty_like(y) if need_z else None
-        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(x), dptr(bias), dptr(bmap),
-                  dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
+        # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
+        w2t = None
+        if Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
+            w2t = torch.empty(Ci, Co, dtype=x.dtype, device=x.device)
+            check(lib.paradis_transpose(dptr(w2), dptr(w2t), Co, Ci, stream_ptr()), "transpose")
+        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(x), dptr(bias),
+                  dptr(bmap), dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act,
+                  stream_ptr())
         ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0))
         ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape)
         return y

@@ -15,9 +15,13 @@ from paradis_model_amd._lib import dptr, lib, stream_ptr  # noqa: E402
 B, P = 32, 2048
 SHAPES = [(1024, 186), (384, 1024), (1536, 384), (768, 1024), (1024, 768), (1024, 1024), (896, 1152),
           (896, 896), (1024, 896), (768, 768), (97, 768)]   # (Co, Ci)
-CONFIGS = [(16, 4), (16, 3), (16, 2), (32, 2), (32, 1)] if len(sys.argv) < 2 else \
+# (bk, workgroups/CU of the register-staged kernel, LDS-DMA ring depth [0 = off])
+CONFIGS = [(16, 4, 0), (16, 4, 2), (16, 4, 3), (16, 4, 4)] if len(sys.argv) < 2 else \
     [tuple(map(int, a.split(","))) for a in sys.argv[1:]]
+CONFIGS = [c if len(c) == 3 else (*c, 0) for c in CONFIGS]
+lib.paradis_debug_set_gemm_dma.argtypes = [ctypes.c_int]
 lib.paradis_debug_set_gemm.argtypes = [ctypes.c_int, ctypes.c_int]
+lib.paradis_debug_set_gemm_stagger.argtypes = [ctypes.c_int]
 
 
 def timeit(fn, reps=5):
@@ -35,6 +39,7 @@ def main():
     tot = {c: {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0} for c in CONFIGS}
     for (Co, Ci) in SHAPES:
         w = torch.randn(Co, Ci, device="cuda") * Ci ** -0.5
+        wt = w.t().contiguous()
         x = torch.randn(B, Ci, P, device="cuda")
         dy = torch.randn(B, Co, P, device="cuda")
         y = torch.empty(B, Co, P, device="cuda")
@@ -44,17 +49,19 @@ def main():
         flops = 2.0 * B * Co * Ci * P
         line = f"Co={Co:5d} Ci={Ci:5d} |"
         for cfg in CONFIGS:
-            lib.paradis_debug_set_gemm(*cfg)
+            lib.paradis_debug_set_gemm(cfg[0], cfg[1])
+            lib.paradis_debug_set_gemm_dma(cfg[2])
+            use_t = cfg[2] >= 2
             t = {}
-            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(x), None, None, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
+            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(x), None, None, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
             t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
             t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), B, Co, Ci, P, Co * P, Ci * P, dptr(ws), st))
             for k in t:
                 tot[cfg][k] += t[k]
-            line += "  bk%d/wg%d: " % cfg + " ".join(f"{k[0]}{flops / t[k] / 1e6:6.1f}" for k in ("fwd", "dgrad", "wgrad"))
+            line += "  bk%d/wg%d/dma%d: " % cfg + " ".join(f"{k[0]}{flops / t[k] / 1e6:6.1f}" for k in ("fwd", "dgrad", "wgrad"))
         print(line, flush=True)
     for cfg in CONFIGS:
-        print("total us bk%d/wg%d:" % cfg, {k: round(v) for k, v in tot[cfg].items()}, "sum", round(sum(tot[cfg].values())))
+        print("total us bk%d/wg%d/dma%d:" % cfg, {k: round(v) for k, v in tot[cfg].items()}, "sum", round(sum(tot[cfg].values())))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Diagnostic: time ablated builds of the pointwise GEMM (results are WRONG by construction; only
+the timing matters) to attribute the matrix-pipe idle time."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "paradis_model_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "variants")
+VARIANTS = {"base": [], "no_stage": ["-DGEMM_NO_STAGE"],
+            "no_stage_no_barrier": ["-DGEMM_NO_STAGE", "-DGEMM_NO_BARRIER"],
+            "mfma_only": ["-DGEMM_NO_STAGE", "-DGEMM_NO_BARRIER", "-DGEMM_NO_LDSREAD"],
+            "no_barrier": ["-DGEMM_NO_BARRIER"], "no_ldsstore": ["-DGEMM_NO_LDSSTORE"],
+            "no_gload": ["-DGEMM_NO_GLOAD"], "unguarded": ["-DGEMM_UNGUARDED"],
+            "unguarded_no_ldsstore": ["-DGEMM_UNGUARDED", "-DGEMM_NO_LDSSTORE"]}
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        so = os.path.join(OUT, f"libgemm_{name}.so")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
+               "-munsafe-fp-atomics", "-shared", *flags, os.path.join(CSRC, "gemm.hip"),
+               os.path.join(CSRC, "error.hip"), "-o", so]
+        subprocess.run(cmd, check=True)
+
+
+def main():
+    if not torch.cuda.is_available():
+        build()
+        print("built")
+        return
+    from paradis_model_amd import _lib
+    B, P, Co, Ci = 32, 2048, 1024, 1024
+    w = torch.randn(Co, Ci, device="cuda") / 32
+    x = torch.randn(B, Ci, P, device="cuda")
+    y = torch.empty(B, Co, P, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    flops = 2.0 * B * Co * Ci * P
+    libs = {}
+    for name in VARIANTS:
+        L = ctypes.CDLL(os.path.join(OUT, f"libgemm_{name}.so"))
+        L.paradis_pw_gemm_fwd.argtypes = _lib.SIGNATURES["paradis_pw_gemm_fwd"][1]
+        libs[name] = L
+    occ = [int(a) for a in sys.argv[1:]] or [4]
+    for name, L in libs.items():
+        L.paradis_debug_set_gemm.argtypes = [ctypes.c_int, ctypes.c_int]
+    for wg in occ:
+      for L in libs.values():
+          L.paradis_debug_set_gemm(16, wg)
+      print("workgroups per CU:", wg)
+      for rnd in range(2):
+        for name, L in libs.items():
+            if name not in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") and wg != 4:
+                continue
+            fn = lambda: L.paradis_pw_gemm_fwd(p(w), None, p(x), None, None, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
+            assert fn() == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 5 * 1e3
+            if rnd:
+                print(f"{name:22s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF")
+
+
+if __name__ == "__main__":
+    main()
