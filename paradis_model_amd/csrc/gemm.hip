@@ -34,6 +34,7 @@ int g_bk = 16;            // k-tile depth: 16 or 32
 int g_wg_per_cu = 4;      // resident workgroups per CU enforced through the dynamic-LDS request
 int g_stagger = 0;        // see GemmArgs::stagger
 int g_dma_stages = 3;     // LDS-DMA ring depth for row-contiguous operands (0 = never use the DMA kernel)
+int g_wgrad_dma_stages = 2;  // LDS-DMA ring depth of the weight-gradient kernel (0 = register-staged)
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -118,12 +119,71 @@ __device__ __forceinline__ void slab_store(float* __restrict__ img, const float4
 }
 
 // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+//   v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v); v += res; C = v
+// Interior tiles take a path without per-element guards in which all loads of one 32-row group are
+// issued back to back (the guarded form serialises every load behind an s_waitcnt vmcnt(0)).
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int bz, int m0,
                                               int n0, int wm, int wn, int li, int lh) {
   float* Cb = g.C + (int64_t)bz * g.c_bs;
   const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
   const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
   float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int mrow = m0 + wm * 64 + tm * 32 + 4 * lh;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int64_t base = (int64_t)mrow * g.ldc + n0 + wn * 64 + tn * 32 + li;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // 8 accumulator registers at a time keeps the kernel <= 128 VGPRs
+          float v[8], t[8];
+          // register r = 8h + q  ->  row offset (q&3) + 8*(2h + (q>>2))
+#define ROWOFF(q) ((int64_t)(((q) & 3) + 8 * (2 * h + ((q) >> 2))) * g.ldc)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = acc[tm][tn][8 * h + q];
+          if (g.bias) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = g.bias[mrow + (q & 3) + 8 * (2 * h + (q >> 2))];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+          }
+          if (g.map) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = g.map[base + ROWOFF(q)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+          }
+          if (zoutb) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zoutb[base + ROWOFF(q)] = v[q];
+          }
+          if (zmulb) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = zmulb[base + ROWOFF(q)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= act_grad(t[q], g.act);
+          } else if (g.act) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = act_apply(v[q], g.act);
+          }
+          if (resb) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = resb[base + ROWOFF(q)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) Cb[base + ROWOFF(q)] = v[q];
+          // keep the scheduler from hoisting the next chunk's loads (register pressure)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#undef ROWOFF
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -149,7 +209,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 }
 
 template <bool A_KC, bool B_KC, int BK>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (BK == 16 ? 4 : 2))
 pw_gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [stage][A|B][STAGE_FLOATS]
   constexpr int LDA = ld_of(A_KC), LDB = ld_of(B_KC);
@@ -288,8 +348,8 @@ constexpr int DTILE = DBK * BM;         // floats per operand per stage (pitch 1
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int S>
-__global__ void __launch_bounds__(256)
+template <int S, int MINW>
+__global__ void __launch_bounds__(256, MINW)
 pw_gemm_dma_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A|B][DTILE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,6 +428,110 @@ pw_gemm_dma_kernel(GemmArgs g) {
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
+// ======================================================================================
+// LDS-DMA weight-gradient kernel: dW[M,N'] = sum over (sample, p) of A[m][p] * B[n][p] with BOTH
+// operands k(=p)-contiguous.  A 128x16 slab is DMA'd as 8 pieces of 16 rows x 64 B into a
+// [row][16 k] LDS image whose 16-B chunks are XOR-swizzled on the SOURCE side
+// (slot = chunk ^ ((row>>2)&3)) so that ds_read_b128 of one chunk per lane is bank-conflict free.
+// MFMA k-permutation: lanes 0-31 read chunk 2g, lanes 32-63 chunk 2g+1 of their row; MFMA e of
+// group g then contracts k = {8g+e, 8g+4+e}; both operands use the same convention, so any
+// permutation of k is legal.  8 ds_read_b128 per wave per k-tile instead of 32 ds_read_b32.
+// ======================================================================================
+template <int S>
+__global__ void __launch_bounds__(256, 4)
+pw_gemm_wgrad_dma_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [S][A|B][128*16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = g.K / DBK;
+  const int64_t total = (int64_t)g.inner * KT;
+  const int t_begin = (int)(total * bz / g.nbatch);
+  const int T = (int)(total * (bz + 1) / g.nbatch) - t_begin;
+
+  // DMA lane mapping inside a 16-row piece: row = lane>>2, LDS slot = lane&3, source chunk swizzled
+  const int prow = lane >> 2, pslot = lane & 3;
+  const int chunk = pslot ^ ((prow >> 2) & 3);
+  const int ra0 = min(m0 + 16 * (2 * wave) + prow, g.M - 1), ra1 = min(m0 + 16 * (2 * wave + 1) + prow, g.M - 1);
+  const int rb0 = min(n0 + 16 * (2 * wave) + prow, g.N - 1), rb1 = min(n0 + 16 * (2 * wave + 1) + prow, g.N - 1);
+  const float* pa0 = g.A + (int64_t)ra0 * g.lda + 4 * chunk;
+  const float* pa1 = g.A + (int64_t)ra1 * g.lda + 4 * chunk;
+  const float* pb0 = g.B + (int64_t)rb0 * g.ldb + 4 * chunk;
+  const float* pb1 = g.B + (int64_t)rb1 * g.ldb + 4 * chunk;
+
+  auto issue = [&](int t) {
+    const int tt = t_begin + t;
+    const int ib = tt / KT, kt = tt - ib * KT;
+    const int64_t oa = (int64_t)ib * g.a_is + (int64_t)kt * DBK, ob = (int64_t)ib * g.b_is + (int64_t)kt * DBK;
+    float* st = lds + (t % S) * (2 * DTILE);
+    float* la = st + (2 * wave) * 256;
+    float* lb = st + DTILE + (2 * wave) * 256;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pa0 + oa), (lds_ptr_t)la, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pa1 + oa), (lds_ptr_t)(la + 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb0 + ob), (lds_ptr_t)lb, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb1 + ob), (lds_ptr_t)(lb + 256), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (t < T) issue(t);
+
+  // fragment addressing: row r = w?*64 + t?*32 + li, slot = (2g+lh) ^ ((li>>2)&3)
+  const int sw = (li >> 2) & 3;
+  const int offA = (wm * 64 + li) * DBK, offB = DTILE + (wn * 64 + li) * DBK;
+  const int s0 = ((0 + lh) ^ sw) * 4, s1 = ((2 + lh) ^ sw) * 4;
+
+  for (int t = 0; t < T; ++t) {
+    const int pending = min(S - 2, T - 1 - t);
+    if (pending >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (pending == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + S - 1 < T) issue(t + S - 1);
+    const float* st = lds + (t % S) * (2 * DTILE);
+    const float4 a00 = *reinterpret_cast<const float4*>(st + offA + s0);
+    const float4 a10 = *reinterpret_cast<const float4*>(st + offA + 32 * DBK + s0);
+    const float4 b00 = *reinterpret_cast<const float4*>(st + offB + s0);
+    const float4 b10 = *reinterpret_cast<const float4*>(st + offB + 32 * DBK + s0);
+    const float4 a01 = *reinterpret_cast<const float4*>(st + offA + s1);
+    const float4 a11 = *reinterpret_cast<const float4*>(st + offA + 32 * DBK + s1);
+    const float4 b01 = *reinterpret_cast<const float4*>(st + offB + s1);
+    const float4 b11 = *reinterpret_cast<const float4*>(st + offB + 32 * DBK + s1);
+#define MFMA4(A0, A1, B0, B1)                                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);   \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);   \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);   \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);
+    MFMA4(a00.x, a10.x, b00.x, b10.x)
+    MFMA4(a00.y, a10.y, b00.y, b10.y)
+    MFMA4(a00.z, a10.z, b00.z, b10.z)
+    MFMA4(a00.w, a10.w, b00.w, b10.w)
+    MFMA4(a01.x, a11.x, b01.x, b11.x)
+    MFMA4(a01.y, a11.y, b01.y, b11.y)
+    MFMA4(a01.z, a11.z, b01.z, b11.z)
+    MFMA4(a01.w, a11.w, b01.w, b11.w)
+#undef MFMA4
+  }
+  gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+}
+
 __global__ void __launch_bounds__(256)
 slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -379,10 +543,18 @@ slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int
 
 int slots() { return 256 * g_wg_per_cu; }
 
-int wgrad_splits(int B, int M, int K, int N) {
+bool wgrad_dma_ok(int N, int64_t dy_bs, int64_t x_bs, const void* a, const void* b) {
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return g_wgrad_dma_stages >= 2 && N % DBK == 0 && (dy_bs & 3) == 0 && (x_bs & 3) == 0 && a16(a) && a16(b);
+}
+
+// number of k-range splits: one round of resident workgroups over the CUs
+int wgrad_splits(int B, int M, int K, int N, bool dma) {
   const int tiles = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
-  const int64_t total_kt = (int64_t)B * ((N + g_bk - 1) / g_bk);
-  int s = slots() / tiles;
+  const int bk = dma ? DBK : g_bk;
+  const int64_t total_kt = (int64_t)B * ((N + bk - 1) / bk);
+  const int wg_per_cu = dma ? (g_wgrad_dma_stages == 2 ? 4 : 3) : g_wg_per_cu;
+  int s = 256 * wg_per_cu / tiles;
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, total_kt));
 }
 
@@ -414,9 +586,9 @@ bool dma_eligible(const GemmArgs& g) {
 int launch_gemm_dma(const GemmArgs& g, int grid, hipStream_t st) {
   const size_t bytes = (size_t)g_dma_stages * 2 * DTILE * sizeof(float);
   switch (g_dma_stages) {
-    case 2: hipLaunchKernelGGL(pw_gemm_dma_kernel<2>, dim3(grid), dim3(256), bytes, st, g); break;
-    case 3: hipLaunchKernelGGL(pw_gemm_dma_kernel<3>, dim3(grid), dim3(256), bytes, st, g); break;
-    default: hipLaunchKernelGGL(pw_gemm_dma_kernel<4>, dim3(grid), dim3(256), (size_t)4 * 2 * DTILE * sizeof(float), st, g); break;
+    case 2: hipLaunchKernelGGL((pw_gemm_dma_kernel<2, 4>), dim3(grid), dim3(256), bytes, st, g); break;
+    case 3: hipLaunchKernelGGL((pw_gemm_dma_kernel<3, 3>), dim3(grid), dim3(256), bytes, st, g); break;
+    default: hipLaunchKernelGGL((pw_gemm_dma_kernel<4, 2>), dim3(grid), dim3(256), (size_t)4 * 2 * DTILE * sizeof(float), st, g); break;
   }
   return 0;
 }
@@ -443,6 +615,7 @@ extern "C" void paradis_debug_set_gemm(int bk, int wg_per_cu) {
 }
 extern "C" void paradis_debug_set_gemm_stagger(int units) { g_stagger = units < 0 ? 0 : units; }
 extern "C" void paradis_debug_set_gemm_dma(int stages) { g_dma_stages = stages < 2 ? 0 : (stages > 4 ? 4 : stages); }
+extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = stages < 2 ? 0 : (stages > 3 ? 3 : stages); }
 
 extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const float* X,
                                    const float* bias, const float* map, const float* res, float* Y,
@@ -499,7 +672,8 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const flo
 }
 
 extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
-  const int S = wgrad_splits(std::max(B, 1), M, K, N);
+  const int S = std::max(wgrad_splits(std::max(B, 1), M, K, N, true),
+                         wgrad_splits(std::max(B, 1), M, K, N, false));
   return S > 1 ? (size_t)S * M * K * sizeof(float) + 256 : 256;
 }
 
@@ -513,7 +687,8 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
     if (hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
     return 0;
   }
-  const int S = wgrad_splits(B, M, K, N);
+  const bool dma = wgrad_dma_ok(N, dy_bs, x_bs, dY, X);
+  const int S = wgrad_splits(B, M, K, N, dma);
   PD_REQUIRE(S == 1 || workspace != nullptr, "pw_gemm_wgrad: workspace required");
   GemmArgs g{};
   g.A = dY; g.B = X; g.C = S > 1 ? (float*)workspace : dW;
@@ -523,7 +698,13 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.inner = B; g.a_is = dy_bs; g.b_is = x_bs;
   g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-  if (int e = launch_gemm<true, true>(g, grid, st)) return e;
+  if (dma) {
+    const size_t bytes = (size_t)g_wgrad_dma_stages * 2 * DTILE * sizeof(float);
+    if (g_wgrad_dma_stages == 2)
+      hipLaunchKernelGGL(pw_gemm_wgrad_dma_kernel<2>, dim3(grid), dim3(256), bytes, st, g);
+    else
+      hipLaunchKernelGGL(pw_gemm_wgrad_dma_kernel<3>, dim3(grid), dim3(256), (size_t)3 * 2 * DTILE * sizeof(float), st, g);
+  } else if (int e = launch_gemm<true, true>(g, grid, st)) return e;
   if (S > 1) {
     const int64_t n = (int64_t)M * K;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);

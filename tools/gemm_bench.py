@@ -20,6 +20,7 @@ CONFIGS = [(16, 4, 0), (16, 4, 2), (16, 4, 3), (16, 4, 4)] if len(sys.argv) < 2 
     [tuple(map(int, a.split(","))) for a in sys.argv[1:]]
 CONFIGS = [c if len(c) == 3 else (*c, 0) for c in CONFIGS]
 lib.paradis_debug_set_gemm_dma.argtypes = [ctypes.c_int]
+lib.paradis_debug_set_wgrad_dma.argtypes = [ctypes.c_int]
 lib.paradis_debug_set_gemm.argtypes = [ctypes.c_int, ctypes.c_int]
 lib.paradis_debug_set_gemm_stagger.argtypes = [ctypes.c_int]
 
@@ -51,6 +52,7 @@ def main():
         for cfg in CONFIGS:
             lib.paradis_debug_set_gemm(cfg[0], cfg[1])
             lib.paradis_debug_set_gemm_dma(cfg[2])
+            lib.paradis_debug_set_wgrad_dma(cfg[2] if cfg[2] <= 3 else 3)
             use_t = cfg[2] >= 2
             t = {}
             t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(x), None, None, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
