@@ -30,6 +30,7 @@ WORKLOADS = {
     "era5_5.625deg_32x64_S1_B32": (32, 64, False, 32, 1),
     "era5_5.625deg_32x64_S6_B32": (32, 64, False, 32, 6),
     "era5_1.4deg_128x256_S1_B8": (128, 256, False, 8, 1),
+    "era5_0.25deg_721x1440_fwd_B1": (721, 1440, True, 1, 1),     # forward only (use --forward-only)
 }
 
 
@@ -120,6 +121,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2,
                     help="batch of the bounded CPU sample (2 = the reference's own CPU case, configs[0]; "
                          "measured best samples/s on the 16-core box)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="inference forward under no_grad (BASELINE configs[4]); value = samples/s")
+    ap.add_argument("--checkpoint", action="store_true", help="per-layer activation checkpointing")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
@@ -143,6 +147,7 @@ def main():
     if args.batch:
         B = args.batch
     cfg = default_config()
+    cfg.compute.gradient_checkpointing = bool(args.checkpoint)
     lay = feature_layout(cfg)
     lat_deg, lg, og = make_grids(nlat, nlon, poles)
     torch.manual_seed(cfg.init.seed)
@@ -152,6 +157,14 @@ def main():
     step = TrainStep(ddp, loss_fn, cfg, num_common=lay.num_common_features,
                      n_inputs=cfg.dataset.n_time_inputs)
     batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234 + rank, device=dev)
+    if args.forward_only:
+        from paradis_model_amd.harness import assemble_model_input
+        mi = assemble_model_input(batch[0], batch[2].permute(0, 1, 4, 2, 3)[:, 0].unsqueeze(1),
+                                  batch[3][:, :1].permute(0, 1, 4, 2, 3))
+
+        def step(_b, _m=model, _x=mi):
+            with torch.no_grad():
+                return _m(_x).mean()
 
     for _ in range(args.warmup):
         step(batch)
@@ -181,6 +194,9 @@ def main():
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
                    "optimizer": "adamw", "parallelism": f"dp{world}",
+                   "mode": "forward-only" if args.forward_only else "train",
+                   "activation_checkpointing": bool(args.checkpoint),
+                   "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
                    "final_loss": float(loss)},
     }
     if prof is not None and rank == 0:

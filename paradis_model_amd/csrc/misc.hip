@@ -11,32 +11,28 @@ inline int stream_blocks(int64_t n_items) {
 }
 
 // ------------------------------------------------------------------ global bias map, forward
+// grid (ceil(W/256), H, Cin): m8[c,h,w] = sum_r (A[c,r] U[r,h]) V[r,w]
 __global__ void __launch_bounds__(256)
 gbias_m8_kernel(const float* __restrict__ A, const float* __restrict__ U, const float* __restrict__ V,
                 float* __restrict__ m8, int Cin, int R, int H, int W) {
-  const int64_t total = (int64_t)Cin * H * W;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * 256) {
-    const int w = (int)(idx % W), h = (int)((idx / W) % H), c = (int)(idx / ((int64_t)W * H));
-    float acc = 0.f;
-    for (int r = 0; r < R; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
-    m8[idx] = acc;
-  }
+  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, c = blockIdx.z;
+  if (w >= W) return;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
+  m8[((int64_t)c * H + h) * W + w] = acc;
 }
 
 // out[o,p] = sum_c Wm[o*ldo + c*ldc] * in[c,p]      (projection and its transpose)
+// grid (ceil(P/256), Cout)
 __global__ void __launch_bounds__(256)
 small_mix_kernel(const float* __restrict__ Wm, int ldo, int ldc, const float* __restrict__ in,
                  float* __restrict__ out, int Cout, int Cin, int64_t P) {
-  const int64_t total = (int64_t)Cout * P;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * 256) {
-    const int64_t p = idx % P;
-    const int o = (int)(idx / P);
-    float acc = 0.f;
-    for (int c = 0; c < Cin; ++c) acc += Wm[(int64_t)o * ldo + (int64_t)c * ldc] * in[(int64_t)c * P + p];
-    out[idx] = acc;
-  }
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;
+  if (p >= P) return;
+  float acc = 0.f;
+  for (int c = 0; c < Cin; ++c) acc += Wm[(int64_t)o * ldo + (int64_t)c * ldc] * in[(int64_t)c * P + p];
+  out[(int64_t)o * P + p] = acc;
 }
 
 // ------------------------------------------------------------------ global bias map, backward
@@ -248,11 +244,12 @@ extern "C" int paradis_global_bias_map_fwd(const float* A, const float* U, const
   hipStream_t st = (hipStream_t)stream;
   const int64_t P = (int64_t)H * W;
   float* m8_dst = Pw ? m8 : map;
-  hipLaunchKernelGGL(gbias_m8_kernel, dim3(stream_blocks(Cin * P)), dim3(256), 0, st, A, U, V, m8_dst, Cin,
+  PD_REQUIRE(H <= 65535 && Cin <= 65535 && Co <= 65535, "global_bias_map_fwd: grid too large");
+  hipLaunchKernelGGL(gbias_m8_kernel, dim3((W + 255) / 256, H, Cin), dim3(256), 0, st, A, U, V, m8_dst, Cin,
                      R, H, W);
   if (Pw)
-    hipLaunchKernelGGL(small_mix_kernel, dim3(stream_blocks(Co * P)), dim3(256), 0, st, Pw, Cin, 1, m8, map,
-                       Co, Cin, P);
+    hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Co), dim3(256), 0, st, Pw, Cin, 1,
+                       m8, map, Co, Cin, P);
   PD_CHECK_LAUNCH("global_bias_map_fwd");
   return 0;
 }
@@ -279,8 +276,8 @@ extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, co
     PD_REQUIRE(m8 != nullptr && gPw != nullptr, "global_bias_map_bwd: m8/gPw required with projection");
     hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
     // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
-    hipLaunchKernelGGL(small_mix_kernel, dim3(stream_blocks(Cin * P)), dim3(256), 0, st, Pw, 1, Cin, gmap,
-                       gm8, Cin, Co, P);
+    hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Cin), dim3(256), 0, st, Pw, 1, Cin,
+                       gmap, gm8, Cin, Co, P);
     gm8_src = gm8;
   }
   const int64_t nwaves = (int64_t)Cin * R * H;

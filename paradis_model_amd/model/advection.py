@@ -57,9 +57,17 @@ class NeuralSemiLagrangian(torch.nn.Module):
         return ops.sl_advect(projected, u, v, self._geom, dt, self.interpolation)
 
     def forward(self, hidden_features: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
-                dt: float, residual_gate=None) -> torch.Tensor:
+                dt: float) -> torch.Tensor:
         projected = self.down_projection(hidden_features)
         interpolated = self.advect(projected, u, v, dt)
+        return self.up_projection(interpolated)
+
+    def forward_velocities(self, hidden_features: torch.Tensor, velocities: torch.Tensor,
+                           dt: float) -> torch.Tensor:
+        """Same as ``forward`` with u = velocities[:, :K], v = velocities[:, K:] passed as one tensor
+        (what ``Paradis._layer_step`` has at hand): saves the slice/zero-fill/copy passes of autograd."""
+        projected = self.down_projection(hidden_features)
+        interpolated = ops.sl_advect_vel(projected, velocities, self._geom, dt, self.interpolation)
         return self.up_projection(interpolated)
 
 

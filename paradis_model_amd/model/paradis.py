@@ -148,13 +148,11 @@ class Paradis(nn.Module):
 
     # ------------------------------------------------------------------ one ADR update
     def _layer_step(self, i: int, hidden: torch.Tensor, hidden_static: torch.Tensor) -> torch.Tensor:
-        K = self.num_vels
         # velocities: channels [0,K) = u, [K,2K) = v  (reference: .view(B,2,K,H,W))
         velocities = self.velocity_nets[i](hidden)
-        u, v = velocities[:, :K], velocities[:, K:]
 
         # transport, gated per latent channel:  h + sigmoid(alpha_i) * (A(h) - h)
-        advected = self.advection[i](hidden, u, v, self.dt)
+        advected = self.advection[i].forward_velocities(hidden, velocities, self.dt)
         hidden = ops.gated_blend(hidden, advected, self.alpha_adv[i])
 
         # mixing: h + D(h)      (residual add fused in the last GEMM epilogue)

@@ -141,6 +141,54 @@ class _SLAdvect(torch.autograd.Function):
         return gfield, gu, gv, None, None, None
 
 
+class _SLAdvectVel(torch.autograd.Function):
+    """Same operator taking the velocity tensor [B,2K,H,W] whole (channels [0,K) = u, [K,2K) = v,
+    reference model/paradis.py:236-237): no slice views, and the velocity gradient is written in
+    place into one [B,2K,H,W] tensor."""
+
+    @staticmethod
+    def forward(ctx, field, vel, geom: AdvectGeometry, dt: float, mode: str):
+        require_hip(field, vel)
+        B, K, H, W = field.shape
+        assert vel.shape == (B, 2 * K, H, W) and (H, W) == (geom.H, geom.W)
+        field, f_bs = _bstride_view(field, K, H, W)
+        vel = vel.contiguous()
+        P = K * H * W
+        out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
+        sl, cl, lo = geom.tables(field.device)
+        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+        u, v = vel[:, :K], vel[:, K:]
+        _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl),
+                  dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, geom.min_lat, geom.min_lon, geom.d_lat,
+                  geom.d_lon, MODE_CODES[mode], dptr(ws), stream_ptr())
+        ctx.save_for_backward(field, vel)
+        ctx.meta = (geom, dt, mode, f_bs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        field, vel = ctx.saved_tensors
+        geom, dt, mode, f_bs = ctx.meta
+        B, K, H, W = gout.shape
+        gout = gout.contiguous()
+        P = K * H * W
+        gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
+        gvel = torch.empty_like(vel)
+        sl, cl, lo = geom.tables(gout.device)
+        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+        _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
+                  dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
+                  dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, geom.min_lat, geom.min_lon, geom.d_lat,
+                  geom.d_lon, MODE_CODES[mode], dptr(ws), stream_ptr())
+        return gfield, gvel, None, None, None
+
+
+def sl_advect_vel(field, vel, geom: AdvectGeometry, dt: float, mode: str = "bicubic"):
+    if mode not in MODE_CODES:
+        raise ValueError(f"interpolation must be one of {list(MODE_CODES)}")
+    return _SLAdvectVel.apply(field, vel, geom, float(dt), mode)
+
+
 def sl_advect(field, u, v, geom: AdvectGeometry, dt: float, mode: str = "bicubic"):
     """[B,K,H,W] x3 -> [B,K,H,W]; fused pole-mean / departure / gather / pole-mean."""
     if mode not in MODE_CODES:
@@ -230,9 +278,20 @@ class _AvgPoolGeo(torch.autograd.Function):
         return gx, None
 
 
+_BOX_WEIGHTS = {}
+
+
 def avgpool_geo(x, stride: int):
     if stride < 1:
         raise ValueError("Coarsening factor must be >=1")
+    if stride == 1 and x.is_cuda:
+        # stride 1 = depthwise 5x5 stencil with uniform taps 1/25: reuse the LDS-tiled kernels
+        # (forward 2.8x, backward 5x faster than the generic strided kernels)
+        key = (x.shape[1], x.device)
+        if key not in _BOX_WEIGHTS:
+            _BOX_WEIGHTS[key] = torch.full((x.shape[1], 1, 5, 5), 1.0 / 25.0, dtype=torch.float32,
+                                           device=x.device)
+        return _DwConvGeo.apply(x, _BOX_WEIGHTS[key], None)
     return _AvgPoolGeo.apply(x, int(stride))
 
 
@@ -260,6 +319,8 @@ class _UpsampleLonP(torch.autograd.Function):
 
 
 def upsample_lonp(x, nlat: int, nlon: int):
+    if tuple(x.shape[-2:]) == (int(nlat), int(nlon)):
+        return x   # equal sizes: ATen's align_corners interpolation is the exact identity
     return _UpsampleLonP.apply(x, int(nlat), int(nlon))
 
 

@@ -43,9 +43,12 @@ def test_pad_rejects_bad_input(ops):
         ops.geocyclic_pad(torch.randn(1, 1, 8, 8), 1)  # CPU tensor: no fallback
 
 
-def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem):
+def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6):
+    """force_gmem: use the tiled schedule (window + global fallback) regardless of plane size;
+    a small halo forces most taps through the fallback path."""
     from paradis_model_amd._lib import lib
     lib.paradis_debug_set_advect_gmem(1 if force_gmem else 0)
+    lib.paradis_debug_set_advect_halo(halo)
     try:
         geom = ops.AdvectGeometry(lg, og)
         fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
@@ -55,10 +58,11 @@ def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem):
         return y.detach().cpu(), fd.grad.cpu(), ud.grad.cpu(), vd.grad.cpu()
     finally:
         lib.paradis_debug_set_advect_gmem(-1)
+        lib.paradis_debug_set_advect_halo(6)
 
 
-@pytest.mark.parametrize("force_gmem", [False, True])
-def test_advect_core_vs_golden_and_fp64(ops, force_gmem):
+@pytest.mark.parametrize("force_gmem,halo", [(False, 6), (True, 6), (True, 0)])
+def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo):
     """Tolerance protocol of SURVEY.md 8c(iii): rms-rel vs CPU fp32 <= 1e-5 and error vs the fp64
     golden <= 1.5x the CPU-fp32 golden's own error vs fp64 (+ a small absolute floor)."""
     g = load_golden("g2_advect.pt")
@@ -72,7 +76,7 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem):
         v = seeded(s + 2, B, K, H, W, scale=rec["scale"])
         ct = seeded(s + 3, B, K, H, W)
         assert_chk([f, u, v, ct], rec["chk"])
-        y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, rec["dt"], rec["mode"], force_gmem)
+        y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, rec["dt"], rec["mode"], force_gmem, halo)
         e_cpu = rms_rel(rec["out_f32"], rec["out_f64"])
         e_gpu = rms_rel(y, rec["out_f64"])
         r32 = rms_rel(y, rec["out_f32"])
@@ -89,7 +93,7 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem):
 
 
 @pytest.mark.parametrize("H,W,poles,mode", [(32, 64, False, "bicubic"), (33, 64, True, "bilinear"),
-                                            (128, 256, False, "bicubic")])
+                                            (128, 256, False, "bicubic"), (65, 130, True, "bicubic")])
 def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode):
     """Gradients against fp64 autograd through the oracle (the formula check)."""
     B, K = 2, 4

@@ -12,16 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "paradis_model_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
-VARIANTS = {"base": [], "no_atomic": ["-DADV_NO_ATOMIC"], "no_trig": ["-DADV_NO_TRIG"],
-            "no_both": ["-DADV_NO_ATOMIC", "-DADV_NO_TRIG"]}
+VARIANTS = {"base": [], "ocml_sincos": ["-DADV_OCML_SINCOS"], "no_atomic": ["-DADV_NO_ATOMIC"],
+            "no_trig": ["-DADV_NO_TRIG"], "no_both": ["-DADV_NO_ATOMIC", "-DADV_NO_TRIG"]}
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
     for name, flags in VARIANTS.items():
         so = os.path.join(OUT, f"libadv_{name}.so")
-        if os.path.exists(so):
-            continue
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
                "-munsafe-fp-atomics", "-ffp-contract=off", "-shared", *flags,
                os.path.join(CSRC, "advect.hip"), os.path.join(CSRC, "error.hip"), "-o", so]
@@ -62,8 +60,14 @@ def main():
         return L.paradis_sl_advect_bwd(p(go), p(f), p(u), p(v), p(gf), p(guv[:, :K]), p(guv[:, K:]), p(sl), p(cl),
                                        p(lo), B, K, H, W, P, P, 2 * P, P, 2 * P, 0.196887, geom.min_lat,
                                        geom.min_lon, geom.d_lat, geom.d_lon, 2, p(ws), st)
-    for scale in (1.0, 0.05):
-        vel.normal_().mul_(scale)
+    for scale in (1.0, "smooth"):
+        if scale == "smooth":   # spatially smooth velocity: neighbouring points are displaced alike
+            yy = torch.linspace(0, 6.28, H, device="cuda").view(1, 1, H, 1)
+            xx = torch.linspace(0, 6.28, W, device="cuda").view(1, 1, 1, W)
+            ph = torch.rand(B, 2 * K, 1, 1, device="cuda") * 6.28
+            vel.copy_(2.0 * torch.sin(yy + ph) * torch.cos(xx * 2 + ph))
+        else:
+            vel.normal_().mul_(scale)
         for kind, fn in (("fwd", fwd), ("bwd", bwd)):
             for rnd in range(2):
                 for name, L in libs.items():
