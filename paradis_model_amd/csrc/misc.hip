@@ -35,6 +35,29 @@ small_mix_kernel(const float* __restrict__ Wm, int ldo, int ldc, const float* __
   out[(int64_t)o * P + p] = acc;
 }
 
+// gm8[c,p] += sum_{o in chunk} Pw[o,c] * gmap[o,p]   (c < CIN <= 16 kept in registers; gm8 pre-zeroed)
+// grid (ceil(P/256), ceil(Co/OCH)): the long reduction over Co is split so the launch fills the chip
+template <int CIN>
+__global__ void __launch_bounds__(256)
+gbias_gm8_kernel(const float* __restrict__ Pw, const float* __restrict__ gmap, float* __restrict__ gm8,
+                 int Cin, int Co, int64_t P, int och) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int o0 = blockIdx.y * och, o1 = min(o0 + och, Co);
+  float acc[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+  for (int o = o0; o < o1; ++o) {
+    const float g = gmap[(int64_t)o * P + p];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+      if (c < Cin) acc[c] += Pw[(int64_t)o * Cin + c] * g;
+  }
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+    if (c < Cin) atomicAdd(&gm8[(int64_t)c * P + p], acc[c]);
+}
+
 // ------------------------------------------------------------------ global bias map, backward
 // gPw[o,c] = sum_p gmap[o,p] * m8[c,p]; one workgroup per (o,c)
 __global__ void __launch_bounds__(256)
@@ -276,8 +299,15 @@ extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, co
     PD_REQUIRE(m8 != nullptr && gPw != nullptr, "global_bias_map_bwd: m8/gPw required with projection");
     hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
     // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
-    hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Cin), dim3(256), 0, st, Pw, 1, Cin,
-                       gmap, gm8, Cin, Co, P);
+    if (Cin <= 16) {
+      if (hipMemsetAsync(gm8, 0, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
+      const int och = 32;
+      hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och),
+                         dim3(256), 0, st, Pw, gmap, gm8, Cin, Co, P, och);
+    } else {
+      hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Cin), dim3(256), 0, st, Pw, 1,
+                         Cin, gmap, gm8, Cin, Co, P);
+    }
     gm8_src = gm8;
   }
   const int64_t nwaves = (int64_t)Cin * R * H;

@@ -69,8 +69,10 @@ class CLinear(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
-    def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None):
-        return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act)
+    def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, x_pre=None,
+                x_act=None, defer_act_grad=False):
+        return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act, x_pre, x_act,
+                             defer_act_grad)
 
 
 class SepConv(nn.Module):
@@ -213,6 +215,7 @@ class GMBlock(nn.Sequential):
         if x_extra is not None and not (n and isinstance(mods[0], ChannelNorm)):
             x = torch.cat([x, x_extra], dim=1)
             x_extra = None
+        pre = pre_act = None        # pre-activation hand-off between two chained CLinear layers
         while i < n:
             m = mods[i]
             if isinstance(m, ChannelNorm):
@@ -229,7 +232,20 @@ class GMBlock(nn.Sequential):
                     act = type(mods[j]).__name__
                     j += 1
                 res = residual if j == n else None
-                x = m(x, bias_map=bias_map, act=act, residual=res)
+                # the activation gradient moves into the next layer's dgrad epilogue when that
+                # layer is a CLinear (only consumer of this output) and autograd is recording
+                hand_off = (act is not None and res is None and j < n and isinstance(mods[j], CLinear)
+                            and isinstance(m, CLinear) and torch.is_grad_enabled())
+                if isinstance(m, CLinear):
+                    out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
+                            defer_act_grad=hand_off)
+                else:
+                    out = m(x, bias_map=bias_map, act=act, residual=res)
+                if hand_off:
+                    x, pre = out
+                    pre_act = act
+                else:
+                    x, pre, pre_act = out, None, None
                 if res is not None:
                     residual = None
                 i = j

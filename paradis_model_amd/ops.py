@@ -424,9 +424,19 @@ def global_bias_map(A, U, V, Pw=None):
 # (reference model/blocks.py:86,110 + :196 + activation + the residual adds of paradis.py:246,253)
 # ---------------------------------------------------------------------------
 class _Pointwise(torch.autograd.Function):
+    """y = residual + act(W x + bias + bias_map).
+
+    Activation-gradient hand-off between two chained ops (GMBlock drives it):
+      * ``defer_act_grad`` (producer): the op's backward receives d(pre-activation) directly and
+        skips its own act' pass; it also returns its pre-activation ``z`` as a second output.
+      * ``x_pre`` / ``x_act`` (consumer): x = act(x_pre) was produced by such an op; the consumer's
+        dgrad multiplies by act'(x_pre) in the GEMM epilogue, so what it returns as the gradient of
+        ``x`` already is the producer's d(pre-activation).
+    """
+
     @staticmethod
-    def forward(ctx, x, weight, bias, bmap, residual, act):
-        require_hip(x, weight, bias, bmap, residual)
+    def forward(ctx, x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad):
+        require_hip(x, weight, bias, bmap, residual, x_pre)
         x, x_bs = _plane_view(x)
         B, Ci, H, W = x.shape
         Co = weight.shape[0]
@@ -440,7 +450,7 @@ class _Pointwise(torch.autograd.Function):
         if bmap is not None:
             bmap = bmap.contiguous()
         y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
-        need_z = act != 0 and any(ctx.needs_input_grad[:4])
+        need_z = act != 0 and (any(ctx.needs_input_grad[:4]) or defer_act_grad)
         z = torch.empty_like(y) if need_z else None
         # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
         w2t = None
@@ -450,29 +460,37 @@ class _Pointwise(torch.autograd.Function):
         _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(x), dptr(bias),
                   dptr(bmap), dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act,
                   stream_ptr())
-        ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0))
-        ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape)
+        if x_pre is not None:
+            x_pre = x_pre.contiguous()
+        ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0),
+                              x_pre if x_pre is not None else x.new_empty(0))
+        ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape,
+                    x_act if x_pre is not None else 0, bool(defer_act_grad))
+        if defer_act_grad:
+            ctx.mark_non_differentiable(z)
+            return y, z
         return y
 
     @staticmethod
-    def backward(ctx, gy):
-        x, w2, z = ctx.saved_tensors
-        x_bs, act, has_bias, has_map, has_res, wshape = ctx.meta
+    def backward(ctx, gy, *unused):
+        x, w2, z, x_pre = ctx.saved_tensors
+        x_bs, act, has_bias, has_map, has_res, wshape, x_act, deferred = ctx.meta
         B, Ci, H, W = x.shape
         Co, P = w2.shape[0], H * W
         gy = gy.contiguous()
         st = stream_ptr()
         gres = gy if has_res else None
-        if act != 0:
+        if act != 0 and not deferred:
             dz = torch.empty_like(gy)
             check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, st), "act_bwd")
         else:
-            dz = gy
+            dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
         gx = gw = gb = gmap = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, Ci, H, W, dtype=gy.dtype, device=gy.device)
-            _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(dz), None, None, dptr(gx),
-                      B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st)
+            zmul = x_pre if x_act != 0 else None
+            _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(dz), dptr(zmul), None, dptr(gx),
+                      B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P, x_act, st)
         if ctx.needs_input_grad[1]:
             gw = torch.empty(Co, Ci, dtype=gy.dtype, device=gy.device)
             ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), gy.device)
@@ -485,12 +503,19 @@ class _Pointwise(torch.autograd.Function):
             gb = torch.empty(Co, dtype=gy.dtype, device=gy.device) if want_b else None
             gmap = torch.empty(Co, H, W, dtype=gy.dtype, device=gy.device) if want_m else None
             check(lib.paradis_bias_grads(dptr(dz), dptr(gmap), dptr(gb), B, Co, P, Co * P, st), "bias_grads")
-        return gx, gw, gb, gmap, gres, None
+        return gx, gw, gb, gmap, gres, None, None, None, None
 
 
-def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None):
-    """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1]."""
-    return _Pointwise.apply(x, weight, bias, bias_map, residual, ACT_CODES[act])
+def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
+              defer_act_grad=False):
+    """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1].
+
+    ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
+    called with ``x_pre=z, x_act=act`` (see ``_Pointwise``); only valid when ``y`` has no other use."""
+    if defer_act_grad and (act is None or residual is not None):
+        raise ValueError("defer_act_grad needs an activation and no residual")
+    return _Pointwise.apply(x, weight, bias, bias_map, residual, ACT_CODES[act], x_pre,
+                            ACT_CODES[x_act], bool(defer_act_grad))
 
 
 # ---------------------------------------------------------------------------
