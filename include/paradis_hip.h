@@ -143,6 +143,25 @@ int paradis_transpose(const float* in, float* out, int rows, int cols, void* str
 /* y[b,i] = x[b,i] + m[i], i < per_sample  (standalone GlobalBias.forward, reference model/blocks.py:196) */
 int paradis_add_bcast(const float* x, const float* m, float* y, int64_t per_sample, int B, void* stream);
 
+/* ---- rows f1-f3 (callers around the model in the training step)
+ * f1: ParadisLoss forward + gradient (reference utils/loss.py:233-282): loss[0] = mean(wf[c]*wl[h]*l(pred-target)),
+ *     grad = d loss / d pred (for upstream gradient 1).  kind: 0 mse, 1 smooth reversed Huber.
+ *     wl may be NULL; partial needs paradis_loss_blocks(total) floats. */
+int paradis_loss_blocks(int64_t total);
+int paradis_loss_fwd_bwd(const float* pred, const float* target, const float* wf, const float* wl,
+                         float* loss, float* grad, float* partial, int B, int C, int H, int W,
+                         int kind, float delta, void* stream);
+/* y = x * scalar[0] (device scalar) */
+int paradis_scale(const float* x, const float* scalar, float* y, int64_t n, void* stream);
+/* f2: dst[b, 0:per_sample] = src[b, 0:per_sample] with different batch strides (channel-block copy used
+ *     to assemble cat([input, forcings, constants]) and the next autoregressive input,
+ *     reference trainer.py:534-538, 710-729) */
+int paradis_copy_channels(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int B,
+                          int64_t per_sample, void* stream);
+/* f3: AdamW update of one tensor, torch.optim.AdamW operation order (reference trainer.py:327-335) */
+int paradis_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,11 @@ SIGNATURES = {
     "paradis_bias_grads": (I, [P, P, P, I, I, I, L, P]),
     "paradis_add": (I, [P, P, P, L, P]),
     "paradis_add_bcast": (I, [P, P, P, L, I, P]),
+    "paradis_loss_blocks": (I, [L]),
+    "paradis_loss_fwd_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "paradis_scale": (I, [P, P, P, L, P]),
+    "paradis_copy_channels": (I, [P, L, P, L, I, L, P]),
+    "paradis_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, P]),
 }
 
 _missing = []

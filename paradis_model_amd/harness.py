@@ -62,6 +62,9 @@ def synthetic_batch(nlat: int, nlon: int, poles: bool, batch: int, steps: int, *
 def assemble_model_input(input_data, forcings_step, constants):
     """cat([input[B,1,166,H,W], forcings[B,1,10,H,W], constants[B,1,10,H,W]], 2).squeeze(1)
     (reference trainer.py:534-538)."""
+    if input_data.is_cuda:
+        from . import ops   # strided block copies by the HIP library (no ATen cat / permute copies)
+        return ops.concat_channels([input_data.squeeze(1), forcings_step.squeeze(1), constants.squeeze(1)])
     return torch.cat([input_data, forcings_step, constants], dim=2).squeeze(1)
 
 
@@ -70,6 +73,9 @@ def next_input(model_input, output, num_common: int, n_inputs: int):
     common = output[:, :num_common]
     if n_inputs == 1:
         return common
+    if model_input.is_cuda:
+        from . import ops
+        return ops.concat_channels([model_input[:, num_common:num_common * n_inputs], common])
     return torch.cat([model_input[:, num_common:num_common * n_inputs], common], dim=1)
 
 
@@ -112,9 +118,13 @@ class TrainStep:
         self.num_common, self.n_inputs = num_common, n_inputs
         o = cfg.training.optimizer
         params = [p for p in model.parameters() if p.requires_grad]
-        use_fused = fused if fused is not None else bool(params and params[0].is_cuda)
-        self.opt = torch.optim.AdamW(params, lr=o.lr, weight_decay=o.weight_decay,
-                                     betas=(o.beta1, o.beta2), fused=use_fused)
+        on_hip = bool(params and params[0].is_cuda)
+        if on_hip and fused is None:
+            from .optim import AdamW   # HIP kernel, torch.optim.AdamW semantics
+            self.opt = AdamW(params, lr=o.lr, weight_decay=o.weight_decay, betas=(o.beta1, o.beta2))
+        else:
+            self.opt = torch.optim.AdamW(params, lr=o.lr, weight_decay=o.weight_decay,
+                                         betas=(o.beta1, o.beta2), fused=bool(fused))
         self.detach_every = o.get("detach_gradient_every", None)
 
     def __call__(self, batch):

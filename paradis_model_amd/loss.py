@@ -2,9 +2,9 @@
 
 Same constructor arguments and weighting rules as the reference, including its
 blocks-of-``num_levels`` walk over the first ``num_features-num_surface_vars`` channels.
-Round 1: the loss is a handful of elementwise device ops on [B,97,H,W] issued through PyTorch on
-the HIP device (a fused loss+grad HIP kernel is the next widening step; it is outside SURVEY.md
-section 8a).
+On the HIP device ``forward`` is ONE fused kernel (``paradis_loss_fwd_bwd``: weighted loss value and
+d loss / d pred in a single pass over pred/target); on CPU tensors (weight construction tests, the
+gloo harness test) it is the plain elementwise formula.
 """
 import re
 
@@ -83,6 +83,11 @@ class ParadisLoss(torch.nn.Module):
         return loss.mean(dim=(0, 2, 3))
 
     def forward(self, pred, target):
+        if pred.is_cuda:
+            from . import ops
+            lw = self.lat_weights_buf.reshape(-1) if self.apply_latitude_weights else None
+            return ops.paradis_loss(pred, target, self.feature_weights_buf.reshape(-1), lw, self.kind,
+                                    self.delta)
         loss = self._pointwise_loss(pred, target) * self.feature_weights_buf
         if self.apply_latitude_weights:
             loss = loss * self.lat_weights_buf

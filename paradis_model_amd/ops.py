@@ -622,3 +622,79 @@ class _AddBiasMap(torch.autograd.Function):
 def add_bias_map(x, bmap):
     """x[B,C,H,W] + bmap[C,H,W] (standalone GlobalBias, reference model/blocks.py:196)"""
     return _AddBiasMap.apply(x, bmap)
+
+
+# ---------------------------------------------------------------------------
+# rows f1-f3: loss, rollout glue, optimiser step (SURVEY.md section 8f)
+# ---------------------------------------------------------------------------
+class _ParadisLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, wf, wl, kind, delta):
+        require_hip(pred, target, wf, wl)
+        pred, target = pred.contiguous(), target.contiguous()
+        B, C, H, W = pred.shape
+        assert target.shape == pred.shape and wf.numel() == C and (wl is None or wl.numel() == H)
+        loss = torch.empty((), dtype=pred.dtype, device=pred.device)
+        want_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(pred) if want_grad else None
+        partial = torch.empty(lib.paradis_loss_blocks(pred.numel()), dtype=pred.dtype, device=pred.device)
+        check(lib.paradis_loss_fwd_bwd(dptr(pred), dptr(target), dptr(wf), dptr(wl), dptr(loss), dptr(grad),
+                                       dptr(partial), B, C, H, W, kind, delta, stream_ptr()), "loss_fwd_bwd")
+        if want_grad:
+            ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        check(lib.paradis_scale(dptr(grad), dptr(gout.contiguous()), dptr(out), grad.numel(), stream_ptr()),
+              "scale")
+        return out, None, None, None, None, None
+
+
+def paradis_loss(pred, target, feature_weights, lat_weights=None, kind="reversed_huber", delta=1.0):
+    """mean(feature_weights[c] * lat_weights[h] * l(pred - target)); forward and d/dpred in one pass."""
+    code = {"mse": 0, "reversed_huber": 1}[kind]
+    return _ParadisLoss.apply(pred, target, feature_weights, lat_weights, code, float(delta))
+
+
+class _ConcatChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *parts):
+        require_hip(*parts)
+        B = parts[0].shape[0]
+        H, W = parts[0].shape[-2:]
+        chans = [p.shape[1] for p in parts]
+        P = H * W
+        out = torch.empty(B, sum(chans), H, W, dtype=parts[0].dtype, device=parts[0].device)
+        off = 0
+        for p, c in zip(parts, chans):
+            p, bs = _plane_view(p)
+            check(lib.paradis_copy_channels(dptr(p), bs, dptr(out[:, off:]), sum(chans) * P, B, c * P,
+                                            stream_ptr()), "copy_channels")
+            off += c
+        ctx.chans = chans
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gout = gout.contiguous()
+        B, Ct, H, W = gout.shape
+        P = H * W
+        grads, off = [], 0
+        for i, c in enumerate(ctx.chans):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty(B, c, H, W, dtype=gout.dtype, device=gout.device)
+                check(lib.paradis_copy_channels(dptr(gout[:, off:]), Ct * P, dptr(g), c * P, B, c * P,
+                                                stream_ptr()), "copy_channels")
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += c
+        return tuple(grads)
+
+
+def concat_channels(parts):
+    """cat(parts, dim=1) for [B,C_i,H,W] tensors (channel slices accepted) by strided block copies."""
+    return _ConcatChannels.apply(*parts)
