@@ -93,9 +93,10 @@ int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy
 int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const float* zpre, const float* addend,
                           float* dX, int B, int M, int K, int N, int64_t dy_bs, int64_t z_bs,
                           int64_t add_bs, int64_t dx_bs, int act, void* stream);
-/* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; workspace >= paradis_pw_gemm_wgrad_ws_bytes */
+/* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; gbias[M] = sum_{b,n} dY (optional, NULL to skip; fused
+ * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes */
 size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N);
-int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
+int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias,
                           int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs,
                           void* workspace, void* stream);
 

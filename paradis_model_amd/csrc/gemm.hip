@@ -49,6 +49,7 @@ struct GemmArgs {
   int64_t res_bs, zmul_bs, zout_bs;
   int act;
   int stagger;                // start-up skew between co-resident workgroups, in units of 512 cycles
+  float* rowsum;              // wgrad only: [nbatch][M] partial row sums of A (= bias gradient), or NULL
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -494,6 +495,12 @@ pw_gemm_wgrad_dma_kernel(GemmArgs g) {
   for (int t = 0; t < S - 1; ++t)
     if (t < T) issue(t);
 
+  // bias gradient for free: the n-tile-0 workgroups also sum their A rows (dZ) over k.
+  // thread t covers row t>>1, 16-B slots 2*(t&1), 2*(t&1)+1 (any chunk order: it is a plain sum)
+  const bool do_rowsum = g.rowsum != nullptr && nt == 0;
+  float rs = 0.f;
+  const int rs_off = (tid >> 1) * DBK + (tid & 1) * 8;
+
   // fragment addressing: row r = w?*64 + t?*32 + li, slot = (2g+lh) ^ ((li>>2)&3)
   const int sw = (li >> 2) & 3;
   const int offA = (wm * 64 + li) * DBK, offB = DTILE + (wn * 64 + li) * DBK;
@@ -506,6 +513,11 @@ pw_gemm_wgrad_dma_kernel(GemmArgs g) {
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + S - 1 < T) issue(t + S - 1);
     const float* st = lds + (t % S) * (2 * DTILE);
+    if (do_rowsum) {
+      const float4 q0 = *reinterpret_cast<const float4*>(st + rs_off);
+      const float4 q1 = *reinterpret_cast<const float4*>(st + rs_off + 4);
+      rs += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+    }
     const float4 a00 = *reinterpret_cast<const float4*>(st + offA + s0);
     const float4 a10 = *reinterpret_cast<const float4*>(st + offA + 32 * DBK + s0);
     const float4 b00 = *reinterpret_cast<const float4*>(st + offB + s0);
@@ -528,6 +540,11 @@ pw_gemm_wgrad_dma_kernel(GemmArgs g) {
     MFMA4(a01.z, a11.z, b01.z, b11.z)
     MFMA4(a01.w, a11.w, b01.w, b11.w)
 #undef MFMA4
+  }
+  if (do_rowsum) {
+    rs += __shfl_xor(rs, 1, 64);
+    const int m = m0 + (tid >> 1);
+    if ((tid & 1) == 0 && m < g.M) g.rowsum[(int64_t)bz * g.M + m] = rs;
   }
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
@@ -674,22 +691,30 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const flo
 extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
   const int S = std::max(wgrad_splits(std::max(B, 1), M, K, N, true),
                          wgrad_splits(std::max(B, 1), M, K, N, false));
-  return S > 1 ? (size_t)S * M * K * sizeof(float) + 256 : 256;
+  return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256;   // slabs + row-sum partials
 }
 
-extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, int B, int M, int K,
-                                     int N, int64_t dy_bs, int64_t x_bs, void* workspace,
+extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
+                                  int64_t dz_bs, void* stream);
+
+extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias, int B,
+                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, void* workspace,
                                      void* stream) {
   // dW[M,K] = sum_b dY[b][M,N] . X[b][K,N]^T : GEMM with M'=M, N'=K, K'=N, reduced over samples.
   if (int e = check_gemm("pw_gemm_wgrad", 1, M, N, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
     if (hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
+    if (gbias && hipMemsetAsync(gbias, 0, (size_t)M * sizeof(float), st) != hipSuccess) return 2;
     return 0;
   }
   const bool dma = wgrad_dma_ok(N, dy_bs, x_bs, dY, X);
   const int S = wgrad_splits(B, M, K, N, dma);
-  PD_REQUIRE(S == 1 || workspace != nullptr, "pw_gemm_wgrad: workspace required");
+  PD_REQUIRE(workspace != nullptr, "pw_gemm_wgrad: workspace required");
+  float* rowsum_ws = (float*)workspace + (size_t)S * M * K;   // [S][M], behind the slabs
+  if (gbias && !dma) {   // register-staged kernel has no fused row sums: separate reduction pass
+    if (int e = paradis_bias_grads(dY, nullptr, gbias, B, M, N, dy_bs, stream)) return e;
+  }
   GemmArgs g{};
   g.A = dY; g.B = X; g.C = S > 1 ? (float*)workspace : dW;
   g.M = M; g.N = K; g.K = N;
@@ -697,6 +722,7 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.a_bs = 0; g.b_bs = 0; g.c_bs = (int64_t)M * K; g.nbatch = S;
   g.inner = B; g.a_is = dy_bs; g.b_is = x_bs;
   g.stagger = g_stagger;
+  g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
   if (dma) {
     const size_t bytes = (size_t)g_wgrad_dma_stages * 2 * DTILE * sizeof(float);
@@ -710,6 +736,9 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, S);
   }
+  if (g.rowsum)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)rowsum_ws,
+                       gbias, (int64_t)M, S);
   PD_CHECK_LAUNCH("pw_gemm_wgrad");
   return 0;
 }

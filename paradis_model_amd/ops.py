@@ -491,14 +491,17 @@ class _Pointwise(torch.autograd.Function):
             zmul = x_pre if x_act != 0 else None
             _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(dz), dptr(zmul), None, dptr(gx),
                       B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P, x_act, st)
+        want_b = has_bias and ctx.needs_input_grad[2]
+        want_m = has_map and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
             gw = torch.empty(Co, Ci, dtype=gy.dtype, device=gy.device)
             ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), gy.device)
-            _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), B, Co, Ci, P,
-                      Co * P, x_bs, dptr(ws), st)
+            if want_b and not want_m:   # bias gradient = row sums of dz: fused into the wgrad GEMM
+                gb = torch.empty(Co, dtype=gy.dtype, device=gy.device)
+                want_b = False
+            _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), dptr(gb), B, Co,
+                      Ci, P, Co * P, x_bs, dptr(ws), st)
             gw = gw.reshape(wshape)
-        want_b = has_bias and ctx.needs_input_grad[2]
-        want_m = has_map and ctx.needs_input_grad[3]
         if want_b or want_m:
             gb = torch.empty(Co, dtype=gy.dtype, device=gy.device) if want_b else None
             gmap = torch.empty(Co, H, W, dtype=gy.dtype, device=gy.device) if want_m else None

@@ -57,7 +57,7 @@ def main():
             t = {}
             t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(x), None, None, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
             t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
-            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), B, Co, Ci, P, Co * P, Ci * P, dptr(ws), st))
+            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, dptr(ws), st))
             for k in t:
                 tot[cfg][k] += t[k]
             line += "  bk%d/wg%d/dma%d: " % cfg + " ".join(f"{k[0]}{flops / t[k] / 1e6:6.1f}" for k in ("fwd", "dgrad", "wgrad"))
