@@ -21,8 +21,8 @@ def short(name):
 
 
 def one(pattern):
-    files = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return files[0] if files else None
+    files = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None   # newest run wins when a tag was profiled more than once
 
 
 stats = one("stats/**/*_kernel_stats.csv")
