@@ -140,6 +140,8 @@ def main():
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
+    if os.environ.get("PARADIS_SHARE_GPU0") == "1":   # test hook: all ranks on cuda:0 (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

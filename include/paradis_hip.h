@@ -163,6 +163,17 @@ int paradis_copy_channels(const float* src, int64_t src_bs, float* dst, int64_t 
 int paradis_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ---- diagnostics (process-global tunables used by tools/ and tests/; not needed in production)
+ * advect: force the tiled schedule (1) / automatic choice (-1 or 0); halo of the tiled window (0..16)
+ * gemm  : k-tile depth (16|32) and workgroups per CU (1..4) of the register-staged kernel; start-up
+ *         stagger; LDS-DMA ring depth for fwd/dgrad (0 = off, 2..4) and for wgrad (0 = off, 2..3) */
+void paradis_debug_set_advect_gmem(int on);
+void paradis_debug_set_advect_halo(int halo);
+void paradis_debug_set_gemm(int bk, int wg_per_cu);
+void paradis_debug_set_gemm_stagger(int units);
+void paradis_debug_set_gemm_dma(int stages);
+void paradis_debug_set_wgrad_dma(int stages);
+
 #ifdef __cplusplus
 }
 #endif

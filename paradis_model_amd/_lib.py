@@ -67,6 +67,12 @@ SIGNATURES = {
     "paradis_scale": (I, [P, P, P, L, P]),
     "paradis_copy_channels": (I, [P, L, P, L, I, L, P]),
     "paradis_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, P]),
+    "paradis_debug_set_advect_gmem": (None, [I]),
+    "paradis_debug_set_advect_halo": (None, [I]),
+    "paradis_debug_set_gemm": (None, [I, I]),
+    "paradis_debug_set_gemm_stagger": (None, [I]),
+    "paradis_debug_set_gemm_dma": (None, [I]),
+    "paradis_debug_set_wgrad_dma": (None, [I]),
 }
 
 _missing = []

@@ -143,7 +143,9 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PARADIS_DIST_BACKEND=gloo lets a 1-GPU box exercise the N>1 code path (tests only)
+            backend = os.environ.get("PARADIS_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

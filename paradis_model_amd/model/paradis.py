@@ -137,6 +137,15 @@ class Paradis(nn.Module):
         only re-bind the step function."""
         self.step_fn = self._checkpointed_step if self.gradient_checkpoint else self._layer_step
 
+    def compile(self, *args, **kwargs):
+        """The reference trainer calls ``model.compile(backend="inductor", fullgraph=True)`` when
+        ``compute.compile`` is set (trainer.py:261-267).  The HIP path is hand-fused and its ops are
+        opaque C-ABI calls, so tracing is neither needed nor possible: stay eager."""
+        import warnings
+        warnings.warn("paradis_model_amd: torch.compile is not used on the HIP path (already fused); "
+                      "running eager", stacklevel=2)
+        return self
+
     def upsample(self, x: torch.Tensor) -> torch.Tensor:
         """Longitude-periodic bilinear interpolation to (nlat, nlon), align_corners=True."""
         return ops.upsample_lonp(x, self.nlat, self.nlon)
