@@ -86,6 +86,9 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value. */
 int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
                         const float* X, const float* bias, const float* map,
+                        const float* m8 /* [cin,N] */, const float* pw /* [M,cin] */, int cin,
+                        /* ^ optional low-rank bias applied on the fly: + sum_c pw[m,c]*m8[c,n] (GlobalBias
+                         *   with projection, reference model/blocks.py:190-196), cin <= 16, or NULL/NULL/0 */
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
                         int act, void* stream);
@@ -123,6 +126,15 @@ int paradis_global_bias_map_bwd(const float* gmap, const float* A, const float* 
                                 const float* Pw, const float* m8, float* gA, float* gU, float* gV,
                                 float* gPw, int Cin, int Co, int R, int H, int W,
                                 void* workspace, void* stream);
+
+/* GlobalBias in two stages, used when the projection is fused into the GEMM epilogue */
+int paradis_global_bias_m8_fwd(const float* A, const float* U, const float* V, float* m8,
+                               int Cin, int R, int H, int W, void* stream);
+int paradis_global_bias_m8_bwd(const float* gm8, const float* A, const float* U, const float* V,
+                               float* gA, float* gU, float* gV, int Cin, int R, int H, int W,
+                               void* workspace, void* stream);
+int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, const float* Pw, float* gPw,
+                                 float* gm8, int Cin, int Co, int64_t P, void* stream);
 
 /* ---- elementwise / reductions used by the blocks */
 int paradis_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);

@@ -43,7 +43,10 @@ SIGNATURES = {
     "paradis_avgpool_geo_bwd": (I, [P, P, L, I, I, I, P]),
     "paradis_upsample_lonp_fwd": (I, [P, P, L, I, I, I, I, P]),
     "paradis_upsample_lonp_bwd": (I, [P, P, L, I, I, I, I, P]),
-    "paradis_pw_gemm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, I, P]),
+    "paradis_pw_gemm_fwd": (I, [P, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
+    "paradis_global_bias_m8_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "paradis_global_bias_m8_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    "paradis_global_bias_proj_bwd": (I, [P, P, P, P, P, I, I, L, P]),
     "paradis_transpose": (I, [P, P, I, I, P]),
     "paradis_pw_gemm_dgrad": (I, [P, P, P, P, P, I, I, I, I, L, L, L, L, I, P]),
     "paradis_pw_gemm_wgrad_ws_bytes": (S, [I, I, I, I]),

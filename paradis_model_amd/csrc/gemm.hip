@@ -50,6 +50,8 @@ struct GemmArgs {
   int act;
   int stagger;                // start-up skew between co-resident workgroups, in units of 512 cycles
   float* rowsum;              // wgrad only: [nbatch][M] partial row sums of A (= bias gradient), or NULL
+  // low-rank bias map applied on the fly: v += sum_c pw[m*cin + c] * m8[c*N + n]  (cin <= 16)
+  const float* m8; const float* pw; int cin;
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -155,6 +157,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += t[q];
           }
+          if (g.pw) {   // GlobalBias projection without materialising the [M,N] map
+            const int ncol = n0 + wn * 64 + tn * 32 + li;
+            for (int c = 0; c < g.cin; ++c) {
+              const float mb = g.m8[(int64_t)c * g.N + ncol];
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                v[q] += g.pw[(int64_t)(mrow + (q & 3) + 8 * (2 * h + (q >> 2))) * g.cin + c] * mb;
+            }
+          }
           if (zoutb) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) zoutb[base + ROWOFF(q)] = v[q];
@@ -199,6 +210,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const int64_t off = (int64_t)m * g.ldc + n;
         float v = acc[tm][tn][r] + bv;
         if (g.map) v += g.map[off];
+        if (g.pw)
+          for (int c = 0; c < g.cin; ++c) v += g.pw[(int64_t)m * g.cin + c] * g.m8[(int64_t)c * g.N + n];
         if (zoutb) zoutb[off] = v;
         if (zmulb) v *= act_grad(zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
@@ -635,13 +648,17 @@ extern "C" void paradis_debug_set_gemm_dma(int stages) { g_dma_stages = stages <
 extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = stages < 2 ? 0 : (stages > 3 ? 3 : stages); }
 
 extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const float* X,
-                                   const float* bias, const float* map, const float* res, float* Y,
-                                   float* zpre, int B, int M, int K, int N, int64_t x_bs,
-                                   int64_t res_bs, int64_t y_bs, int act, void* stream) {
+                                   const float* bias, const float* map, const float* m8,
+                                   const float* pw, int cin, const float* res, float* Y, float* zpre,
+                                   int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
+                                   int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
+  PD_REQUIRE((m8 == nullptr) == (pw == nullptr) && (pw == nullptr || (cin >= 1 && cin <= 16)),
+             "pw_gemm_fwd: projected bias needs m8, pw and 1 <= cin <= 16");
   if (B == 0) return 0;
   GemmArgs g{};
+  g.m8 = m8; g.pw = pw; g.cin = cin;
   g.A = Wt; g.B = X; g.C = Y; g.M = M; g.N = N; g.K = K;
   g.lda = K; g.ldb = N; g.ldc = N;
   g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0;

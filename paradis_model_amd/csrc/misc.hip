@@ -417,3 +417,32 @@ extern "C" int paradis_transpose(const float* in, float* out, int rows, int cols
   PD_CHECK_LAUNCH("transpose");
   return 0;
 }
+
+// ---- GlobalBias in two stages (lets the GEMM epilogue apply the projection on the fly) ----
+// stage 1: m8[Cin,H,W] = sum_r A[c,r] U[r,h] V[r,w]
+extern "C" int paradis_global_bias_m8_fwd(const float* A, const float* U, const float* V, float* m8,
+                                          int Cin, int R, int H, int W, void* stream) {
+  return paradis_global_bias_map_fwd(A, U, V, nullptr, nullptr, m8, Cin, Cin, R, H, W, stream);
+}
+// adjoint of stage 1: (gA, gU, gV) from gm8; workspace >= paradis_global_bias_map_bwd_ws_bytes
+extern "C" int paradis_global_bias_m8_bwd(const float* gm8, const float* A, const float* U,
+                                          const float* V, float* gA, float* gU, float* gV, int Cin,
+                                          int R, int H, int W, void* workspace, void* stream) {
+  return paradis_global_bias_map_bwd(gm8, A, U, V, nullptr, nullptr, gA, gU, gV, nullptr, Cin, Cin, R, H,
+                                     W, workspace, stream);
+}
+// adjoint of the projection map[o,p] = sum_c Pw[o,c] m8[c,p]:  gPw[o,c] = sum_p gmap[o,p] m8[c,p],
+// gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
+extern "C" int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, const float* Pw,
+                                            float* gPw, float* gm8, int Cin, int Co, int64_t P,
+                                            void* stream) {
+  PD_REQUIRE(Cin >= 1 && Cin <= 16 && Co >= 1 && P >= 1, "global_bias_proj_bwd: bad shape (Cin <= 16)");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
+  if (hipMemsetAsync(gm8, 0, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
+  const int och = 32;
+  hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och), dim3(256),
+                     0, st, Pw, gmap, gm8, Cin, Co, P, och);
+  PD_CHECK_LAUNCH("global_bias_proj_bwd");
+  return 0;
+}

@@ -70,9 +70,9 @@ class CLinear(nn.Module):
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
     def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, x_pre=None,
-                x_act=None, defer_act_grad=False):
+                x_act=None, defer_act_grad=False, bias_proj=None):
         return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act, x_pre, x_act,
-                             defer_act_grad)
+                             defer_act_grad, bias_proj)
 
 
 class SepConv(nn.Module):
@@ -88,9 +88,10 @@ class SepConv(nn.Module):
         self.depthwise = nn.Conv2d(input_dim, input_dim, kernel_size, groups=input_dim, bias=False)
         self.pointwise = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
-    def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None):
+    def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, bias_proj=None):
         x = ops.dwconv_geo(x, self.depthwise.weight, self.depthwise.bias)
-        return ops.pointwise(x, self.pointwise.weight, self.pointwise.bias, bias_map, residual, act)
+        return ops.pointwise(x, self.pointwise.weight, self.pointwise.bias, bias_map, residual, act,
+                             bias_proj=bias_proj)
 
 
 class ChannelNorm(nn.Module):
@@ -130,6 +131,14 @@ class GlobalBias(nn.Module):
             nn.init.normal_(self.V, mean=0.0, std=1e-3)
         self.projection = (nn.Linear(input_dim, output_dim, bias=False)
                            if input_dim != output_dim else None)
+
+    def bias_terms(self):
+        """(bias_map, bias_proj) for the fused GEMM epilogue: with a projection (and <= 16 bias
+        channels) the [output_dim,H,W] map is never materialised - the GEMM adds
+        sum_c P[o,c] * m8[c,h,w] on the fly."""
+        if self.projection is not None and self.input_dim <= 16:
+            return None, (ops.global_bias_m8(self.A, self.U, self.V), self.projection.weight)
+        return self.bias_map(), None
 
     def bias_map(self) -> torch.Tensor:
         """[output_dim, H, W]; batch independent, recomputed every forward like the reference."""
@@ -224,9 +233,9 @@ class GMBlock(nn.Sequential):
                 i += 1
             elif isinstance(m, (CLinear, SepConv)):
                 j = i + 1
-                bias_map = act = None
+                bias_map = bias_proj = act = None
                 if j < n and isinstance(mods[j], GlobalBias):
-                    bias_map = mods[j].bias_map()
+                    bias_map, bias_proj = mods[j].bias_terms()
                     j += 1
                 if j < n and isinstance(mods[j], _ACT_TYPES):
                     act = type(mods[j]).__name__
@@ -238,9 +247,9 @@ class GMBlock(nn.Sequential):
                             and isinstance(m, CLinear) and torch.is_grad_enabled())
                 if isinstance(m, CLinear):
                     out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
-                            defer_act_grad=hand_off)
+                            defer_act_grad=hand_off, bias_proj=bias_proj)
                 else:
-                    out = m(x, bias_map=bias_map, act=act, residual=res)
+                    out = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj)
                 if hand_off:
                     x, pre = out
                     pre_act = act

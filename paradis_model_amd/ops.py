@@ -418,6 +418,39 @@ def global_bias_map(A, U, V, Pw=None):
     return _GlobalBiasMap.apply(A, U, V, Pw)
 
 
+class _GlobalBiasM8(torch.autograd.Function):
+    """Un-projected rank-R map m8[Cin,H,W]; the projection to the layer width is applied inside
+    the GEMM epilogue (``pointwise(..., bias_proj=(m8, Pw))``) so the [Co,H,W] map is never stored."""
+
+    @staticmethod
+    def forward(ctx, A, U, V):
+        require_hip(A, U, V)
+        A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
+        Cin, R = A.shape
+        H, W = U.shape[1], V.shape[1]
+        m8 = torch.empty(Cin, H, W, dtype=A.dtype, device=A.device)
+        check(lib.paradis_global_bias_m8_fwd(dptr(A), dptr(U), dptr(V), dptr(m8), Cin, R, H, W, stream_ptr()),
+              "global_bias_m8_fwd")
+        ctx.save_for_backward(A, U, V)
+        return m8
+
+    @staticmethod
+    def backward(ctx, gm8):
+        A, U, V = ctx.saved_tensors
+        Cin, R = A.shape
+        H, W = U.shape[1], V.shape[1]
+        gm8 = gm8.contiguous()
+        gA, gU, gV = torch.empty_like(A), torch.empty_like(U), torch.empty_like(V)
+        ws = _ws(lib.paradis_global_bias_map_bwd_ws_bytes(Cin, Cin, R, H, W), A.device)
+        check(lib.paradis_global_bias_m8_bwd(dptr(gm8), dptr(A), dptr(U), dptr(V), dptr(gA), dptr(gU), dptr(gV),
+                                             Cin, R, H, W, dptr(ws), stream_ptr()), "global_bias_m8_bwd")
+        return gA, gU, gV
+
+
+def global_bias_m8(A, U, V):
+    return _GlobalBiasM8.apply(A, U, V)
+
+
 # ---------------------------------------------------------------------------
 # a6 pointwise channel mixing on FP32 MFMA with fused epilogue
 #     y = residual + act(W x + bias + bias_map)
@@ -435,8 +468,8 @@ class _Pointwise(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad):
-        require_hip(x, weight, bias, bmap, residual, x_pre)
+    def forward(ctx, x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw):
+        require_hip(x, weight, bias, bmap, residual, x_pre, m8, pw)
         x, x_bs = _plane_view(x)
         B, Ci, H, W = x.shape
         Co = weight.shape[0]
@@ -450,7 +483,13 @@ class _Pointwise(torch.autograd.Function):
         if bmap is not None:
             bmap = bmap.contiguous()
         y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
-        need_z = act != 0 and (any(ctx.needs_input_grad[:4]) or defer_act_grad)
+        need_z = act != 0 and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[9:11])
+                               or defer_act_grad)
+        cin = 0
+        if pw is not None:
+            m8, pw = m8.contiguous(), pw.contiguous()
+            cin = pw.shape[1]
+            assert pw.shape[0] == Co and m8.shape == (cin, H, W) and bmap is None
         z = torch.empty_like(y) if need_z else None
         # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
         w2t = None
@@ -458,12 +497,14 @@ class _Pointwise(torch.autograd.Function):
             w2t = torch.empty(Ci, Co, dtype=x.dtype, device=x.device)
             check(lib.paradis_transpose(dptr(w2), dptr(w2t), Co, Ci, stream_ptr()), "transpose")
         _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(x), dptr(bias),
-                  dptr(bmap), dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs, res_bs, Co * P, act,
-                  stream_ptr())
+                  dptr(bmap), dptr(m8), dptr(pw), cin, dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs,
+                  res_bs, Co * P, act, stream_ptr())
         if x_pre is not None:
             x_pre = x_pre.contiguous()
         ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0),
-                              x_pre if x_pre is not None else x.new_empty(0))
+                              x_pre if x_pre is not None else x.new_empty(0),
+                              m8 if pw is not None else x.new_empty(0),
+                              pw if pw is not None else x.new_empty(0))
         ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape,
                     x_act if x_pre is not None else 0, bool(defer_act_grad))
         if defer_act_grad:
@@ -473,8 +514,9 @@ class _Pointwise(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *unused):
-        x, w2, z, x_pre = ctx.saved_tensors
+        x, w2, z, x_pre, m8, pw = ctx.saved_tensors
         x_bs, act, has_bias, has_map, has_res, wshape, x_act, deferred = ctx.meta
+        has_proj = pw.numel() > 0
         B, Ci, H, W = x.shape
         Co, P = w2.shape[0], H * W
         gy = gy.contiguous()
@@ -485,14 +527,15 @@ class _Pointwise(torch.autograd.Function):
             check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, st), "act_bwd")
         else:
             dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
-        gx = gw = gb = gmap = None
+        gx = gw = gb = gmap = gm8 = gpw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, Ci, H, W, dtype=gy.dtype, device=gy.device)
             zmul = x_pre if x_act != 0 else None
             _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(dz), dptr(zmul), None, dptr(gx),
                       B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P, x_act, st)
         want_b = has_bias and ctx.needs_input_grad[2]
-        want_m = has_map and ctx.needs_input_grad[3]
+        want_p = has_proj and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10])
+        want_m = (has_map and ctx.needs_input_grad[3]) or want_p
         if ctx.needs_input_grad[1]:
             gw = torch.empty(Co, Ci, dtype=gy.dtype, device=gy.device)
             ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), gy.device)
@@ -506,19 +549,29 @@ class _Pointwise(torch.autograd.Function):
             gb = torch.empty(Co, dtype=gy.dtype, device=gy.device) if want_b else None
             gmap = torch.empty(Co, H, W, dtype=gy.dtype, device=gy.device) if want_m else None
             check(lib.paradis_bias_grads(dptr(dz), dptr(gmap), dptr(gb), B, Co, P, Co * P, st), "bias_grads")
-        return gx, gw, gb, gmap, gres, None, None, None, None
+        if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
+            cin = pw.shape[1]
+            gpw = torch.empty_like(pw)
+            gm8 = torch.empty_like(m8)
+            check(lib.paradis_global_bias_proj_bwd(dptr(gmap), dptr(m8), dptr(pw), dptr(gpw), dptr(gm8), cin,
+                                                   Co, P, st), "global_bias_proj_bwd")
+            gmap = None
+        return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw
 
 
 def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
-              defer_act_grad=False):
+              defer_act_grad=False, bias_proj=None):
     """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1].
 
+    ``bias_proj=(m8[Cin,H,W], Pw[Co,Cin])`` adds the projected low-rank GlobalBias map inside the GEMM
+    epilogue instead of a materialised ``bias_map``.
     ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
     called with ``x_pre=z, x_act=act`` (see ``_Pointwise``); only valid when ``y`` has no other use."""
     if defer_act_grad and (act is None or residual is not None):
         raise ValueError("defer_act_grad needs an activation and no residual")
+    m8, pw = bias_proj if bias_proj is not None else (None, None)
     return _Pointwise.apply(x, weight, bias, bias_map, residual, ACT_CODES[act], x_pre,
-                            ACT_CODES[x_act], bool(defer_act_grad))
+                            ACT_CODES[x_act], bool(defer_act_grad), m8, pw)
 
 
 # ---------------------------------------------------------------------------

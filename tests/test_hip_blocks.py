@@ -51,6 +51,35 @@ def test_pointwise_gemm(ops, B, Ci, Co, H, W, act):
         _cmp(d.grad, t.grad, BWD, name)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,cin,R", [(2, 10, 7, 12, 16, 4, 6), (2, 128, 160, 32, 64, 8, 16),
+                                               (1, 130, 258, 17, 32, 3, 5)])
+@pytest.mark.parametrize("act", [None, "SiLU"])
+def test_pointwise_fused_global_bias_projection(ops, B, Ci, Co, H, W, cin, R, act):
+    """GlobalBias with projection applied inside the GEMM epilogue (no [Co,H,W] map in the forward)
+    == reference GlobalBias(x) = x + P(einsum(A,U,V)) (model/blocks.py:190-196) after a 1x1 conv."""
+    x = seeded(1, B, Ci, H, W)
+    w = seeded(2, Co, Ci, 1, 1, scale=Ci ** -0.5)
+    b = seeded(3, Co, scale=0.1)
+    A, U, V = seeded(4, cin, R, scale=0.5), seeded(5, R, H), seeded(6, R, W)
+    Pw = seeded(7, Co, cin, scale=0.5)
+    res = seeded(8, B, Co, H, W)
+    ct = seeded(9, B, Co, H, W)
+    ts = [t.clone().requires_grad_(True) for t in (x, w, b, A, U, V, Pw, res)]
+    bm = O.global_bias_map(ts[3], ts[4], ts[5], ts[6])
+    y = O.pointwise(ts[0], ts[1], ts[2]) + bm.unsqueeze(0)
+    if act:
+        y = O.activation(y, act)
+    y = y + ts[7]
+    y.backward(ct)
+    ds = [_dev(t) for t in (x, w, b, A, U, V, Pw, res)]
+    m8 = ops.global_bias_m8(ds[3], ds[4], ds[5])
+    yd = ops.pointwise(ds[0], ds[1], ds[2], None, ds[7], act, bias_proj=(m8, ds[6]))
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "y")
+    for name, d, t in zip(("gx", "gw", "gb", "gA", "gU", "gV", "gPw", "gres"), ds, ts):
+        _cmp(d.grad, t.grad, BWD, name)
+
+
 def test_pointwise_channel_slice_input(ops):
     big = seeded(1, 2, 40, 16, 32)
     w = seeded(2, 24, 16, 1, 1, scale=0.25)

@@ -55,7 +55,7 @@ def main():
             lib.paradis_debug_set_wgrad_dma(cfg[2] if cfg[2] <= 3 else 3)
             use_t = cfg[2] >= 2
             t = {}
-            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(x), None, None, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
+            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
             t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
             t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, dptr(ws), st))
             for k in t:

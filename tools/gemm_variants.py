@@ -59,7 +59,7 @@ def main():
         for name, L in libs.items():
             if name not in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") and wg != 4:
                 continue
-            fn = lambda: L.paradis_pw_gemm_fwd(p(w), None, p(x), None, None, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
+            fn = lambda: L.paradis_pw_gemm_fwd(p(w), None, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
             assert fn() == 0
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
