@@ -30,7 +30,7 @@ WORKLOADS = {
     "era5_5.625deg_32x64_S1_B32": (32, 64, False, 32, 1),
     "era5_5.625deg_32x64_S6_B32": (32, 64, False, 32, 6),
     "era5_1.4deg_128x256_S1_B8": (128, 256, False, 8, 1),
-    "era5_0.25deg_721x1440_fwd_B1": (721, 1440, True, 1, 1),     # forward only (use --forward-only)
+    "era5_0.25deg_721x1440_fwd_B1": (721, 1440, True, 1, 1),     # forward only (implies --forward-only)
 }
 
 
@@ -146,6 +146,8 @@ def main():
     dev = torch.device("cuda", local)
 
     nlat, nlon, poles, B, S = WORKLOADS[args.workload]
+    if "_fwd_" in args.workload:
+        args.forward_only = True   # 0.25 deg is an inference configuration (BASELINE configs[4])
     if args.batch:
         B = args.batch
     cfg = default_config()

@@ -86,9 +86,9 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value. */
 int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
                         const float* X, const float* bias, const float* map,
-                        const float* m8 /* [cin,N] */, const float* pw /* [M,cin] */, int cin,
-                        /* ^ optional low-rank bias applied on the fly: + sum_c pw[m,c]*m8[c,n] (GlobalBias
-                         *   with projection, reference model/blocks.py:190-196), cin <= 16, or NULL/NULL/0 */
+                        const float* m8 /* [cin,N] */, const float* pwT /* [cin,M] */, int cin,
+                        /* ^ optional low-rank bias applied on the fly: + sum_c pwT[c,m]*m8[c,n] (GlobalBias
+                         *   with projection, reference model/blocks.py:190-196), M % 4 == 0, or NULL/NULL/0 */
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
                         int act, void* stream);

@@ -50,7 +50,7 @@ struct GemmArgs {
   int act;
   int stagger;                // start-up skew between co-resident workgroups, in units of 512 cycles
   float* rowsum;              // wgrad only: [nbatch][M] partial row sums of A (= bias gradient), or NULL
-  // low-rank bias map applied on the fly: v += sum_c pw[m*cin + c] * m8[c*N + n]  (cin <= 16)
+  // low-rank bias map applied on the fly: acc[m,n] += sum_c pw[c*M + m] * m8[c*N + n]  (M % 4 == 0)
   const float* m8; const float* pw; int cin;
 };
 
@@ -121,6 +121,33 @@ __device__ __forceinline__ void slab_store(float* __restrict__ img, const float4
   }
 }
 
+// ---- low-rank bias (GlobalBias with projection) accumulated straight into the MFMA accumulators:
+//   acc[m,n] += sum_c pwT[c,m] * m8[c,n].  pwT is the transposed projection weight so that the four
+//   consecutive rows (r&3) of an accumulator group come from one 16-byte load (needs M % 4 == 0).
+//   One channel at a time keeps the live set at acc + 8 registers.
+__device__ __forceinline__ void gemm_add_projection(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0,
+                                                    int wm, int wn, int li, int lh) {
+  const int nc0 = min(n0 + wn * 64 + li, g.N - 1), nc1 = min(n0 + wn * 64 + 32 + li, g.N - 1);
+#pragma unroll 1
+  for (int c = 0; c < g.cin; ++c) {
+    const float mb0 = g.m8[(int64_t)c * g.N + nc0], mb1 = g.m8[(int64_t)c * g.N + nc1];
+    const float* pc = g.pw + (int64_t)c * g.M;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int mrow = m0 + wm * 64 + tm * 32 + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mr = mrow + 8 * j;
+        const float4 p4 = (mr < g.M) ? *reinterpret_cast<const float4*>(pc + mr) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[tm][0][4 * j + 0] += p4.x * mb0; acc[tm][1][4 * j + 0] += p4.x * mb1;
+        acc[tm][0][4 * j + 1] += p4.y * mb0; acc[tm][1][4 * j + 1] += p4.y * mb1;
+        acc[tm][0][4 * j + 2] += p4.z * mb0; acc[tm][1][4 * j + 2] += p4.z * mb1;
+        acc[tm][0][4 * j + 3] += p4.w * mb0; acc[tm][1][4 * j + 3] += p4.w * mb1;
+      }
+    }
+  }
+}
+
 // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 //   v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v); v += res; C = v
 // Interior tiles take a path without per-element guards in which all loads of one 32-row group are
@@ -131,6 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
   const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
   const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
   float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
+  if (g.pw) gemm_add_projection(g, acc, m0, n0, wm, wn, li, lh);
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -156,15 +184,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             for (int q = 0; q < 8; ++q) t[q] = g.map[base + ROWOFF(q)];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += t[q];
-          }
-          if (g.pw) {   // GlobalBias projection without materialising the [M,N] map
-            const int ncol = n0 + wn * 64 + tn * 32 + li;
-            for (int c = 0; c < g.cin; ++c) {
-              const float mb = g.m8[(int64_t)c * g.N + ncol];
-#pragma unroll
-              for (int q = 0; q < 8; ++q)
-                v[q] += g.pw[(int64_t)(mrow + (q & 3) + 8 * (2 * h + (q >> 2))) * g.cin + c] * mb;
-            }
           }
           if (zoutb) {
 #pragma unroll
@@ -210,8 +229,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const int64_t off = (int64_t)m * g.ldc + n;
         float v = acc[tm][tn][r] + bv;
         if (g.map) v += g.map[off];
-        if (g.pw)
-          for (int c = 0; c < g.cin; ++c) v += g.pw[(int64_t)m * g.cin + c] * g.m8[(int64_t)c * g.N + n];
         if (zoutb) zoutb[off] = v;
         if (zmulb) v *= act_grad(zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
@@ -649,16 +666,16 @@ extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = s
 
 extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const float* X,
                                    const float* bias, const float* map, const float* m8,
-                                   const float* pw, int cin, const float* res, float* Y, float* zpre,
+                                   const float* pwT, int cin, const float* res, float* Y, float* zpre,
                                    int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
                                    int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
-  PD_REQUIRE((m8 == nullptr) == (pw == nullptr) && (pw == nullptr || (cin >= 1 && cin <= 16)),
-             "pw_gemm_fwd: projected bias needs m8, pw and 1 <= cin <= 16");
+  PD_REQUIRE((m8 == nullptr) == (pwT == nullptr) && (pwT == nullptr || (cin >= 1 && M % 4 == 0)),
+             "pw_gemm_fwd: projected bias needs m8, pwT, cin >= 1 and M %% 4 == 0");
   if (B == 0) return 0;
   GemmArgs g{};
-  g.m8 = m8; g.pw = pw; g.cin = cin;
+  g.m8 = m8; g.pw = pwT; g.cin = cin;
   g.A = Wt; g.B = X; g.C = Y; g.M = M; g.N = N; g.K = K;
   g.lda = K; g.ldb = N; g.ldc = N;
   g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0;

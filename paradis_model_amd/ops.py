@@ -490,6 +490,8 @@ class _Pointwise(torch.autograd.Function):
             m8, pw = m8.contiguous(), pw.contiguous()
             cin = pw.shape[1]
             assert pw.shape[0] == Co and m8.shape == (cin, H, W) and bmap is None
+            assert Co % 4 == 0 and cin <= 16, "fused GlobalBias projection needs Co % 4 == 0 and <= 16 bias channels"
+            pwt = pw.t().contiguous()   # [cin, Co]: four consecutive output rows per 16-byte load
         z = torch.empty_like(y) if need_z else None
         # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
         w2t = None
@@ -497,7 +499,7 @@ class _Pointwise(torch.autograd.Function):
             w2t = torch.empty(Ci, Co, dtype=x.dtype, device=x.device)
             check(lib.paradis_transpose(dptr(w2), dptr(w2t), Co, Ci, stream_ptr()), "transpose")
         _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(x), dptr(bias),
-                  dptr(bmap), dptr(m8), dptr(pw), cin, dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs,
+                  dptr(bmap), dptr(m8), dptr(pwt) if cin else None, cin, dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs,
                   res_bs, Co * P, act, stream_ptr())
         if x_pre is not None:
             x_pre = x_pre.contiguous()

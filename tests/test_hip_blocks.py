@@ -51,8 +51,8 @@ def test_pointwise_gemm(ops, B, Ci, Co, H, W, act):
         _cmp(d.grad, t.grad, BWD, name)
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,cin,R", [(2, 10, 7, 12, 16, 4, 6), (2, 128, 160, 32, 64, 8, 16),
-                                               (1, 130, 258, 17, 32, 3, 5)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,cin,R", [(2, 10, 8, 12, 16, 4, 6), (2, 128, 160, 32, 64, 8, 16),
+                                               (1, 130, 260, 17, 32, 3, 5)])
 @pytest.mark.parametrize("act", [None, "SiLU"])
 def test_pointwise_fused_global_bias_projection(ops, B, Ci, Co, H, W, cin, R, act):
     """GlobalBias with projection applied inside the GEMM epilogue (no [Co,H,W] map in the forward)
