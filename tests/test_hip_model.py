@@ -18,9 +18,13 @@ def _build(cfg, lg, og, state=None):
     return m.cuda()
 
 
-@pytest.mark.parametrize("variant", ["a", "b", "c"])
-def test_reduced_model_vs_reference_golden(variant):
+@pytest.mark.parametrize("variant,fuse_projection", [("a", False), ("b", False), ("c", False), ("a", True),
+                                                     ("c", True)])
+def test_reduced_model_vs_reference_golden(variant, fuse_projection, monkeypatch):
     from paradis_model_amd.loss import build_loss
+    from paradis_model_amd.model import blocks
+    # the large-plane path (GlobalBias projection inside the GEMM) must give the same model
+    monkeypatch.setattr(blocks, "FUSE_BIAS_PROJECTION_MIN_POINTS", 0 if fuse_projection else 1 << 40)
     rec = load_golden(f"g4_model_{variant}.pt")
     v = rec["variant"]
     cfg = reduced_config(activation=v["activation"], adv_interpolation=v["adv_interpolation"],
