@@ -34,7 +34,7 @@
 #pragma clang fp contract(off)
 
 // Diagnostic ablation switches (tools/advect_variants.py builds side libraries with them; the
-// shipped library defines none):  ADV_NO_ATOMIC, ADV_NO_TRIG, ADV_OCML_SINCOS
+// shipped library defines none):  ADV_NO_ATOMIC, ADV_NO_TRIG, ADV_CW_SINCOS, ADV_IEEE_DIV, ADV_OCML_ATAN2
 namespace {
 
 constexpr float TWO_PI_F = 6.283185307179586f;
@@ -47,11 +47,31 @@ constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule
 #ifndef ADV_UNROLL_BWD
 #define ADV_UNROLL_BWD 2
 #endif
+#ifndef ADV_PF
+#define ADV_PF 1   // prefetch distance (points) of the velocity loads in the forward kernel (2/4/8 measured slower)
+#endif
 
 struct AdvGeom {
   int H, W, p;
   float dt, min_lat, min_lon, d_lat, d_lon;
+  // correctly rounded reciprocals of the four loop-invariant divisors (host, via double)
+  float r_lat, r_lon, r_wpm1, r_hpm1;
 };
+
+// x / d for a loop-invariant d with rd = RN(1/d): q = RN(x rd), r = x - q d (exact in the FMA),
+// q' = RN(q + r rd) is the correctly rounded quotient (Markstein), i.e. bit-identical to the IEEE
+// division of the reference's fp32 chain at 3 instructions instead of ~10.  Verified bit-exact
+// against '/' for the divisors of every grid (tests/test_hip_pad_advect.py, oracle/check_div.c).
+__device__ __forceinline__ float div_by(float x, float d, float rd) {
+#ifdef ADV_IEEE_DIV
+  (void)rd;
+  return x / d;
+#else
+  const float q = x * rd;
+  const float r = fmaf(-q, d, x);
+  return fmaf(r, rd, q);
+#endif
+}
 
 struct DepState {  // intermediates needed by the backward chain
   float sp, cp, sl, cl, s, n, d;
@@ -60,7 +80,7 @@ struct DepState {  // intermediates needed by the backward chain
 // sin and cos with a Cody-Waite reduction (fdlibm's float split of pi/2) and the cephes minimax
 // polynomials on [-pi/4, pi/4] (<= ~1 ulp); huge arguments take the ocml path.
 __device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
-#ifdef ADV_OCML_SINCOS
+#ifndef ADV_CW_SINCOS   // measured: the ocml routine is 5 % faster in the forward kernel than this one
   sincosf(x, &s, &c);
 #else
   if (fabsf(x) > 8192.0f) {
@@ -73,9 +93,10 @@ __device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
   r = fmaf(-k, 6.0770999344e-11f, r);
   const int q = (int)k;
   const float z = r * r;
-  const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-  const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z -
-                   0.5f * z + 1.0f;
+  const float ps =
+      fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                        z * z, fmaf(-0.5f, z, 1.0f));
   const float ss = (q & 1) ? pc : ps;
   const float cc = (q & 1) ? ps : pc;
   s = (q & 2) ? -ss : ss;
@@ -96,6 +117,32 @@ __device__ __forceinline__ float wrap_two_pi(float t) {
   return m;
 }
 
+// atan2f for finite arguments of ordinary magnitude (here n^2 + d^2 = cos^2(lat_d) > 1e-7): the
+// ocml algorithm (min/max quotient by v_rcp, degree-8 minimax in t^2, octant fix-ups) without its
+// frexp/ldexp overflow scaling and inf/NaN classification - same bits in this range.
+__device__ __forceinline__ float atan2_finite(float y, float x) {
+#ifdef ADV_OCML_ATAN2
+  return atan2f(y, x);
+#else
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float z = t * t;
+  float pp = fmaf(z, 0x1.5a54bp-9f, -0x1.f4b218p-7f);
+  pp = fmaf(z, pp, 0x1.53f67ep-5f);
+  pp = fmaf(z, pp, -0x1.2fa9aep-4f);
+  pp = fmaf(z, pp, 0x1.b26364p-4f);
+  pp = fmaf(z, pp, -0x1.22c1ccp-3f);
+  pp = fmaf(z, pp, 0x1.99717ep-3f);
+  pp = fmaf(z, pp, -0x1.5554c4p-2f);
+  float a = fmaf(t, z * pp, t);
+  a = (ay > ax) ? 0x1.921fb6p+0f - a : a;
+  a = (x < 0.f) ? 0x1.921fb6p+1f - a : a;
+  a = (y == 0.f) ? ((__float_as_int(x) < 0) ? 0x1.921fb6p+1f : 0.f) : a;   // also covers 0/0
+  return copysignf(a, y);
+#endif
+}
+
 __device__ __forceinline__ void departure(float u, float v, float sa, float ca, float lon_a,
                                           const AdvGeom& g, float& ix, float& iy, DepState* st) {
 #ifdef ADV_NO_TRIG
@@ -114,14 +161,14 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
   const float lat_d = asinf(sc);
   const float n = cp * sl;
   const float d = cc * ca - sp * sa;
-  float lon_d = lon_a + atan2f(n, d);
+  float lon_d = lon_a + atan2_finite(n, d);
   lon_d = lon_d + TWO_PI_F;
   const float m = wrap_two_pi(lon_d);
-  const float pix_x = (m - g.min_lon) / g.d_lon * ((float)g.W - 1.0f);
-  const float pix_y = (lat_d - g.min_lat) / g.d_lat * ((float)g.H - 1.0f);
+  const float pix_x = div_by(m - g.min_lon, g.d_lon, g.r_lon) * ((float)g.W - 1.0f);
+  const float pix_y = div_by(lat_d - g.min_lat, g.d_lat, g.r_lat) * ((float)g.H - 1.0f);
   const float wpm1 = (float)(g.W + 2 * g.p - 1), hpm1 = (float)(g.H + 2 * g.p - 1);
-  const float gx = 2.0f * ((pix_x + (float)g.p) / wpm1) - 1.0f;
-  const float gy = 2.0f * ((pix_y + (float)g.p) / hpm1) - 1.0f;
+  const float gx = 2.0f * div_by(pix_x + (float)g.p, wpm1, g.r_wpm1) - 1.0f;
+  const float gy = 2.0f * div_by(pix_y + (float)g.p, hpm1, g.r_hpm1) - 1.0f;
   ix = ((gx + 1.0f) / 2.0f) * wpm1;
   iy = ((gy + 1.0f) / 2.0f) * hpm1;
   if (st) {
@@ -129,10 +176,12 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
   }
 }
 
-__device__ __forceinline__ float cub1(float x) { return ((KA + 2.f) * x - (KA + 3.f)) * x * x + 1.f; }
-__device__ __forceinline__ float cub2(float x) { return ((KA * x - 5.f * KA) * x + 8.f * KA) * x - 4.f * KA; }
-__device__ __forceinline__ float dcub1(float x) { return (3.f * (KA + 2.f) * x - 2.f * (KA + 3.f)) * x; }
-__device__ __forceinline__ float dcub2(float x) { return (3.f * KA * x - 10.f * KA) * x + 8.f * KA; }
+// (explicit FMAs: the weights and tap sums are not coordinate-critical - an ulp of a weight is
+//  1e-7 relative in the result, whereas an ulp of a sample coordinate is multiplied by the field slope)
+__device__ __forceinline__ float cub1(float x) { return fmaf(fmaf(KA + 2.f, x, -(KA + 3.f)) * x, x, 1.f); }
+__device__ __forceinline__ float cub2(float x) { return fmaf(fmaf(fmaf(KA, x, -5.f * KA), x, 8.f * KA), x, -4.f * KA); }
+__device__ __forceinline__ float dcub1(float x) { return fmaf(3.f * (KA + 2.f), x, -2.f * (KA + 3.f)) * x; }
+__device__ __forceinline__ float dcub2(float x) { return fmaf(fmaf(3.f * KA, x, -10.f * KA), x, 8.f * KA); }
 
 template <int MODE>
 struct Interp {
@@ -181,8 +230,9 @@ __device__ __forceinline__ void tap_origin(float ix, float iy, int Hp, int Wp, i
   const float x0f = floorf(ix), y0f = floorf(iy);
   tx = ix - x0f;
   ty = iy - y0f;
-  const bool sane = (fabsf(ix) < 1e8f) && (fabsf(iy) < 1e8f);  // NaN/inf: every tap lies outside
-  const int x0 = sane ? (int)x0f + OFF0 : -1000000, y0 = sane ? (int)y0f + OFF0 : -1000000;
+  // NaN/inf/huge: v_med3 clamps (NaN -> the lower bound), the shift then zeroes every weight
+  const int x0 = (int)__builtin_amdgcn_fmed3f(x0f, -8.0f, (float)(Wp + 8)) + OFF0;
+  const int y0 = (int)__builtin_amdgcn_fmed3f(y0f, -8.0f, (float)(Hp + 8)) + OFF0;
   bx = min(max(x0, 0), Wp - NT);
   by = min(max(y0, 0), Hp - NT);
   sx = bx - x0;
@@ -200,40 +250,6 @@ struct Window {
   int wy0, wx0, WH, WW;
 };
 
-// stage src plane (image H x W) into the window through the geocyclic map; subst: replace source
-// rows 0 / H-1 by the given means (tiled schedule; WHOLE computes the means in LDS afterwards)
-__device__ __forceinline__ void stage_window(float* win, const float* __restrict__ F, const Window& w,
-                                             int H, int W, int p, bool subst, float m0, float m1) {
-  const int Hp = H + 2 * p;
-  for (int lr = threadIdx.x >> 6; lr < w.WH; lr += 4) {
-    const int r = w.wy0 + lr;  // padded row
-    float* dst = win + lr * w.WW;
-    if (r < 0 || r >= Hp) {
-      for (int lc = threadIdx.x & 63; lc < w.WW; lc += 64) dst[lc] = 0.f;
-      continue;
-    }
-    const int ii = r - p;
-    int sr;
-    bool mir = false;
-    if (ii < 0) { sr = -ii; mir = true; }
-    else if (ii >= H) { sr = 2 * (H - 1) - ii; mir = true; }
-    else sr = ii;
-    const float* srow = F + (int64_t)sr * W;
-    const bool pole0 = subst && sr == 0, pole1 = subst && sr == H - 1;
-    // periodic in longitude for any window offset: one modulo per row, then incremental wraps
-    int jj = (w.wx0 + (int)(threadIdx.x & 63) - p + (mir ? (W >> 1) : 0)) % W;
-    if (jj < 0) jj += W;
-    const int step = 64 % W;
-    for (int lc = threadIdx.x & 63; lc < w.WW; lc += 64, jj += step) {
-      if (jj >= W) jj -= W;
-      float val = srow[jj];
-      if (pole0) val = m0;
-      if (pole1) val = m1;
-      dst[lc] = val;
-    }
-  }
-}
-
 // iterate i = tid, tid+256, ... < th*tw as (yl, xl) without a division per point
 struct TileIter {
   int yl, xl, dy, dx, tw;
@@ -245,6 +261,106 @@ struct TileIter {
     if (xl >= tw) { xl -= tw; ++yl; }
   }
 };
+
+// stage src plane (image H x W) into the window through the geocyclic map; subst: replace source
+// rows 0 / H-1 by the given means (tiled schedule; WHOLE computes the means in LDS afterwards).
+// Flat over the window in batches: all loads of a batch are issued before the first LDS write, so a
+// workgroup pays ~one memory round trip for its window.  (A row-per-wave loop serialised one round
+// trip per row - 9 per wave at 32x64 - and cost 23 % of the forward kernel.)
+constexpr int STAGE_BATCH = 10;
+__device__ __forceinline__ void stage_window(float* win, const float* __restrict__ F, const Window& w,
+                                             int H, int W, int p, bool subst, float m0, float m1) {
+  const int Hp = H + 2 * p, n = w.WH * w.WW;
+  const bool narrow = 2 * w.WW < 3 * W && W > 16;
+  TileIter it(threadIdx.x, w.WW);
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * STAGE_BATCH) {
+    float val[STAGE_BATCH];
+#pragma unroll
+    for (int j = 0; j < STAGE_BATCH; ++j) {
+      val[j] = 0.f;
+      const int r = w.wy0 + it.yl;  // padded row
+      if (i0 + 256 * j < n && r >= 0 && r < Hp) {
+        const int ii = r - p;
+        int sr = ii;
+        bool mir = false;
+        if (ii < 0) { sr = -ii; mir = true; }
+        else if (ii >= H) { sr = 2 * (H - 1) - ii; mir = true; }
+        // periodic in longitude: with a window narrower than 1.5 W the offset lies in (-W, 3W)
+        int jj = w.wx0 + it.xl - p + (mir ? (W >> 1) : 0);
+        if (narrow) {
+          if (jj < 0) jj += W;
+          if (jj >= W) jj -= W;
+          if (jj >= W) jj -= W;
+        } else {
+          jj %= W;
+          if (jj < 0) jj += W;
+        }
+        float v = F[(int64_t)sr * W + jj];
+        if (subst && sr == 0) v = m0;
+        if (subst && sr == H - 1) v = m1;
+        val[j] = v;
+      }
+      it.next();
+    }
+#pragma unroll
+    for (int j = 0; j < STAGE_BATCH; ++j)
+      if (i0 + 256 * j < n) win[i0 + 256 * j] = val[j];
+  }
+}
+
+// WHOLE schedule, 16-byte path: the H x W interior of the padded plane is a plain copy (one float4
+// load + two 8-byte LDS writes per four cells); only the 2p halo columns and 2p mirrored rows go
+// through the index map.  ~4 loads and ~60 VALU instructions per thread instead of 10 and ~300.
+// Needs W % 4 == 0 and a 16-byte aligned plane.
+__device__ __forceinline__ void stage_whole_vec4(float* win, const float* __restrict__ F, int H, int W, int p) {
+  const int Wp = W + 2 * p, Hp = H + 2 * p, tid = threadIdx.x;
+  const int w4 = W >> 2, nvec = H * w4;
+  const int nhalo_rows = 2 * p * Wp, nhalo = nhalo_rows + H * 2 * p;
+  constexpr int VB = 2, HB = 2;
+  const float4* F4 = reinterpret_cast<const float4*>(F);
+  for (int v0 = tid, k0 = tid; v0 < nvec || k0 < nhalo; v0 += 256 * VB, k0 += 256 * HB) {
+    float4 q[VB];
+    float hv[HB];
+    int hdst[HB];
+#pragma unroll
+    for (int j = 0; j < VB; ++j)
+      if (v0 + 256 * j < nvec) q[j] = F4[v0 + 256 * j];
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const int k = k0 + 256 * j;
+      hdst[j] = -1;
+      if (k < nhalo) {
+        int lr, lc;
+        if (k < nhalo_rows) {          // the p rows beyond each pole, full padded width
+          const int rr = k / Wp;
+          lc = k - rr * Wp;
+          lr = rr < p ? rr : Hp - 2 * p + rr;
+        } else {                       // left / right halo columns of the interior rows
+          const int e = k - nhalo_rows, rr = e / (2 * p), cc = e - rr * 2 * p;
+          lr = rr + p;
+          lc = cc < p ? cc : W + cc;
+        }
+        int sr, sc;
+        geo_src(lr - p, lc - p, H, W, sr, sc);
+        hv[j] = F[sr * W + sc];
+        hdst[j] = lr * Wp + lc;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+      const int v = v0 + 256 * j;
+      if (v < nvec) {
+        const int y = v / w4, x4 = v - y * w4;
+        float2* d = reinterpret_cast<float2*>(win + (y + p) * Wp + p + 4 * x4);   // 8-byte aligned (p even, Wp even)
+        d[0] = make_float2(q[j].x, q[j].y);
+        d[1] = make_float2(q[j].z, q[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HB; ++j)
+      if (hdst[j] >= 0) win[hdst[j]] = hv[j];
+  }
+}
 
 // ======================================================================================
 // forward
@@ -279,21 +395,28 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
 
   float m0 = 0.f, m1 = 0.f;
   if (!WHOLE) { m0 = fmeans[2 * plane]; m1 = fmeans[2 * plane + 1]; }
-  stage_window(win, F, w, H, W, p, !WHOLE, m0, m1);
+#ifndef ADV_NO_STAGE
+  if (WHOLE && vec4) stage_whole_vec4(win, F, H, W, p);
+  else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1);
+#endif
   __syncthreads();
   if (WHOLE) {
-    if (wave < 2) {  // pole rows <- their mean, over the whole padded row (lon halo included)
+    // pole rows <- their mean, over the whole padded row (lon halo included).  (Reducing the two rows
+    // from global before staging would save this barrier but puts a dependent load in front of the
+    // staging loads: measured 2-7 % slower.)
+    if (wave < 2) {
       float* row = win + (wave == 0 ? p : H - 1 + p) * Wp;
       const float m = wave_row_mean(row + p, W);
       for (int x = tid & 63; x < Wp; x += 64) row[x] = m;
     }
     __syncthreads();
   }
+  // W == 64: an output row is one wave's lanes in one iteration -> its mean is a wave reduction
+  const bool rowwave = WHOLE && W == 64;
 
   const int npts = th * tw;
   // (a 4-points-per-thread variant with 16-B loads/stores measured SLOWER: 124 VGPRs halve the
   //  occupancy and the kernel is latency/issue-bound, not bandwidth-bound)
-  (void)vec4;
   // one arrival point: departure -> tap block -> window gather (or L2 fallback in the tiled schedule)
   auto point = [&](float uu, float vv, float sa, float ca, float lo) -> float {
     float ix, iy, tx, ty, wx[NT], wy[NT];
@@ -302,8 +425,10 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
     tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
     Interp<MODE>::weights(tx, wx);
     Interp<MODE>::weights(ty, wy);
-    shift_weights<NT>(wx, sx);
-    shift_weights<NT>(wy, sy);
+    if (sx | sy) {   // only when a coordinate rounds onto the plane edge (or is not finite)
+      shift_weights<NT>(wx, sx);
+      shift_weights<NT>(wy, sy);
+    }
     int ry = by - w.wy0, rx = bx - w.wx0;
     bool inwin = true;
     if (!WHOLE) {
@@ -313,13 +438,18 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
     float acc = 0.f;
     if (inwin) {
       const float* base = win + ry * w.WW + rx;
+#ifdef ADV_NO_GATHER
+      acc = (float)(ry * w.WW + rx) * (wx[0] + wx[1] + wy[0] + wy[1] + wx[NT - 1] + wy[NT - 1]);
+      (void)base;
+#else
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         float rowacc = 0.f;
 #pragma unroll
-        for (int bb = 0; bb < NT; ++bb) rowacc += base[a * w.WW + bb] * wx[bb];
-        acc += rowacc * wy[a];
+        for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[a * w.WW + bb], wx[bb], rowacc);
+        acc = fmaf(rowacc, wy[a], acc);
       }
+#endif
     } else {  // tiled schedule only: taps served by L2 through the index map
       const int lastrow = H - 1;
 #pragma unroll
@@ -339,16 +469,53 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
     return acc;
   };
   {
-    TileIter it(tid, tw);
-    for (int i = tid; i < npts; i += 256, it.next()) {
+    // Operand prefetch: the velocities (the HBM streams) are loaded ADV_PF points ahead and the
+    // geometry tables (L2-resident) one point ahead, so that every wave keeps enough bytes in flight
+    // by itself; with loads issued at the point of use the kernel ran at ~60 % VALU issue with the
+    // waves parked on s_waitcnt 57 % of the time (PMC).
+    TileIter it(tid, tw), itp(tid, tw);
+    float qu[ADV_PF], qv[ADV_PF];
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) {
+      qu[d] = 0.f; qv[d] = 0.f;
+      if (tid + 256 * d < npts) {
+        const int idx = (ty0 + itp.yl) * W + tx0 + itp.xl;
+        qu[d] = U[idx]; qv[d] = V[idx];
+      }
+      itp.next();
+    }
+    float nsa = 0.f, nca = 0.f, nlo = 0.f;
+    if (tid < npts) {
+      const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
+      nsa = sin_lat[idx]; nca = cos_lat[idx]; nlo = lon[idx];
+    }
+    for (int i = tid; i < npts; i += 256) {
       const int y = ty0 + it.yl, x = tx0 + it.xl, idx = y * W + x;
-      const float acc = point(U[idx], V[idx], sin_lat[idx], cos_lat[idx], lon[idx]);
-      if (WHOLE && y == 0) pole_out[x] = acc;
-      else if (WHOLE && y == H - 1) pole_out[W + x] = acc;
-      else O[idx] = acc;
+      const float cu = qu[0], cv = qv[0], csa = nsa, cca = nca, clo = nlo;
+#pragma unroll
+      for (int d = 0; d + 1 < ADV_PF; ++d) { qu[d] = qu[d + 1]; qv[d] = qv[d + 1]; }
+      if (i + 256 * ADV_PF < npts) {
+        const int pidx = (ty0 + itp.yl) * W + tx0 + itp.xl;
+        qu[ADV_PF - 1] = U[pidx]; qv[ADV_PF - 1] = V[pidx];
+      }
+      itp.next();
+      it.next();
+#ifndef ADV_NO_TABLES
+      if (i + 256 < npts) {
+        const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
+        nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx];
+      }
+#endif
+      const float acc = point(cu, cv, csa, cca, clo);
+      if (WHOLE && (y == 0 || y == H - 1)) {
+        if (rowwave) O[idx] = wave_sum(acc) / (float)W;
+        else pole_out[(y == 0 ? 0 : W) + x] = acc;
+      } else {
+        O[idx] = acc;
+      }
     }
   }
-  if (WHOLE) {
+  if (WHOLE && !rowwave) {
     __syncthreads();
     if (wave < 2) {
       const float* row = pole_out + (wave == 0 ? 0 : W);
@@ -362,6 +529,19 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
 // ======================================================================================
 // backward
 // ======================================================================================
+// round-to-nearest-even integer of x (|x| < 2^51) as a two's-complement 64-bit pattern in three
+// instructions: widen, add 1.5*2^52 (the integer lands in the low mantissa bits), strip the exponent
+// pattern from the high word.  (A float -> int64 conversion proper is ~12 VALU instructions and the
+// scatter does 16 of them per point.)
+__device__ __forceinline__ unsigned long long fixed_from_float(float x) {
+#ifdef ADV_CVT_I64
+  return (unsigned long long)__float2ll_rn(x);
+#else
+  const double d = (double)x + 6755399441055744.0;
+  return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
+#endif
+}
+
 __device__ __forceinline__ void fixed_point_scale(float mx, float& scale, float& inv) {
   scale = 0.f; inv = 0.f;
   if (mx > 0.f && mx < INFINITY) {
@@ -380,10 +560,20 @@ __device__ __forceinline__ void departure_backward(const DepState& st, float sa,
                                                    float& gv) {
   const float glam_c = gix * kx, gphi_c = giy * ky;
   const float sc = fminf(fmaxf(st.s, -CLAMP_HI), CLAMP_HI);
+#ifdef ADV_IEEE_DIV
   const float gs = (st.s >= -CLAMP_HI && st.s <= CLAMP_HI) ? gphi_c / sqrtf(1.0f - sc * sc) : 0.f;
   const float den = st.n * st.n + st.d * st.d;
   const float gn = glam_c * st.d / den;
   const float gd = -glam_c * st.n / den;
+#else
+  // v_rsq / v_rcp (1 ulp) with one Newton step on the reciprocal: gradient error ~1e-7 relative
+  const float gs = (st.s >= -CLAMP_HI && st.s <= CLAMP_HI) ? gphi_c * __builtin_amdgcn_rsqf(1.0f - sc * sc) : 0.f;
+  const float den = st.n * st.n + st.d * st.d;
+  float rden = __builtin_amdgcn_rcpf(den);
+  rden = fmaf(fmaf(-den, rden, 1.0f), rden, rden);
+  const float gn = glam_c * st.d * rden;
+  const float gd = -glam_c * st.n * rden;
+#endif
   const float gphi = gs * (st.cp * ca - st.sp * st.cl * sa) + gn * (-st.sp * st.sl) +
                      gd * (-st.sp * st.cl * ca - st.cp * sa);
   const float glam = gs * (-st.cp * st.sl * sa) + gn * (st.cp * st.cl) + gd * (-st.cp * st.sl * ca);
@@ -399,7 +589,8 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
                      const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                      const float* __restrict__ lon, const float* __restrict__ fmeans,
                      const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
-                     int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles) {
+                     int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles,
+                     int vec4) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -423,21 +614,23 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
   const int wn = w.WH * w.WW, wn2 = (wn + 1) & ~1;
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);  // [wn] fixed-point sums
   float* win = smem + 2 * wn2;                                             // [wn]  F~ window
-  float* misc = win + wn2;   // [0..1] pole means of gout, [2..5] per-wave max, [6] scale, [7] 1/scale
+  float* misc = win + wn2;   // [0..1] pole means of gout, [2..5] per-wave max |cotangent|
 
   float m0 = 0.f, m1 = 0.f, gm0 = 0.f, gm1 = 0.f;
   if (!WHOLE) {
     m0 = fmeans[2 * plane]; m1 = fmeans[2 * plane + 1];
     gm0 = gmeans[2 * plane]; gm1 = gmeans[2 * plane + 1];
   }
-  stage_window(win, F, w, H, W, p, !WHOLE, m0, m1);
+  if (WHOLE && vec4) stage_whole_vec4(win, F, H, W, p);
+  else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1);
   for (int i = tid; i < wn; i += 256) acc[i] = 0ull;
   // max |cotangent| over this workgroup's arrival points -> fixed-point scale
   const int npts = th * tw;
   float gmax = WHOLE ? 0.f : fmaxf(fabsf(gm0), fabsf(gm1));
-  for (int i = tid; i < npts; i += 256) {
-    const int yl = i / tw, xl = i - yl * tw;
-    gmax = fmaxf(gmax, fabsf(GO[(ty0 + yl) * W + tx0 + xl]));
+  {
+    TileIter itg(tid, tw);
+    for (int i = tid; i < npts; i += 256, itg.next())
+      gmax = fmaxf(gmax, fabsf(GO[(ty0 + itg.yl) * W + tx0 + itg.xl]));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
@@ -454,34 +647,45 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
       const float m = wave_row_mean(row, W);
       if ((tid & 63) == 0) misc[wave - 2] = m;
     }
+    __syncthreads();
+    gm0 = misc[0]; gm1 = misc[1];
   }
-  if (tid == 0) {
-    const float mx = fmaxf(fmaxf(misc[2], misc[3]), fmaxf(misc[4], misc[5]));
-    fixed_point_scale(mx, misc[6], misc[7]);
-  }
-  __syncthreads();
-  if (WHOLE) { gm0 = misc[0]; gm1 = misc[1]; }
-  const float scale = misc[6];
+  float scale, inv_scale;   // every thread derives the same power-of-two scale
+  fixed_point_scale(fmaxf(fmaxf(misc[2], misc[3]), fmaxf(misc[4], misc[5])), scale, inv_scale);
+  const bool rowwave = WHOLE && W == 64;
 
   const float kx = ((float)W - 1.0f) / g.d_lon, ky = ((float)H - 1.0f) / g.d_lat;
   TileIter it(tid, tw);
-  for (int i = tid; i < npts; i += 256, it.next()) {
+  // operands of point i+1 are in flight while point i is computed (see the forward kernel)
+  float nu = 0.f, nv = 0.f, nsa = 0.f, nca = 0.f, nlo = 0.f, ngo = 0.f;
+  if (tid < npts) {
+    const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
+    nu = U[idx]; nv = V[idx]; nsa = sin_lat[idx]; nca = cos_lat[idx]; nlo = lon[idx]; ngo = GO[idx];
+  }
+  for (int i = tid; i < npts; i += 256) {
     const int y = ty0 + it.yl, x = tx0 + it.xl, idx = y * W + x;
-    const float sa = sin_lat[idx], ca = cos_lat[idx];
+    const float cu = nu, cv = nv, sa = nsa, ca = nca, clo = nlo, cgo = ngo;
+    it.next();
+    if (i + 256 < npts) {
+      const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
+      nu = U[nidx]; nv = V[nidx]; nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx]; ngo = GO[nidx];
+    }
     float ix, iy, tx, ty, wx[NT], wy[NT], dwx[NT], dwy[NT];
     int bx, by, sx, sy;
     DepState st;
-    departure(U[idx], V[idx], sa, ca, lon[idx], g, ix, iy, &st);
+    departure(cu, cv, sa, ca, clo, g, ix, iy, &st);
     tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
     Interp<MODE>::weights(tx, wx);
     Interp<MODE>::weights(ty, wy);
     Interp<MODE>::dweights(tx, dwx);
     Interp<MODE>::dweights(ty, dwy);
-    shift_weights<NT>(wx, sx);
-    shift_weights<NT>(dwx, sx);
-    shift_weights<NT>(wy, sy);
-    shift_weights<NT>(dwy, sy);
-    const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : GO[idx]);
+    if (sx | sy) {
+      shift_weights<NT>(wx, sx);
+      shift_weights<NT>(dwx, sx);
+      shift_weights<NT>(wy, sy);
+      shift_weights<NT>(dwy, sy);
+    }
+    const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
     const float gs_ = gval * scale;
     int ry = by - w.wy0, rx = bx - w.wx0;
     bool inwin = true;
@@ -501,13 +705,13 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
           const int cell = base + a * w.WW + bb;
           const float val = win[cell];
 #ifndef ADV_NO_ATOMIC
-          atomicAdd(&acc[cell], (unsigned long long)__float2ll_rn(gwy * wx[bb]));
+          atomicAdd(&acc[cell], fixed_from_float(gwy * wx[bb]));
 #endif
-          sxv += val * wx[bb];
-          sdx += val * dwx[bb];
+          sxv = fmaf(val, wx[bb], sxv);
+          sdx = fmaf(val, dwx[bb], sdx);
         }
-        gix += wy[a] * sdx;
-        giy += dwy[a] * sxv;
+        gix = fmaf(wy[a], sdx, gix);
+        giy = fmaf(dwy[a], sxv, giy);
       }
     } else {  // tiled schedule only
       const int lastrow = H - 1;
@@ -536,24 +740,32 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     GV[idx] = gvv;
   }
   __syncthreads();
-  const double inv = (double)misc[7];
+  const double inv = (double)inv_scale;
   if (WHOLE) {
     // fold the halo back: every source cell sums its aliases (adjoint of the a1 map), then the
-    // adjoint of the first pole mean; the float plane reuses the window storage
+    // adjoint of the first pole mean (rows 0, H-1 <- their mean)
     for (int i = tid; i < P; i += 256) {
       const int y = i / W, x = i - y * W;
       long long s = 0;
       geo_for_each_alias(y, x, H, W, p, [&](int ii, int jj) { s += (long long)acc[(ii + p) * Wp + jj + p]; });
-      win[i] = (float)((double)s * inv);
+      float val = (float)((double)s * inv);
+      if (rowwave) {   // a row is one wave's lanes in one iteration
+        if (y == 0 || y == H - 1) val = wave_sum(val) / (float)W;
+        GF[i] = val;
+      } else {
+        win[i] = val;  // the float plane reuses the window storage
+      }
     }
-    __syncthreads();
-    if (wave < 2) {
-      float* row = win + (wave == 0 ? 0 : (H - 1) * W);
-      const float m = wave_row_mean(row, W);
-      for (int x = tid & 63; x < W; x += 64) row[x] = m;
+    if (!rowwave) {
+      __syncthreads();
+      if (wave < 2) {
+        float* row = win + (wave == 0 ? 0 : (H - 1) * W);
+        const float m = wave_row_mean(row, W);
+        for (int x = tid & 63; x < W; x += 64) row[x] = m;
+      }
+      __syncthreads();
+      for (int i = tid; i < P; i += 256) GF[i] = win[i];
     }
-    __syncthreads();
-    for (int i = tid; i < P; i += 256) GF[i] = win[i];
   } else {
     // flush the window once: one global float atomic per touched cell instead of 16 per point
     for (int i = tid; i < wn; i += 256) {
@@ -604,6 +816,15 @@ int check_adv(const char* name, int B, int K, int H, int W, int mode) {
   return 0;
 }
 
+AdvGeom make_geom(int H, int W, int p, float dt, float min_lat, float min_lon, float d_lat, float d_lon) {
+  AdvGeom g{H, W, p, dt, min_lat, min_lon, d_lat, d_lon, 0.f, 0.f, 0.f, 0.f};
+  g.r_lat = (float)(1.0 / (double)d_lat);
+  g.r_lon = (float)(1.0 / (double)d_lon);
+  g.r_wpm1 = (float)(1.0 / (double)(W + 2 * p - 1));
+  g.r_hpm1 = (float)(1.0 / (double)(H + 2 * p - 1));
+  return g;
+}
+
 constexpr size_t WHOLE_LDS_LIMIT = 64 * 1024;
 int g_force_tiled = -1;   // debug: -1 auto, 0/1 force
 int g_halo = 6;           // window halo (padded cells) of the tiled schedule
@@ -643,13 +864,13 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   if (int e = check_adv("sl_advect_fwd", B, K, H, W, mode)) return e;
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
-  AdvGeom g{H, W, p, dt, min_lat, min_lon, d_lat, d_lon};
+  AdvGeom g = make_geom(H, W, p, dt, min_lat, min_lon, d_lat, d_lon);
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * K;
   const size_t whole = ((size_t)(H + 2 * p) * (W + 2 * p) + 2 * W) * sizeof(float);
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const int vec4 = (W % 4 == 0) && (uv_bs % 4 == 0) && (o_bs % 4 == 0) && a16(u) && a16(v) && a16(out) &&
-                   a16(sin_lat) && a16(cos_lat) && a16(lon);
+  // 16-byte staging path: aligned planes, p even (bicubic), padded width even
+  const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && a16(field) && (p % 2 == 0);
   if (!use_tiled(whole)) {
     ADV_LAUNCH(sl_advect_fwd_kernel, true, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
                (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
@@ -680,15 +901,17 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   if (int e = check_adv("sl_advect_bwd", B, K, H, W, mode)) return e;
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
-  AdvGeom g{H, W, p, dt, min_lat, min_lon, d_lat, d_lon};
+  AdvGeom g = make_geom(H, W, p, dt, min_lat, min_lon, d_lat, d_lon);
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * K, P = H * W;
   auto lds_of = [](size_t cells) { return (3 * ((cells + 1) & ~(size_t)1) + 8) * sizeof(float); };
+  const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && (p % 2 == 0) &&
+                   (reinterpret_cast<uintptr_t>(field) & 15) == 0;
   const size_t whole = lds_of((size_t)(H + 2 * p) * (W + 2 * p));
   if (!use_tiled(whole)) {
     ADV_LAUNCH(sl_advect_bwd_kernel, true, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
                cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
-               gf_bs, guv_bs, 0, 1, 1);
+               gf_bs, guv_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_bwd");
     return 0;
   }
@@ -708,7 +931,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   const size_t lds = lds_of((size_t)(TILE_H + 2 * g_halo + NT) * (TILE_W + 2 * g_halo + NT));
   ADV_LAUNCH(sl_advect_bwd_kernel, false, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
              gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-             f_bs, uv_bs, gf_bs, guv_bs, g_halo, tx, tiles);
+             f_bs, uv_bs, gf_bs, guv_bs, g_halo, tx, tiles, vec4);
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");
   return 0;

@@ -111,8 +111,17 @@ def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode):
     y32.backward(ct)
     assert rms_rel(y, yr.detach()) <= 1.5 * rms_rel(y32.detach(), yr.detach()) + 2e-7
     assert rms_rel(gf, fd.grad) <= 1.5 * rms_rel(f32.grad, fd.grad) + 1e-6
-    assert rms_rel(gu, ud.grad) <= 1.5 * rms_rel(u32.grad, ud.grad) + 1e-5
-    assert rms_rel(gv, vd.grad) <= 1.5 * rms_rel(v32.grad, vd.grad) + 1e-5
+    # Velocity gradients: d asin(s) = 1/sqrt(1-s^2) amplifies one ulp of s by up to ~2000 next to the
+    # poles, so a handful of ill-conditioned points (different in every fp32 implementation) carries
+    # the rms and the max (tools/advect_accuracy.py prints the distribution).  The bulk of the
+    # distribution is what a formula error would move: compare quantiles tightly, the rms loosely.
+    q = torch.tensor([0.5, 0.99, 0.999], dtype=torch.float64)
+    for name, got, g32, g64 in (("gu", gu, u32.grad, ud.grad), ("gv", gv, v32.grad, vd.grad)):
+        sc = float(g64.abs().max())
+        e_gpu = torch.quantile(((got.double() - g64).abs() / sc).flatten(), q)
+        e_cpu = torch.quantile(((g32.double() - g64).abs() / sc).flatten(), q)
+        assert bool((e_gpu <= 1.5 * e_cpu + 1e-8).all()), (name, e_gpu.tolist(), e_cpu.tolist())
+        assert rms_rel(got, g64) <= 8 * rms_rel(g32, g64) + 1e-5, name
 
 
 def test_advect_channel_slice_inputs(ops):

@@ -12,8 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "paradis_model_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
-VARIANTS = {"base": [], "ocml_sincos": ["-DADV_OCML_SINCOS"], "no_atomic": ["-DADV_NO_ATOMIC"],
-            "no_trig": ["-DADV_NO_TRIG"], "no_both": ["-DADV_NO_ATOMIC", "-DADV_NO_TRIG"]}
+VARIANTS = {"base": [], "ieee_div": ["-DADV_IEEE_DIV"], "ocml_atan2": ["-DADV_OCML_ATAN2"],
+            "cw_sincos": ["-DADV_CW_SINCOS"], "no_atomic": ["-DADV_NO_ATOMIC"],
+            "no_trig": ["-DADV_NO_TRIG"], "no_both": ["-DADV_NO_ATOMIC", "-DADV_NO_TRIG"],
+            "cvt_i64": ["-DADV_CVT_I64"], "pf2": ["-DADV_PF=2"], "pf4": ["-DADV_PF=4"], "no_stage": ["-DADV_NO_STAGE"],
+            "no_gather": ["-DADV_NO_GATHER"], "no_tables": ["-DADV_NO_TABLES"],
+            "no_sgt": ["-DADV_NO_STAGE", "-DADV_NO_GATHER", "-DADV_NO_TABLES"],
+            "no_sgtt": ["-DADV_NO_STAGE", "-DADV_NO_GATHER", "-DADV_NO_TABLES", "-DADV_NO_TRIG"]}
+if os.environ.get("ADV_VARIANTS"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ADV_VARIANTS"].split(",")}
 
 
 def build():
@@ -60,7 +67,7 @@ def main():
         return L.paradis_sl_advect_bwd(p(go), p(f), p(u), p(v), p(gf), p(guv[:, :K]), p(guv[:, K:]), p(sl), p(cl),
                                        p(lo), B, K, H, W, P, P, 2 * P, P, 2 * P, 0.196887, geom.min_lat,
                                        geom.min_lon, geom.d_lat, geom.d_lon, 2, p(ws), st)
-    for scale in (1.0, "smooth"):
+    for scale in (1.0,):
         if scale == "smooth":   # spatially smooth velocity: neighbouring points are displaced alike
             yy = torch.linspace(0, 6.28, H, device="cuda").view(1, 1, H, 1)
             xx = torch.linspace(0, 6.28, W, device="cuda").view(1, 1, 1, W)
@@ -69,18 +76,20 @@ def main():
         else:
             vel.normal_().mul_(scale)
         for kind, fn in (("fwd", fwd), ("bwd", bwd)):
-            for rnd in range(2):
+            best = {name: 1e9 for name in libs}
+            for rnd in range(5):   # interleaved rounds, best-of: box clocks drift by a few percent
                 for name, L in libs.items():
                     assert fn(L) == 0
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(5):
+                    for _ in range(20):
                         fn(L)
                     e1.record()
                     torch.cuda.synchronize()
-                    if rnd == 1:
-                        print(f"vel_scale={scale} {kind} {name:10s} {e0.elapsed_time(e1) / 5 * 1e3:9.1f} us")
+                    best[name] = min(best[name], e0.elapsed_time(e1) / 20 * 1e3)
+            for name in libs:
+                print(f"vel_scale={scale} {kind} {name:12s} {best[name]:9.1f} us")
 
 
 if __name__ == "__main__":
