@@ -34,7 +34,7 @@
 #pragma clang fp contract(off)
 
 // Diagnostic ablation switches (tools/advect_variants.py builds side libraries with them; the
-// shipped library defines none):  ADV_NO_ATOMIC, ADV_NO_TRIG, ADV_CW_SINCOS, ADV_IEEE_DIV, ADV_OCML_ATAN2
+// shipped library defines none):  ADV_NO_ATOMIC, ADV_NO_TRIG, ADV_OCML_SINCOS, ADV_NO_SMALL_ANGLE, ADV_IEEE_DIV, ADV_OCML_ATAN2, ...
 namespace {
 
 constexpr float TWO_PI_F = 6.283185307179586f;
@@ -48,7 +48,7 @@ constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule
 #define ADV_UNROLL_BWD 2
 #endif
 #ifndef ADV_PF
-#define ADV_PF 1   // prefetch distance (points) of the velocity loads in the forward kernel (2/4/8 measured slower)
+#define ADV_PF 2   // prefetch distance (points) of the operand loads in the whole-plane forward kernel
 #endif
 
 struct AdvGeom {
@@ -77,12 +77,16 @@ struct DepState {  // intermediates needed by the backward chain
   float sp, cp, sl, cl, s, n, d;
 };
 
-// sin and cos with a Cody-Waite reduction (fdlibm's float split of pi/2) and the cephes minimax
-// polynomials on [-pi/4, pi/4] (<= ~1 ulp); huge arguments take the ocml path.
+// sin and cos: cephes minimax polynomials on [-pi/4, pi/4] (<= ~1 ulp) behind a Cody-Waite reduction
+// (fdlibm's float split of pi/2); huge arguments take the ocml path.
+__device__ __forceinline__ void sincos_kernel(float r, float& ps, float& pc) {
+  const float z = r * r;
+  ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+            fmaf(-0.5f, z, 1.0f));
+}
+
 __device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
-#ifndef ADV_CW_SINCOS   // measured: the ocml routine is 5 % faster in the forward kernel than this one
-  sincosf(x, &s, &c);
-#else
   if (fabsf(x) > 8192.0f) {
     sincosf(x, &s, &c);
     return;
@@ -92,15 +96,32 @@ __device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
   r = fmaf(-k, 1.0804273188e-05f, r);
   r = fmaf(-k, 6.0770999344e-11f, r);
   const int q = (int)k;
-  const float z = r * r;
-  const float ps =
-      fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
-  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
-                        z * z, fmaf(-0.5f, z, 1.0f));
+  float ps, pc;
+  sincos_kernel(r, ps, pc);
   const float ss = (q & 1) ? pc : ps;
   const float cc = (q & 1) ? ps : pc;
   s = (q & 2) ? -ss : ss;
   c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// sin/cos of the two rotation angles of a point.  |angle| < 0.78 (< pi/4: the reduction's k is 0 and
+// r = x exactly) for every lane of the wave is the normal case - displacements of less than 45 degrees
+// per step - and needs no reduction and no quadrant selects: same bits, 9 instead of ~35
+// instructions per angle.
+__device__ __forceinline__ void sincos_pair(float phi, float lam, float& sp, float& cp, float& sl, float& cl) {
+#if defined(ADV_OCML_SINCOS)
+  sincosf(phi, &sp, &cp);
+  sincosf(lam, &sl, &cl);
+#else
+#ifndef ADV_NO_SMALL_ANGLE
+  if (__all(fabsf(phi) < 0.78f && fabsf(lam) < 0.78f)) {
+    sincos_kernel(phi, sp, cp);
+    sincos_kernel(lam, sl, cl);
+    return;
+  }
+#endif
+  sincos_fast(phi, sp, cp);
+  sincos_fast(lam, sl, cl);
 #endif
 }
 
@@ -153,8 +174,7 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
   const float lam = -u * g.dt;
   const float phi = -v * g.dt;
   float sp, cp, sl, cl;
-  sincos_fast(phi, sp, cp);
-  sincos_fast(lam, sl, cl);
+  sincos_pair(phi, lam, sp, cp, sl, cl);
   const float cc = cp * cl;
   const float s = sp * ca + cc * sa;
   const float sc = fminf(fmaxf(s, -CLAMP_HI), CLAMP_HI);
@@ -277,29 +297,30 @@ __device__ __forceinline__ void stage_window(float* win, const float* __restrict
     float val[STAGE_BATCH];
 #pragma unroll
     for (int j = 0; j < STAGE_BATCH; ++j) {
-      val[j] = 0.f;
+      // unconditional load from a clamped (always valid) source cell, then select: loads under
+      // per-lane conditions make the compiler wait for each one separately
       const int r = w.wy0 + it.yl;  // padded row
-      if (i0 + 256 * j < n && r >= 0 && r < Hp) {
-        const int ii = r - p;
-        int sr = ii;
-        bool mir = false;
-        if (ii < 0) { sr = -ii; mir = true; }
-        else if (ii >= H) { sr = 2 * (H - 1) - ii; mir = true; }
-        // periodic in longitude: with a window narrower than 1.5 W the offset lies in (-W, 3W)
-        int jj = w.wx0 + it.xl - p + (mir ? (W >> 1) : 0);
-        if (narrow) {
-          if (jj < 0) jj += W;
-          if (jj >= W) jj -= W;
-          if (jj >= W) jj -= W;
-        } else {
-          jj %= W;
-          if (jj < 0) jj += W;
-        }
-        float v = F[(int64_t)sr * W + jj];
-        if (subst && sr == 0) v = m0;
-        if (subst && sr == H - 1) v = m1;
-        val[j] = v;
+      const bool valid = r >= 0 && r < Hp;
+      const int ii = min(max(r, 0), Hp - 1) - p;
+      int sr = ii;
+      bool mir = false;
+      if (ii < 0) { sr = -ii; mir = true; }
+      else if (ii >= H) { sr = 2 * (H - 1) - ii; mir = true; }
+      sr = min(sr, H - 1);   // (rows of a partial last batch run past the window)
+      // periodic in longitude: with a window narrower than 1.5 W the offset lies in (-W, 3W)
+      int jj = w.wx0 + it.xl - p + (mir ? (W >> 1) : 0);
+      if (narrow) {
+        if (jj < 0) jj += W;
+        if (jj >= W) jj -= W;
+        if (jj >= W) jj -= W;
+      } else {
+        jj %= W;
+        if (jj < 0) jj += W;
       }
+      float v = F[(int64_t)sr * W + jj];
+      if (subst && sr == 0) v = m0;
+      if (subst && sr == H - 1) v = m1;
+      val[j] = valid ? v : 0.f;
       it.next();
     }
 #pragma unroll
@@ -323,28 +344,24 @@ __device__ __forceinline__ void stage_whole_vec4(float* win, const float* __rest
     float hv[HB];
     int hdst[HB];
 #pragma unroll
-    for (int j = 0; j < VB; ++j)
-      if (v0 + 256 * j < nvec) q[j] = F4[v0 + 256 * j];
+    for (int j = 0; j < VB; ++j) q[j] = F4[min(v0 + 256 * j, nvec - 1)];
 #pragma unroll
     for (int j = 0; j < HB; ++j) {
-      const int k = k0 + 256 * j;
-      hdst[j] = -1;
-      if (k < nhalo) {
-        int lr, lc;
-        if (k < nhalo_rows) {          // the p rows beyond each pole, full padded width
-          const int rr = k / Wp;
-          lc = k - rr * Wp;
-          lr = rr < p ? rr : Hp - 2 * p + rr;
-        } else {                       // left / right halo columns of the interior rows
-          const int e = k - nhalo_rows, rr = e / (2 * p), cc = e - rr * 2 * p;
-          lr = rr + p;
-          lc = cc < p ? cc : W + cc;
-        }
-        int sr, sc;
-        geo_src(lr - p, lc - p, H, W, sr, sc);
-        hv[j] = F[sr * W + sc];
-        hdst[j] = lr * Wp + lc;
+      const int kk = k0 + 256 * j, k = min(kk, nhalo - 1);   // clamped: the load is unconditional
+      int lr, lc;
+      if (k < nhalo_rows) {          // the p rows beyond each pole, full padded width
+        const int rr = k / Wp;
+        lc = k - rr * Wp;
+        lr = rr < p ? rr : Hp - 2 * p + rr;
+      } else {                       // left / right halo columns of the interior rows
+        const int e = k - nhalo_rows, rr = e / (2 * p), cc = e - rr * 2 * p;
+        lr = rr + p;
+        lc = cc < p ? cc : W + cc;
       }
+      int sr, sc;
+      geo_src(lr - p, lc - p, H, W, sr, sc);
+      hv[j] = F[sr * W + sc];
+      hdst[j] = kk < nhalo ? lr * Wp + lc : -1;
     }
 #pragma unroll
     for (int j = 0; j < VB; ++j) {
@@ -468,51 +485,60 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
     }
     return acc;
   };
-  {
-    // Operand prefetch: the velocities (the HBM streams) are loaded ADV_PF points ahead and the
-    // geometry tables (L2-resident) one point ahead, so that every wave keeps enough bytes in flight
-    // by itself; with loads issued at the point of use the kernel ran at ~60 % VALU issue with the
-    // waves parked on s_waitcnt 57 % of the time (PMC).
-    TileIter it(tid, tw), itp(tid, tw);
-    float qu[ADV_PF], qv[ADV_PF];
+  if constexpr (WHOLE) {
+    // Whole plane: the arrival index is the flat index.  Operands are prefetched ADV_PF points ahead
+    // into a queue whose slots are fixed registers (the loop is unrolled ADV_PF times) with
+    // unconditional, clamped loads: straight-line code lets the compiler count vmcnt exactly -
+    // with per-lane conditionals around the loads it emitted s_waitcnt vmcnt(0) every iteration,
+    // i.e. every point waited for the previous point's store to be acknowledged.
+    const int last = npts - 1;
+    float qu[ADV_PF], qv[ADV_PF], qs[ADV_PF], qc[ADV_PF], ql[ADV_PF];
 #pragma unroll
     for (int d = 0; d < ADV_PF; ++d) {
-      qu[d] = 0.f; qv[d] = 0.f;
-      if (tid + 256 * d < npts) {
-        const int idx = (ty0 + itp.yl) * W + tx0 + itp.xl;
-        qu[d] = U[idx]; qv[d] = V[idx];
-      }
-      itp.next();
+      const int j = min(tid + 256 * d, last);
+      qu[d] = U[j]; qv[d] = V[j]; qs[d] = sin_lat[j]; qc[d] = cos_lat[j]; ql[d] = lon[j];
     }
-    float nsa = 0.f, nca = 0.f, nlo = 0.f;
+    const int lastrow0 = (H - 1) * W;
+    for (int i0 = tid; i0 < npts; i0 += 256 * ADV_PF) {
+#pragma unroll
+      for (int d = 0; d < ADV_PF; ++d) {
+        const int i = i0 + 256 * d;
+        const float cu = qu[d], cv = qv[d], csa = qs[d], cca = qc[d], clo = ql[d];
+        {
+          const int j = min(i + 256 * ADV_PF, last);
+          qu[d] = U[j]; qv[d] = V[j];
+#ifndef ADV_NO_TABLES
+          qs[d] = sin_lat[j]; qc[d] = cos_lat[j]; ql[d] = lon[j];
+#endif
+        }
+        const float acc = point(cu, cv, csa, cca, clo);
+        if (i < npts) {
+          if (i < W || i >= lastrow0) {
+            if (rowwave) O[i] = wave_sum(acc) / (float)W;
+            else pole_out[i < W ? i : W + i - lastrow0] = acc;
+          } else {
+            O[i] = acc;
+          }
+        }
+      }
+    }
+  } else {
+    // tiled schedule: operands of point i+1 are loaded before point i is computed
+    TileIter it(tid, tw);
+    float nu = 0.f, nv = 0.f, nsa = 0.f, nca = 0.f, nlo = 0.f;
     if (tid < npts) {
       const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
-      nsa = sin_lat[idx]; nca = cos_lat[idx]; nlo = lon[idx];
+      nu = U[idx]; nv = V[idx]; nsa = sin_lat[idx]; nca = cos_lat[idx]; nlo = lon[idx];
     }
     for (int i = tid; i < npts; i += 256) {
-      const int y = ty0 + it.yl, x = tx0 + it.xl, idx = y * W + x;
-      const float cu = qu[0], cv = qv[0], csa = nsa, cca = nca, clo = nlo;
-#pragma unroll
-      for (int d = 0; d + 1 < ADV_PF; ++d) { qu[d] = qu[d + 1]; qv[d] = qv[d + 1]; }
-      if (i + 256 * ADV_PF < npts) {
-        const int pidx = (ty0 + itp.yl) * W + tx0 + itp.xl;
-        qu[ADV_PF - 1] = U[pidx]; qv[ADV_PF - 1] = V[pidx];
-      }
-      itp.next();
+      const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
+      const float cu = nu, cv = nv, csa = nsa, cca = nca, clo = nlo;
       it.next();
-#ifndef ADV_NO_TABLES
       if (i + 256 < npts) {
         const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
-        nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx];
+        nu = U[nidx]; nv = V[nidx]; nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx];
       }
-#endif
-      const float acc = point(cu, cv, csa, cca, clo);
-      if (WHOLE && (y == 0 || y == H - 1)) {
-        if (rowwave) O[idx] = wave_sum(acc) / (float)W;
-        else pole_out[(y == 0 ? 0 : W) + x] = acc;
-      } else {
-        O[idx] = acc;
-      }
+      O[idx] = point(cu, cv, csa, cca, clo);
     }
   }
   if (WHOLE && !rowwave) {

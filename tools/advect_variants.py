@@ -13,9 +13,9 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "paradis_model_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
 VARIANTS = {"base": [], "ieee_div": ["-DADV_IEEE_DIV"], "ocml_atan2": ["-DADV_OCML_ATAN2"],
-            "cw_sincos": ["-DADV_CW_SINCOS"], "no_atomic": ["-DADV_NO_ATOMIC"],
+            "ocml_sincos": ["-DADV_OCML_SINCOS"], "no_small": ["-DADV_NO_SMALL_ANGLE"], "no_atomic": ["-DADV_NO_ATOMIC"],
             "no_trig": ["-DADV_NO_TRIG"], "no_both": ["-DADV_NO_ATOMIC", "-DADV_NO_TRIG"],
-            "cvt_i64": ["-DADV_CVT_I64"], "pf2": ["-DADV_PF=2"], "pf4": ["-DADV_PF=4"], "no_stage": ["-DADV_NO_STAGE"],
+            "cvt_i64": ["-DADV_CVT_I64"], "pf1": ["-DADV_PF=1"], "pf3": ["-DADV_PF=3"], "pf4": ["-DADV_PF=4"], "no_stage": ["-DADV_NO_STAGE"],
             "no_gather": ["-DADV_NO_GATHER"], "no_tables": ["-DADV_NO_TABLES"],
             "no_sgt": ["-DADV_NO_STAGE", "-DADV_NO_GATHER", "-DADV_NO_TABLES"],
             "no_sgtt": ["-DADV_NO_STAGE", "-DADV_NO_GATHER", "-DADV_NO_TABLES", "-DADV_NO_TRIG"]}
@@ -27,9 +27,16 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     for name, flags in VARIANTS.items():
         so = os.path.join(OUT, f"libadv_{name}.so")
+        # a flag "src=<file>" builds the variant from another source file (A/B of two revisions);
+        # it is compiled from inside csrc/ so that its relative includes resolve
+        src = os.path.join(CSRC, "advect.hip")
+        for f in flags:
+            if f.startswith("src="):
+                src = os.path.join(ROOT, f[4:])
+        flags = [f for f in flags if not f.startswith("src=")]
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
-               "-munsafe-fp-atomics", "-ffp-contract=off", "-shared", *flags,
-               os.path.join(CSRC, "advect.hip"), os.path.join(CSRC, "error.hip"), "-o", so]
+               "-munsafe-fp-atomics", "-ffp-contract=off", "-shared", "-I", CSRC, *flags,
+               src, os.path.join(CSRC, "error.hip"), "-o", so]
         subprocess.run(cmd, check=True)
 
 
