@@ -44,6 +44,9 @@ SIGNATURES = {
     "paradis_upsample_lonp_fwd": (I, [P, P, L, I, I, I, I, P]),
     "paradis_upsample_lonp_bwd": (I, [P, P, L, I, I, I, I, P]),
     "paradis_pw_gemm_fwd": (I, [P, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
+    "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I]),
+    "paradis_forcings": (I, [P, P, P, I, I, I, I, I, P, I, ctypes.c_double, ctypes.c_double, P, P, P]),
+    "paradis_normalize_features": (I, [P, P, P, P, L, I, ctypes.c_float, I, P]),
     "paradis_global_bias_m8_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "paradis_global_bias_m8_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "paradis_global_bias_proj_bwd": (I, [P, P, P, P, P, I, I, L, P]),
@@ -112,14 +115,14 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def require_hip(*tensors) -> None:
+def require_hip(*tensors, any_dtype: bool = False) -> None:
     for t in tensors:
         if t is None:
             continue
         if not t.is_cuda:
             raise RuntimeError("paradis_model_amd ops run on the MI355X only: got a CPU tensor "
                                "(there is no CPU fallback; use oracle/ for CPU checks)")
-        if t.dtype != torch.float32:
+        if t.dtype != torch.float32 and not any_dtype:
             raise RuntimeError(f"paradis_model_amd ops are fp32; got {t.dtype}")
 
 

@@ -333,8 +333,11 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   const int C = C1 + C2;
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    hipMemsetAsync(gw, 0, C * sizeof(float), st);
-    hipMemsetAsync(gb, 0, C * sizeof(float), st);
+    if (hipMemsetAsync(gw, 0, C * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(gb, 0, C * sizeof(float), st) != hipSuccess) {
+      paradis_set_error("channel_norm_bwd: memset failed");
+      return 2;
+    }
     return 0;
   }
   CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};

@@ -44,13 +44,25 @@ def test_argument_validation_without_gpu():
                                    0.1, 0.0, 0.0, 1.0, 1.0, 3, None, None) == 1           # bad mode
     assert L.paradis_pw_gemm_fwd(None, None, None, None, None, None, None, 0, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None) == 1
     assert L.paradis_avgpool_geo_fwd(None, None, 1, 16, 32, 0, None) == 1      # stride < 1
+    # data feed (row f4): window longer than the series; unknown forcing code; no variables
+    import ctypes
+    codes = (ctypes.c_int * 2)(0, 9)
+    assert L.paradis_forcings(None, None, None, 0, 1, 8, 16, 2, codes, 2, 0.0, 1.0, None, None, None) == 1
+    assert L.paradis_forcings(None, None, None, 0, 3, 8, 16, 2, codes, 2, 0.0, 1.0, None, None, None) == 1
+    assert "workspace" in _lib.last_error() or "code" in _lib.last_error()
+    assert L.paradis_forcings(None, None, None, 0, 3, 8, 16, 2, codes, 0, 0.0, 1.0, None, None, None) == 1
+    assert L.paradis_forcings_ws_bytes(4) >= 4 * 15 * 8 + 4 * 49 * 4
+    assert L.paradis_normalize_features(None, None, None, None, 4, 0, 1e-12, 0, None) == 1
+    assert L.paradis_normalize_features(None, None, None, None, 0, 5, 1e-12, 0, None) == 0
     # zero-sized batches are accepted and do nothing
     assert L.paradis_geocyclic_pad_fwd(None, None, 0, 8, 8, 1, None) == 0
     assert L.paradis_sl_advect_ws_bytes(2, 3, 8, 16) >= 2 * 3 * 4 * 4
 
 
 def test_ops_refuse_cpu_tensors():
-    from paradis_model_amd import ops
+    from paradis_model_amd import feed, ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        feed.normalize_features_(torch.zeros(2, 3), [0, 0, 0], [0.0] * 3, [1.0] * 3)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.pointwise(torch.randn(1, 4, 8, 8), torch.randn(3, 4, 1, 1))
     with pytest.raises(RuntimeError):
