@@ -187,16 +187,17 @@ void paradis_debug_set_gemm_dma(int stages);
 void paradis_debug_set_wgrad_dma(int stages);
 
 /* ---- f4: data feed on the device --------------------------------------------------------------
- * Forcings of T consecutive timestamps as the dataset assembles them (reference
- * data/era5_dataset.py:587-621; data/forcings/time_vars.py:6-40; data/forcings/toa_radiation.py:38-199):
- * out[T-n+1, H, W, n_vars*n] float32, out[s,y,x, v*n+k] = forcing v at time s+k.
+ * Forcings of B series of T consecutive timestamps each, every series as the dataset assembles one
+ * sample (reference data/era5_dataset.py:587-621; data/forcings/time_vars.py:6-40;
+ * data/forcings/toa_radiation.py:38-199):
+ * out[B, T-n+1, H, W, n_vars*n] float32, out[b,s,y,x, v*n+k] = forcing v at time s+k of series b.
  * times_us: int64 microseconds since 1970-01-01 (numpy datetime64[us]); lat/lon in degrees (float64
  * storage; lat_is_f32 != 0 reproduces the float32 arithmetic numpy uses when the latitude array is
  * float32).  var_codes (HOST array): 0 toa_incident_solar_radiation (z-scored with toa_mean/std),
  * 1 sin_time_of_day, 2 cos_time_of_day, 3 sin_year_progress, 4 cos_year_progress. */
-size_t paradis_forcings_ws_bytes(int T);
-int paradis_forcings(const int64_t* times_us, const double* lat_deg, const double* lon_deg, int lat_is_f32,
-                     int T, int H, int W, int n_time_inputs, const int* var_codes, int n_vars,
+size_t paradis_forcings_ws_bytes(int B, int T);
+int paradis_forcings(const int64_t* times_us /* [B,T] */, const double* lat_deg, const double* lon_deg,
+                     int lat_is_f32, int B, int T, int H, int W, int n_time_inputs, const int* var_codes, int n_vars,
                      double toa_mean, double toa_std, float* out, void* workspace, void* stream);
 /* Channels-last feature (de)normalisation in place (reference utils/normalization.py:6-80 as applied by
  * data/era5_dataset.py:547-584): data[rows, C]; kind[c]: 0 none, 1 z-score (p0 mean, p1 std),

@@ -44,8 +44,8 @@ SIGNATURES = {
     "paradis_upsample_lonp_fwd": (I, [P, P, L, I, I, I, I, P]),
     "paradis_upsample_lonp_bwd": (I, [P, P, L, I, I, I, I, P]),
     "paradis_pw_gemm_fwd": (I, [P, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
-    "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I]),
-    "paradis_forcings": (I, [P, P, P, I, I, I, I, I, P, I, ctypes.c_double, ctypes.c_double, P, P, P]),
+    "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I, I]),
+    "paradis_forcings": (I, [P, P, P, I, I, I, I, I, I, P, I, ctypes.c_double, ctypes.c_double, P, P, P]),
     "paradis_normalize_features": (I, [P, P, P, P, L, I, ctypes.c_float, I, P]),
     "paradis_global_bias_m8_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "paradis_global_bias_m8_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P]),

@@ -108,18 +108,19 @@ struct ForcingVars {
   int code[8];   // 0 = toa radiation, 1..4 = sin/cos time of day, sin/cos year progress
 };
 
-// thread (t, y, x): TOA radiation of one cell at one time, scattered (with the temporal forcings of t)
-// to every window (s, k) with s + k = t:  out[s, y, x, v*n + k]
+// thread (b, t, y, x): TOA radiation of one cell at one time of series b, scattered (with the temporal
+// forcings of that time) to every window (s, k) with s + k = t:  out[b, s, y, x, v*n + k]
 __global__ void __launch_bounds__(256)
-forcings_kernel(const double* __restrict__ lat_deg, const double* __restrict__ lon_deg, int lat_f32, int T,
-                int H, int W, int n, ForcingVars fv, float toa_mean, float toa_std,
+forcings_kernel(const double* __restrict__ lat_deg, const double* __restrict__ lon_deg, int lat_f32, int B,
+                int T, int H, int W, int n, ForcingVars fv, float toa_mean, float toa_std,
                 const float* __restrict__ tf, const float* __restrict__ sc_f, const double* __restrict__ sc_w,
                 float* __restrict__ out) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t P = (int64_t)H * W;
-  if (gid >= (int64_t)T * P) return;
-  const int t = (int)(gid / P);
+  if (gid >= (int64_t)B * T * P) return;
+  const int t = (int)(gid / P);            // flat (series, time) index
   const int64_t cell = gid - (int64_t)t * P;
+  const int b = t / T, tl = t - b * T;     // windows never straddle two series
   const int y = (int)(cell / W), x = (int)(cell - (int64_t)y * W);
   bool need_toa = false;
   for (int v = 0; v < fv.n; ++v) need_toa |= fv.code[v] == 0;
@@ -144,9 +145,9 @@ forcings_kernel(const double* __restrict__ lat_deg, const double* __restrict__ l
   }
   const int steps = T - n + 1, C = fv.n * n;
   for (int k = 0; k < n; ++k) {
-    const int s = t - k;
+    const int s = tl - k;
     if (s < 0 || s >= steps) continue;
-    float* o = out + ((int64_t)s * P + cell) * C;
+    float* o = out + (((int64_t)b * steps + s) * P + cell) * C;
     for (int v = 0; v < fv.n; ++v) o[v * n + k] = fv.code[v] == 0 ? toa : tf[t * 4 + fv.code[v] - 1];
   }
 }
@@ -181,17 +182,19 @@ normalize_kernel(float* __restrict__ data, const int* __restrict__ kind, const f
 
 }  // namespace
 
-extern "C" size_t paradis_forcings_ws_bytes(int T) {
-  // [T*15] double weights, [T*15*3] float scalars, [T*4] float temporal forcings
-  return (size_t)T * 15 * sizeof(double) + (size_t)T * (15 * 3 + 4) * sizeof(float) + 256;
+extern "C" size_t paradis_forcings_ws_bytes(int B, int T) {
+  // per timestamp: [15] double weights, [15*3] float scalars, [4] float temporal forcings
+  const size_t n = (size_t)(B < 0 ? 0 : B) * (size_t)(T < 0 ? 0 : T);
+  return n * 15 * sizeof(double) + n * (15 * 3 + 4) * sizeof(float) + 256;
 }
 
 extern "C" int paradis_forcings(const int64_t* times_us, const double* lat_deg, const double* lon_deg,
-                                int lat_is_f32, int T, int H, int W, int n_time_inputs,
+                                int lat_is_f32, int B, int T, int H, int W, int n_time_inputs,
                                 const int* var_codes, int n_vars, double toa_mean, double toa_std,
                                 float* out, void* workspace, void* stream) {
-  PD_REQUIRE(T >= 1 && H >= 1 && W >= 1 && n_time_inputs >= 1 && n_time_inputs <= T,
-             "forcings: bad shape T=%d H=%d W=%d n_time_inputs=%d", T, H, W, n_time_inputs);
+  PD_REQUIRE(B >= 0 && T >= 1 && H >= 1 && W >= 1 && n_time_inputs >= 1 && n_time_inputs <= T,
+             "forcings: bad shape B=%d T=%d H=%d W=%d n_time_inputs=%d", B, T, H, W, n_time_inputs);
+  PD_REQUIRE((int64_t)B * T < (1 << 26), "forcings: too many timestamps");
   PD_REQUIRE(n_vars >= 1 && n_vars <= 8 && var_codes != nullptr, "forcings: 1..8 forcing variables");
   PD_REQUIRE(workspace != nullptr, "forcings: workspace required");
   ForcingVars fv{};
@@ -200,15 +203,17 @@ extern "C" int paradis_forcings(const int64_t* times_us, const double* lat_deg, 
     PD_REQUIRE(var_codes[v] >= 0 && var_codes[v] <= 4, "forcings: unknown variable code %d", var_codes[v]);
     fv.code[v] = var_codes[v];
   }
+  if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  const int TT = B * T;
   double* sc_w = (double*)workspace;
-  float* sc_f = (float*)(sc_w + (size_t)T * 15);
-  float* tf = sc_f + (size_t)T * 15 * 3;
-  hipLaunchKernelGGL(forcing_scalars_kernel, dim3((T * 16 + 63) / 64), dim3(64), 0, st, times_us, T, tf, sc_f, sc_w);
-  const int64_t total = (int64_t)T * H * W;
+  float* sc_f = (float*)(sc_w + (size_t)TT * 15);
+  float* tf = sc_f + (size_t)TT * 15 * 3;
+  hipLaunchKernelGGL(forcing_scalars_kernel, dim3((TT * 16 + 63) / 64), dim3(64), 0, st, times_us, TT, tf, sc_f, sc_w);
+  const int64_t total = (int64_t)TT * H * W;
   PD_REQUIRE((total + 255) / 256 < (1ll << 31), "forcings: too large");
   hipLaunchKernelGGL(forcings_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, lat_deg, lon_deg,
-                     lat_is_f32, T, H, W, n_time_inputs, fv, (float)toa_mean, (float)toa_std, (const float*)tf,
+                     lat_is_f32, B, T, H, W, n_time_inputs, fv, (float)toa_mean, (float)toa_std, (const float*)tf,
                      (const float*)sc_f, (const double*)sc_w, out);
   PD_CHECK_LAUNCH("forcings");
   return 0;

@@ -28,35 +28,43 @@ def times_to_us(times) -> torch.Tensor:
     return torch.from_numpy(np.asarray(times).astype("datetime64[us]").astype(np.int64))
 
 
+def _grid64(g, device):
+    t = g if isinstance(g, torch.Tensor) else torch.as_tensor(np.asarray(g))
+    return t.to(device=device, dtype=torch.float64).contiguous(), int(t.dtype == torch.float32)
+
+
 def compute_forcings(times, lat_deg, lon_deg, n_time_inputs: int, toa_mean: float, toa_std: float,
                      forcing_inputs: Sequence[str] = DEFAULT_FORCINGS, device="cuda") -> torch.Tensor:
     """``Era5Dataset._compute_forcings`` (reference data/era5_dataset.py:587-621) on the device.
 
-    times: T = steps + n_time_inputs - 1 consecutive timestamps (datetime64 array or int64 us tensor);
-    lat_deg [H], lon_deg [W]: 1-D grids in degrees (numpy or torch; a float32 latitude array keeps
-    numpy's float32 arithmetic).  Returns [steps, H, W, len(forcing_inputs) * n_time_inputs] float32;
-    names the reference does not know are skipped, as it does."""
+    times: T = steps + n_time_inputs - 1 consecutive timestamps (datetime64 array or int64 us tensor),
+    or a [B, T] stack of such series - one launch for a whole batch, each row treated as the dataset
+    treats one sample; lat_deg [H], lon_deg [W]: 1-D grids in degrees (numpy or torch, ideally already
+    on the device; a float32 latitude array keeps numpy's float32 arithmetic).
+    Returns [steps, H, W, len(forcing_inputs) * n_time_inputs] float32 (with a leading B for stacked
+    series); names the reference does not know are skipped, as it does."""
     codes = [FORCING_CODES[v] for v in forcing_inputs if v in FORCING_CODES]
     if not codes:
         return None
-    t_us = times_to_us(times).to(device)
-    lat = torch.as_tensor(np.asarray(lat_deg) if not isinstance(lat_deg, torch.Tensor) else lat_deg)
-    lon = torch.as_tensor(np.asarray(lon_deg) if not isinstance(lon_deg, torch.Tensor) else lon_deg)
-    lat_is_f32 = int(lat.dtype == torch.float32)
-    lat64, lon64 = lat.to(device=device, dtype=torch.float64).contiguous(), \
-        lon.to(device=device, dtype=torch.float64).contiguous()
+    t_us = times_to_us(times).to(device).contiguous()
+    batched = t_us.dim() == 2
+    if t_us.dim() not in (1, 2):
+        raise ValueError("times must be [T] or [B, T]")
+    B, T = (t_us.shape if batched else (1, t_us.numel()))
+    lat64, lat_is_f32 = _grid64(lat_deg, t_us.device)
+    lon64, _ = _grid64(lon_deg, t_us.device)
     require_hip(t_us, lat64, lon64, any_dtype=True)
-    T, H, W = t_us.numel(), lat64.numel(), lon64.numel()
+    H, W = lat64.numel(), lon64.numel()
     steps = T - n_time_inputs + 1
     if steps < 1:
         raise ValueError(f"need at least n_time_inputs={n_time_inputs} timestamps, got {T}")
-    out = torch.empty(steps, H, W, len(codes) * n_time_inputs, dtype=torch.float32, device=t_us.device)
-    ws = torch.empty(lib.paradis_forcings_ws_bytes(T), dtype=torch.uint8, device=t_us.device)
+    out = torch.empty(B, steps, H, W, len(codes) * n_time_inputs, dtype=torch.float32, device=t_us.device)
+    ws = torch.empty(lib.paradis_forcings_ws_bytes(B, T), dtype=torch.uint8, device=t_us.device)
     arr = (ctypes.c_int * len(codes))(*codes)
-    check(lib.paradis_forcings(dptr(t_us), dptr(lat64), dptr(lon64), lat_is_f32, T, H, W, n_time_inputs, arr,
+    check(lib.paradis_forcings(dptr(t_us), dptr(lat64), dptr(lon64), lat_is_f32, B, T, H, W, n_time_inputs, arr,
                                len(codes), float(toa_mean), float(toa_std), dptr(out), dptr(ws), stream_ptr()),
           "forcings")
-    return out
+    return out if batched else out[0]
 
 
 def normalize_features_(data: torch.Tensor, kind, p0, p1, eps_q: float = 1e-12, inverse: bool = False):

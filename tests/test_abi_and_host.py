@@ -47,11 +47,11 @@ def test_argument_validation_without_gpu():
     # data feed (row f4): window longer than the series; unknown forcing code; no variables
     import ctypes
     codes = (ctypes.c_int * 2)(0, 9)
-    assert L.paradis_forcings(None, None, None, 0, 1, 8, 16, 2, codes, 2, 0.0, 1.0, None, None, None) == 1
-    assert L.paradis_forcings(None, None, None, 0, 3, 8, 16, 2, codes, 2, 0.0, 1.0, None, None, None) == 1
+    assert L.paradis_forcings(None, None, None, 0, 1, 1, 8, 16, 2, codes, 2, 0.0, 1.0, None, None, None) == 1
+    assert L.paradis_forcings(None, None, None, 0, 1, 3, 8, 16, 2, codes, 2, 0.0, 1.0, None, None, None) == 1
     assert "workspace" in _lib.last_error() or "code" in _lib.last_error()
-    assert L.paradis_forcings(None, None, None, 0, 3, 8, 16, 2, codes, 0, 0.0, 1.0, None, None, None) == 1
-    assert L.paradis_forcings_ws_bytes(4) >= 4 * 15 * 8 + 4 * 49 * 4
+    assert L.paradis_forcings(None, None, None, 0, 1, 3, 8, 16, 2, codes, 0, 0.0, 1.0, None, None, None) == 1
+    assert L.paradis_forcings_ws_bytes(2, 4) >= 8 * 15 * 8 + 8 * 49 * 4
     assert L.paradis_normalize_features(None, None, None, None, 4, 0, 1e-12, 0, None) == 1
     assert L.paradis_normalize_features(None, None, None, None, 0, 5, 1e-12, 0, None) == 0
     # zero-sized batches are accepted and do nothing

@@ -55,6 +55,13 @@ def test_forcings_vs_oracle_normalised_and_subset():
     assert max_rel(got[..., 0], want[..., 0]) <= 1e-5
     with pytest.raises(ValueError):
         feed.compute_forcings(t[:1], lat, lon, 2, 0.0, 1.0)
+    # a [B,T] stack in one launch == the per-series results (windows do not straddle series)
+    stack = np.stack([times[0] + np.arange(4) * np.timedelta64(h, "h") for h in (6, 1, 24)])
+    got = feed.compute_forcings(stack, torch.from_numpy(lat).cuda(), torch.from_numpy(lon).cuda(), 2, 10.0, 20.0)
+    assert got.shape == (3, 3, len(lat), len(lon), 10)
+    for b in range(3):
+        one = feed.compute_forcings(stack[b], lat, lon, 2, 10.0, 20.0)
+        assert torch.equal(got[b], one)
 
 
 def test_normalise_features_vs_reference_golden():
