@@ -180,7 +180,8 @@ int paradis_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, 
  * gemm  : k-tile depth (16|32) and workgroups per CU (1..4) of the register-staged kernel; start-up
  *         stagger; LDS-DMA ring depth for fwd/dgrad (0 = off, 2..4) and for wgrad (0 = off, 2..3) */
 void paradis_debug_set_advect_gmem(int on);
-void paradis_debug_set_advect_halo(int halo);
+void paradis_debug_set_advect_halo(int halo);            /* both directions */
+void paradis_debug_set_advect_halos(int fwd, int bwd);   /* -1 = default */
 void paradis_debug_set_gemm(int bk, int wg_per_cu);
 void paradis_debug_set_gemm_stagger(int units);
 void paradis_debug_set_gemm_dma(int stages);

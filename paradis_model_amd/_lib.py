@@ -75,6 +75,7 @@ SIGNATURES = {
     "paradis_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, P]),
     "paradis_debug_set_advect_gmem": (None, [I]),
     "paradis_debug_set_advect_halo": (None, [I]),
+    "paradis_debug_set_advect_halos": (None, [I, I]),
     "paradis_debug_set_gemm": (None, [I, I]),
     "paradis_debug_set_gemm_stagger": (None, [I]),
     "paradis_debug_set_gemm_dma": (None, [I]),

@@ -41,6 +41,11 @@ constexpr float TWO_PI_F = 6.283185307179586f;
 constexpr float CLAMP_HI = 0.9999999f;  // float(1 - 1e-7), as torch.clamp converts its python bound
 constexpr float KA = -0.75f;
 constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule
+// threads per tile in the tiled schedule: the window fixes the LDS per workgroup, so waves per SIMD
+// come from the workgroup size.  Backward (12 B/cell, 2 workgroups per CU): at 256 threads it ran 1.7
+// waves per SIMD at 29 % VALU issue, 512 threads measured 6.9 -> 5.6 ms at 128x256; the forward
+// (4 B/cell) has the occupancy already and is 5-10 % faster with 256.
+constexpr int TILED_THREADS_FWD = 256, TILED_THREADS_BWD = 512;
 #ifndef ADV_UNROLL
 #define ADV_UNROLL 4
 #endif
@@ -273,8 +278,8 @@ struct Window {
 // iterate i = tid, tid+256, ... < th*tw as (yl, xl) without a division per point
 struct TileIter {
   int yl, xl, dy, dx, tw;
-  __device__ __forceinline__ TileIter(int tid, int tw_) : tw(tw_) {
-    yl = tid / tw_; xl = tid - yl * tw_; dy = 256 / tw_; dx = 256 - dy * tw_;
+  __device__ __forceinline__ TileIter(int tid, int tw_, int nth = 256) : tw(tw_) {
+    yl = tid / tw_; xl = tid - yl * tw_; dy = nth / tw_; dx = nth - dy * tw_;
   }
   __device__ __forceinline__ void next() {
     yl += dy; xl += dx;
@@ -287,45 +292,49 @@ struct TileIter {
 // Flat over the window in batches: all loads of a batch are issued before the first LDS write, so a
 // workgroup pays ~one memory round trip for its window.  (A row-per-wave loop serialised one round
 // trip per row - 9 per wave at 32x64 - and cost 23 % of the forward kernel.)
-constexpr int STAGE_BATCH = 10;
+constexpr int STAGE_BATCH = 6;
 __device__ __forceinline__ void stage_window(float* win, const float* __restrict__ F, const Window& w,
-                                             int H, int W, int p, bool subst, float m0, float m1) {
-  const int Hp = H + 2 * p, n = w.WH * w.WW;
-  const bool narrow = 2 * w.WW < 3 * W && W > 16;
-  TileIter it(threadIdx.x, w.WW);
-  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * STAGE_BATCH) {
-    float val[STAGE_BATCH];
+                                             int H, int W, int p, bool subst, float m0, float m1,
+                                             int nth = 256) {
+  // A thread keeps one window column (its longitude wrap - plain and mirrored - is computed once) and
+  // walks down the rows; only the cheap row map (mirror beyond a pole) is per element.  A flat
+  // element-per-thread assignment paid the full index map (~50 VALU) for each of the 2.6x more window
+  // cells than arrival points: 1 of the 2.1 ms of the tiled forward at 128x256.
+  const int Hp = H + 2 * p;
+  const int tid = threadIdx.x;
+  const int cols = w.WW < nth ? w.WW : nth;          // window columns per pass
+  const int rpp = nth / cols;                         // window rows per pass
+  const int r0 = tid / cols, c0 = tid - r0 * cols;
+  if (r0 >= rpp) return;
+  for (int lc = c0; lc < w.WW; lc += cols) {
+    int jj = (w.wx0 + lc - p) % W;
+    if (jj < 0) jj += W;
+    int jm = jj + (W >> 1);
+    if (jm >= W) jm -= W;
+    for (int l0 = r0; l0 < w.WH; l0 += rpp * STAGE_BATCH) {
+      float val[STAGE_BATCH];
 #pragma unroll
-    for (int j = 0; j < STAGE_BATCH; ++j) {
-      // unconditional load from a clamped (always valid) source cell, then select: loads under
-      // per-lane conditions make the compiler wait for each one separately
-      const int r = w.wy0 + it.yl;  // padded row
-      const bool valid = r >= 0 && r < Hp;
-      const int ii = min(max(r, 0), Hp - 1) - p;
-      int sr = ii;
-      bool mir = false;
-      if (ii < 0) { sr = -ii; mir = true; }
-      else if (ii >= H) { sr = 2 * (H - 1) - ii; mir = true; }
-      sr = min(sr, H - 1);   // (rows of a partial last batch run past the window)
-      // periodic in longitude: with a window narrower than 1.5 W the offset lies in (-W, 3W)
-      int jj = w.wx0 + it.xl - p + (mir ? (W >> 1) : 0);
-      if (narrow) {
-        if (jj < 0) jj += W;
-        if (jj >= W) jj -= W;
-        if (jj >= W) jj -= W;
-      } else {
-        jj %= W;
-        if (jj < 0) jj += W;
+      for (int j = 0; j < STAGE_BATCH; ++j) {
+        // unconditional load from a clamped (always valid) source cell, then select
+        const int lr = l0 + rpp * j;
+        const int r = w.wy0 + lr;                      // padded row
+        const bool valid = lr < w.WH && r >= 0 && r < Hp;
+        const int ii = min(max(r, 0), Hp - 1) - p;
+        int sr = ii;
+        bool mir = false;
+        if (ii < 0) { sr = -ii; mir = true; }
+        else if (ii >= H) { sr = 2 * (H - 1) - ii; mir = true; }
+        float v = F[(int64_t)sr * W + (mir ? jm : jj)];
+        if (subst && sr == 0) v = m0;
+        if (subst && sr == H - 1) v = m1;
+        val[j] = valid ? v : 0.f;
       }
-      float v = F[(int64_t)sr * W + jj];
-      if (subst && sr == 0) v = m0;
-      if (subst && sr == H - 1) v = m1;
-      val[j] = valid ? v : 0.f;
-      it.next();
-    }
 #pragma unroll
-    for (int j = 0; j < STAGE_BATCH; ++j)
-      if (i0 + 256 * j < n) win[i0 + 256 * j] = val[j];
+      for (int j = 0; j < STAGE_BATCH; ++j) {
+        const int lr = l0 + rpp * j;
+        if (lr < w.WH) win[lr * w.WW + lc] = val[j];
+      }
+    }
   }
 }
 
@@ -382,8 +391,8 @@ __device__ __forceinline__ void stage_whole_vec4(float* win, const float* __rest
 // ======================================================================================
 // forward
 // ======================================================================================
-template <int MODE, bool WHOLE>
-__global__ void __launch_bounds__(256)
+template <int MODE, bool WHOLE, int NTH>
+__global__ void __launch_bounds__(NTH)
 sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ u,
                      const float* __restrict__ v, float* __restrict__ out,
                      const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
@@ -414,7 +423,7 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
   if (!WHOLE) { m0 = fmeans[2 * plane]; m1 = fmeans[2 * plane + 1]; }
 #ifndef ADV_NO_STAGE
   if (WHOLE && vec4) stage_whole_vec4(win, F, H, W, p);
-  else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1);
+  else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1, NTH);
 #endif
   __syncthreads();
   if (WHOLE) {
@@ -495,17 +504,17 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
     float qu[ADV_PF], qv[ADV_PF], qs[ADV_PF], qc[ADV_PF], ql[ADV_PF];
 #pragma unroll
     for (int d = 0; d < ADV_PF; ++d) {
-      const int j = min(tid + 256 * d, last);
+      const int j = min(tid + NTH * d, last);
       qu[d] = U[j]; qv[d] = V[j]; qs[d] = sin_lat[j]; qc[d] = cos_lat[j]; ql[d] = lon[j];
     }
     const int lastrow0 = (H - 1) * W;
-    for (int i0 = tid; i0 < npts; i0 += 256 * ADV_PF) {
+    for (int i0 = tid; i0 < npts; i0 += NTH * ADV_PF) {
 #pragma unroll
       for (int d = 0; d < ADV_PF; ++d) {
-        const int i = i0 + 256 * d;
+        const int i = i0 + NTH * d;
         const float cu = qu[d], cv = qv[d], csa = qs[d], cca = qc[d], clo = ql[d];
         {
-          const int j = min(i + 256 * ADV_PF, last);
+          const int j = min(i + NTH * ADV_PF, last);
           qu[d] = U[j]; qv[d] = V[j];
 #ifndef ADV_NO_TABLES
           qs[d] = sin_lat[j]; qc[d] = cos_lat[j]; ql[d] = lon[j];
@@ -524,17 +533,17 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
     }
   } else {
     // tiled schedule: operands of point i+1 are loaded before point i is computed
-    TileIter it(tid, tw);
+    TileIter it(tid, tw, NTH);
     float nu = 0.f, nv = 0.f, nsa = 0.f, nca = 0.f, nlo = 0.f;
     if (tid < npts) {
       const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
       nu = U[idx]; nv = V[idx]; nsa = sin_lat[idx]; nca = cos_lat[idx]; nlo = lon[idx];
     }
-    for (int i = tid; i < npts; i += 256) {
+    for (int i = tid; i < npts; i += NTH) {
       const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
       const float cu = nu, cv = nv, csa = nsa, cca = nca, clo = nlo;
       it.next();
-      if (i + 256 < npts) {
+      if (i + NTH < npts) {
         const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
         nu = U[nidx]; nv = V[nidx]; nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx];
       }
@@ -607,8 +616,8 @@ __device__ __forceinline__ void departure_backward(const DepState& st, float sa,
   gv = -dt * gphi;
 }
 
-template <int MODE, bool WHOLE>
-__global__ void __launch_bounds__(256)
+template <int MODE, bool WHOLE, int NTH>
+__global__ void __launch_bounds__(NTH)
 sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ field,
                      const float* __restrict__ u, const float* __restrict__ v,
                      float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
@@ -640,7 +649,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
   const int wn = w.WH * w.WW, wn2 = (wn + 1) & ~1;
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);  // [wn] fixed-point sums
   float* win = smem + 2 * wn2;                                             // [wn]  F~ window
-  float* misc = win + wn2;   // [0..1] pole means of gout, [2..5] per-wave max |cotangent|
+  float* misc = win + wn2;   // [0..1] pole means of gout, [2..2+NTH/64) per-wave max |cotangent|
 
   float m0 = 0.f, m1 = 0.f, gm0 = 0.f, gm1 = 0.f;
   if (!WHOLE) {
@@ -648,14 +657,14 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     gm0 = gmeans[2 * plane]; gm1 = gmeans[2 * plane + 1];
   }
   if (WHOLE && vec4) stage_whole_vec4(win, F, H, W, p);
-  else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1);
-  for (int i = tid; i < wn; i += 256) acc[i] = 0ull;
+  else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1, NTH);
+  for (int i = tid; i < wn; i += NTH) acc[i] = 0ull;
   // max |cotangent| over this workgroup's arrival points -> fixed-point scale
   const int npts = th * tw;
   float gmax = WHOLE ? 0.f : fmaxf(fabsf(gm0), fabsf(gm1));
   {
-    TileIter itg(tid, tw);
-    for (int i = tid; i < npts; i += 256, itg.next())
+    TileIter itg(tid, tw, NTH);
+    for (int i = tid; i < npts; i += NTH, itg.next())
       gmax = fmaxf(gmax, fabsf(GO[(ty0 + itg.yl) * W + tx0 + itg.xl]));
   }
 #pragma unroll
@@ -677,22 +686,25 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     gm0 = misc[0]; gm1 = misc[1];
   }
   float scale, inv_scale;   // every thread derives the same power-of-two scale
-  fixed_point_scale(fmaxf(fmaxf(misc[2], misc[3]), fmaxf(misc[4], misc[5])), scale, inv_scale);
+  float mxall = misc[2];
+#pragma unroll
+  for (int q = 1; q < NTH / 64; ++q) mxall = fmaxf(mxall, misc[2 + q]);
+  fixed_point_scale(mxall, scale, inv_scale);
   const bool rowwave = WHOLE && W == 64;
 
   const float kx = ((float)W - 1.0f) / g.d_lon, ky = ((float)H - 1.0f) / g.d_lat;
-  TileIter it(tid, tw);
+  TileIter it(tid, tw, NTH);
   // operands of point i+1 are in flight while point i is computed (see the forward kernel)
   float nu = 0.f, nv = 0.f, nsa = 0.f, nca = 0.f, nlo = 0.f, ngo = 0.f;
   if (tid < npts) {
     const int idx = (ty0 + it.yl) * W + tx0 + it.xl;
     nu = U[idx]; nv = V[idx]; nsa = sin_lat[idx]; nca = cos_lat[idx]; nlo = lon[idx]; ngo = GO[idx];
   }
-  for (int i = tid; i < npts; i += 256) {
+  for (int i = tid; i < npts; i += NTH) {
     const int y = ty0 + it.yl, x = tx0 + it.xl, idx = y * W + x;
     const float cu = nu, cv = nv, sa = nsa, ca = nca, clo = nlo, cgo = ngo;
     it.next();
-    if (i + 256 < npts) {
+    if (i + NTH < npts) {
       const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
       nu = U[nidx]; nv = V[nidx]; nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx]; ngo = GO[nidx];
     }
@@ -770,7 +782,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
   if (WHOLE) {
     // fold the halo back: every source cell sums its aliases (adjoint of the a1 map), then the
     // adjoint of the first pole mean (rows 0, H-1 <- their mean)
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += NTH) {
       const int y = i / W, x = i - y * W;
       long long s = 0;
       geo_for_each_alias(y, x, H, W, p, [&](int ii, int jj) { s += (long long)acc[(ii + p) * Wp + jj + p]; });
@@ -790,11 +802,13 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
         for (int x = tid & 63; x < W; x += 64) row[x] = m;
       }
       __syncthreads();
-      for (int i = tid; i < P; i += 256) GF[i] = win[i];
+      for (int i = tid; i < P; i += NTH) GF[i] = win[i];
     }
   } else {
     // flush the window once: one global float atomic per touched cell instead of 16 per point
-    for (int i = tid; i < wn; i += 256) {
+    // (consecutive lanes -> consecutive cells: the 16 atomics per 64-byte line of one wave-instruction
+    //  are combined by the memory pipeline; spreading them over 64 lines measured 2x slower)
+    for (int i = tid; i < wn; i += NTH) {
       const long long s = (long long)acc[i];
       if (s == 0) continue;
       const int lr = i / w.WW, lc = i - lr * w.WW;
@@ -853,7 +867,23 @@ AdvGeom make_geom(int H, int W, int p, float dt, float min_lat, float min_lon, f
 
 constexpr size_t WHOLE_LDS_LIMIT = 64 * 1024;
 int g_force_tiled = -1;   // debug: -1 auto, 0/1 force
-int g_halo = 6;           // window halo (padded cells) of the tiled schedule
+// window halos (padded cells) of the tiled schedule.  Forward windows are cheap (4 B/cell); the
+// backward holds 12 B/cell (64-bit accumulators + field), so its halo is what LDS allows at 2
+// workgroups per CU.  Taps outside the window take the L2 / global-atomic path.
+int g_halo = 8;           // forward (in-model optimum 6-12 at 128x256 and 721x1440; 24 pays only for ~45 px
+                          // displacements)
+int g_halo_bwd = 10;      // backward (two workgroups of 512 threads per CU)
+constexpr int MAX_HALO = 32;
+
+template <typename K>
+int reserve_lds(K kernel, const char* what) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024) != hipSuccess) {
+    paradis_set_error(what);
+    return 2;
+  }
+  return 0;
+}
 
 bool use_tiled(size_t whole_bytes) {
   if (g_force_tiled == 1) return true;
@@ -864,21 +894,27 @@ bool use_tiled(size_t whole_bytes) {
 
 // test/diagnostic hooks: force the tiled schedule regardless of plane size; set its halo
 extern "C" void paradis_debug_set_advect_gmem(int on) { g_force_tiled = on; }
-extern "C" void paradis_debug_set_advect_halo(int halo) { g_halo = halo < 0 ? 0 : (halo > 16 ? 16 : halo); }
+extern "C" void paradis_debug_set_advect_halo(int halo) {   // both directions (tests force tiny halos)
+  g_halo = g_halo_bwd = halo < 0 ? 0 : (halo > MAX_HALO ? MAX_HALO : halo);
+}
+extern "C" void paradis_debug_set_advect_halos(int fwd, int bwd) {
+  g_halo = fwd < 0 ? 8 : (fwd > MAX_HALO ? MAX_HALO : fwd);
+  g_halo_bwd = bwd < 0 ? 10 : (bwd > MAX_HALO ? MAX_HALO : bwd);
+}
 
 extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W) {
   (void)H; (void)W;
   return (size_t)B * K * 4 * sizeof(float) + 256;
 }
 
-#define ADV_LAUNCH(KERNEL, WHOLE_, grid, lds, ...)                                                  \
-  do {                                                                                              \
-    if (mode == PARADIS_INTERP_BICUBIC)                                                             \
-      hipLaunchKernelGGL((KERNEL<PARADIS_INTERP_BICUBIC, WHOLE_>), dim3(grid), dim3(256), lds, st,  \
-                         __VA_ARGS__);                                                              \
-    else                                                                                            \
-      hipLaunchKernelGGL((KERNEL<PARADIS_INTERP_BILINEAR, WHOLE_>), dim3(grid), dim3(256), lds, st, \
-                         __VA_ARGS__);                                                              \
+#define ADV_LAUNCH(KERNEL, WHOLE_, NTH_, grid, lds, ...)                                                  \
+  do {                                                                                                    \
+    if (mode == PARADIS_INTERP_BICUBIC)                                                                   \
+      hipLaunchKernelGGL((KERNEL<PARADIS_INTERP_BICUBIC, WHOLE_, NTH_>), dim3(grid), dim3(NTH_), lds, st,  \
+                         __VA_ARGS__);                                                                    \
+    else                                                                                                  \
+      hipLaunchKernelGGL((KERNEL<PARADIS_INTERP_BILINEAR, WHOLE_, NTH_>), dim3(grid), dim3(NTH_), lds, st, \
+                         __VA_ARGS__);                                                                    \
   } while (0)
 
 extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, float* out,
@@ -898,7 +934,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   // 16-byte staging path: aligned planes, p even (bicubic), padded width even
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && a16(field) && (p % 2 == 0);
   if (!use_tiled(whole)) {
-    ADV_LAUNCH(sl_advect_fwd_kernel, true, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
+    ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
                (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_fwd");
     return 0;
@@ -909,9 +945,18 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, field, fmeans, planes, K, H, W, f_bs);
   const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H, tiles = tx * ty;
   PD_REQUIRE((int64_t)planes * tiles < (1ll << 31), "sl_advect_fwd: too many tiles");
-  const size_t lds = (size_t)(TILE_H + 2 * g_halo + NT) * (TILE_W + 2 * g_halo + NT) * sizeof(float);
-  ADV_LAUNCH(sl_advect_fwd_kernel, false, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
-             cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, g_halo, tx, tiles, vec4);
+  const int halo = g_halo;
+  const size_t lds = (size_t)(TILE_H + 2 * halo + NT) * (TILE_W + 2 * halo + NT) * sizeof(float);
+  PD_REQUIRE(lds <= 160 * 1024, "sl_advect_fwd: window does not fit LDS");
+  static bool reserved = false;
+  if (!reserved) {
+    if (reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
+      return 2;
+    reserved = true;
+  }
+  ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
+             cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, out, planes, K, H, W, o_bs);
   PD_CHECK_LAUNCH("sl_advect_fwd(tiled)");
   return 0;
@@ -930,12 +975,12 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   AdvGeom g = make_geom(H, W, p, dt, min_lat, min_lon, d_lat, d_lon);
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * K, P = H * W;
-  auto lds_of = [](size_t cells) { return (3 * ((cells + 1) & ~(size_t)1) + 8) * sizeof(float); };
+  auto lds_of = [](size_t cells) { return (3 * ((cells + 1) & ~(size_t)1) + 24) * sizeof(float); };
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && (p % 2 == 0) &&
                    (reinterpret_cast<uintptr_t>(field) & 15) == 0;
   const size_t whole = lds_of((size_t)(H + 2 * p) * (W + 2 * p));
   if (!use_tiled(whole)) {
-    ADV_LAUNCH(sl_advect_bwd_kernel, true, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
+    ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
                cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
                gf_bs, guv_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_bwd");
@@ -954,10 +999,18 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   }
   const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H, tiles = tx * ty;
   PD_REQUIRE((int64_t)planes * tiles < (1ll << 31), "sl_advect_bwd: too many tiles");
-  const size_t lds = lds_of((size_t)(TILE_H + 2 * g_halo + NT) * (TILE_W + 2 * g_halo + NT));
-  ADV_LAUNCH(sl_advect_bwd_kernel, false, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
+  const size_t lds = lds_of((size_t)(TILE_H + 2 * g_halo_bwd + NT) * (TILE_W + 2 * g_halo_bwd + NT));
+  PD_REQUIRE(lds <= 160 * 1024, "sl_advect_bwd: window does not fit LDS");
+  static bool reserved = false;
+  if (!reserved) {
+    if (reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS"))
+      return 2;
+    reserved = true;
+  }
+  ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
              gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-             f_bs, uv_bs, gf_bs, guv_bs, g_halo, tx, tiles, vec4);
+             f_bs, uv_bs, gf_bs, guv_bs, g_halo_bwd, tx, tiles, vec4);
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");
   return 0;

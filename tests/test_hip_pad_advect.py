@@ -58,7 +58,7 @@ def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6):
         return y.detach().cpu(), fd.grad.cpu(), ud.grad.cpu(), vd.grad.cpu()
     finally:
         lib.paradis_debug_set_advect_gmem(-1)
-        lib.paradis_debug_set_advect_halo(6)
+        lib.paradis_debug_set_advect_halos(-1, -1)
 
 
 @pytest.mark.parametrize("force_gmem,halo", [(False, 6), (True, 6), (True, 0)])
