@@ -180,6 +180,8 @@ int paradis_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, 
  * gemm  : k-tile depth (16|32) and workgroups per CU (1..4) of the register-staged kernel; start-up
  *         stagger; LDS-DMA ring depth for fwd/dgrad (0 = off, 2..4) and for wgrad (0 = off, 2..3) */
 void paradis_debug_set_advect_gmem(int on);
+void paradis_debug_set_norm_bwd_reread(int on);          /* ChannelNorm backward: x re-read via L2 (1, default) or xhat in LDS (0) */
+void paradis_debug_set_norm_fwd_px(int px);              /* ChannelNorm forward: 32 (default) or 64 pixels per workgroup */
 void paradis_debug_set_advect_halo(int halo);            /* both directions */
 void paradis_debug_set_advect_halos(int fwd, int bwd);   /* -1 = default */
 void paradis_debug_set_gemm(int bk, int wg_per_cu);

@@ -338,56 +338,6 @@ __device__ __forceinline__ void stage_window(float* win, const float* __restrict
   }
 }
 
-// WHOLE schedule, 16-byte path: the H x W interior of the padded plane is a plain copy (one float4
-// load + two 8-byte LDS writes per four cells); only the 2p halo columns and 2p mirrored rows go
-// through the index map.  ~4 loads and ~60 VALU instructions per thread instead of 10 and ~300.
-// Needs W % 4 == 0 and a 16-byte aligned plane.
-__device__ __forceinline__ void stage_whole_vec4(float* win, const float* __restrict__ F, int H, int W, int p) {
-  const int Wp = W + 2 * p, Hp = H + 2 * p, tid = threadIdx.x;
-  const int w4 = W >> 2, nvec = H * w4;
-  const int nhalo_rows = 2 * p * Wp, nhalo = nhalo_rows + H * 2 * p;
-  constexpr int VB = 2, HB = 2;
-  const float4* F4 = reinterpret_cast<const float4*>(F);
-  for (int v0 = tid, k0 = tid; v0 < nvec || k0 < nhalo; v0 += 256 * VB, k0 += 256 * HB) {
-    float4 q[VB];
-    float hv[HB];
-    int hdst[HB];
-#pragma unroll
-    for (int j = 0; j < VB; ++j) q[j] = F4[min(v0 + 256 * j, nvec - 1)];
-#pragma unroll
-    for (int j = 0; j < HB; ++j) {
-      const int kk = k0 + 256 * j, k = min(kk, nhalo - 1);   // clamped: the load is unconditional
-      int lr, lc;
-      if (k < nhalo_rows) {          // the p rows beyond each pole, full padded width
-        const int rr = k / Wp;
-        lc = k - rr * Wp;
-        lr = rr < p ? rr : Hp - 2 * p + rr;
-      } else {                       // left / right halo columns of the interior rows
-        const int e = k - nhalo_rows, rr = e / (2 * p), cc = e - rr * 2 * p;
-        lr = rr + p;
-        lc = cc < p ? cc : W + cc;
-      }
-      int sr, sc;
-      geo_src(lr - p, lc - p, H, W, sr, sc);
-      hv[j] = F[sr * W + sc];
-      hdst[j] = kk < nhalo ? lr * Wp + lc : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < VB; ++j) {
-      const int v = v0 + 256 * j;
-      if (v < nvec) {
-        const int y = v / w4, x4 = v - y * w4;
-        float2* d = reinterpret_cast<float2*>(win + (y + p) * Wp + p + 4 * x4);   // 8-byte aligned (p even, Wp even)
-        d[0] = make_float2(q[j].x, q[j].y);
-        d[1] = make_float2(q[j].z, q[j].w);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < HB; ++j)
-      if (hdst[j] >= 0) win[hdst[j]] = hv[j];
-  }
-}
-
 // ======================================================================================
 // forward
 // ======================================================================================
@@ -422,7 +372,7 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
   float m0 = 0.f, m1 = 0.f;
   if (!WHOLE) { m0 = fmeans[2 * plane]; m1 = fmeans[2 * plane + 1]; }
 #ifndef ADV_NO_STAGE
-  if (WHOLE && vec4) stage_whole_vec4(win, F, H, W, p);
+  if (WHOLE && vec4) stage_plane_vec4(win, F, H, W, p);
   else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1, NTH);
 #endif
   __syncthreads();
@@ -656,7 +606,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     m0 = fmeans[2 * plane]; m1 = fmeans[2 * plane + 1];
     gm0 = gmeans[2 * plane]; gm1 = gmeans[2 * plane + 1];
   }
-  if (WHOLE && vec4) stage_whole_vec4(win, F, H, W, p);
+  if (WHOLE && vec4) stage_plane_vec4(win, F, H, W, p);
   else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1, NTH);
   for (int i = tid; i < wn; i += NTH) acc[i] = 0ull;
   // max |cotangent| over this workgroup's arrival points -> fixed-point scale

@@ -20,18 +20,22 @@ struct CatSrc {
   }
 };
 
-// 1024 threads = 16 waves; wave g owns channels c = g + 16*i.  MAXV values per thread are kept
-// in registers so x is read from HBM exactly once (MAXV = 0: three passes, any C).
-template <int MAXV>
+// 1024 threads = NPXF pixels x G = 1024/NPXF channel groups; group g owns channels c = g + G*i.
+// MAXV values per thread stay in registers so x is read from HBM exactly once (MAXV = 0: three
+// passes, any C).  NPXF = 32 (128-byte row segments, 36 values per thread, ~64 VGPRs) keeps two
+// workgroups per CU so that one loads while the other stores; with 64 pixels x 72 values only one
+// 1024-thread workgroup fits and its load / reduce / store phases run back to back (2.7 TB/s).
+template <int MAXV, int NPXF>
 __global__ void __launch_bounds__(1024)
 channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
                         float* __restrict__ y, float* __restrict__ mean_out,
                         float* __restrict__ rstd_out, int P, int tiles, float eps) {
-  __shared__ float red[16][NPX];
-  __shared__ float stat[2][NPX];
+  constexpr int G = 1024 / NPXF;
+  __shared__ float red[G][NPXF];
+  __shared__ float stat[2][NPXF];
   const int C = s.C1 + s.C2;
-  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPX;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPXF;
+  const int lane = threadIdx.x % NPXF, grp = threadIdx.x / NPXF;
   const int p = p0 + lane;
   const bool live = p < P;
   float vals[MAXV > 0 ? MAXV : 1];
@@ -40,19 +44,19 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   if (MAXV > 0) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = grp + 16 * i;
+      const int c = grp + G * i;
       vals[i] = (live && c < C) ? s.row(b, c, P)[p] : 0.f;
       sum += vals[i];
     }
   } else {
-    for (int c = grp; c < C; c += 16) sum += live ? s.row(b, c, P)[p] : 0.f;
+    for (int c = grp; c < C; c += G) sum += live ? s.row(b, c, P)[p] : 0.f;
   }
   red[grp][lane] = sum;
   __syncthreads();
   if (grp == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    for (int k = 0; k < G; ++k) t += red[k][lane];
     stat[0][lane] = t / (float)C;
   }
   __syncthreads();
@@ -61,12 +65,12 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   if (MAXV > 0) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = grp + 16 * i;
+      const int c = grp + G * i;
       const float d = (c < C) ? vals[i] - mean : 0.f;
       sq += d * d;
     }
   } else {
-    for (int c = grp; c < C; c += 16) {
+    for (int c = grp; c < C; c += G) {
       const float d = live ? s.row(b, c, P)[p] - mean : 0.f;
       sq += d * d;
     }
@@ -77,7 +81,7 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   if (grp == 0) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    for (int k = 0; k < G; ++k) t += red[k][lane];
     const float var = t / (float)(C - 1);
     const float r = 1.0f / sqrtf(var + eps);
     stat[1][lane] = r;
@@ -93,11 +97,11 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   if (MAXV > 0) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = grp + 16 * i;
+      const int c = grp + G * i;
       if (c < C) yb[(int64_t)c * P] = (vals[i] - mean) * rstd * w[c] + bias[c];
     }
   } else {
-    for (int c = grp; c < C; c += 16)
+    for (int c = grp; c < C; c += G)
       yb[(int64_t)c * P] = (s.row(b, c, P)[p] - mean) * rstd * w[c] + bias[c];
   }
 }
@@ -264,6 +268,88 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
   }
 }
 
+// Same work with nothing parked between the two phases: gy and x are streamed twice, the second time
+// a few microseconds after the first (the tile is 32 px x C x 8 B = 295 KiB: served by L2 / the
+// Infinity Cache, HBM traffic unchanged).  512 threads = 32 pixels x 16 channel groups, 4 KiB of LDS,
+// ~40 VGPRs: four workgroups share a CU, so loads, reductions and stores of different tiles overlap
+// (the register/LDS-resident version fits one workgroup per CU and runs its phases back to back).
+__global__ void __launch_bounds__(512)
+channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
+                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                               float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
+                               int64_t gbs2, float* __restrict__ partial, int P, int tiles) {
+  constexpr int NPB = 32, G = 16;
+  __shared__ float red[2][G][NPB];
+  const int C = s.C1 + s.C2;
+  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPB;
+  const int px = threadIdx.x % NPB, grp = threadIdx.x / NPB;
+  const int p = min(p0 + px, P - 1);          // clamped: loads are unconditional, stores predicated
+  const bool live = p0 + px < P;
+  const float mean = mean_in[(int64_t)b * P + p];
+  const float rstd = rstd_in[(int64_t)b * P + p];
+  const float* gyb = gy + (int64_t)b * C * P + p;
+  float s1 = 0.f, s2 = 0.f;
+  constexpr int U = 6;   // channels per batch: 2*U loads in flight per thread, issued before their use
+  for (int c0 = grp; c0 < C; c0 += G * U) {
+    float gv[U], xv[U], wv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int c = min(c0 + G * j, C - 1);
+      gv[j] = gyb[(int64_t)c * P];
+      xv[j] = s.row(b, c, P)[p];
+      wv[j] = c0 + G * j < C ? w[c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const float gh = gv[j] * wv[j];
+      s1 += gh;
+      s2 += gh * ((xv[j] - mean) * rstd);
+    }
+  }
+  red[0][grp][px] = live ? s1 : 0.f;
+  red[1][grp][px] = live ? s2 : 0.f;
+  __syncthreads();
+  if (grp < 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) t += red[grp][k][px];
+    red[grp][0][px] = t;
+  }
+  __syncthreads();
+  const float m1 = red[0][0][px] / (float)C, m2 = red[1][0][px] / (float)(C - 1);
+  float* pw = partial + (int64_t)blockIdx.x * 2 * C;
+  for (int c0 = grp; c0 < C; c0 += G * U) {
+    float gv[U], xv[U], wv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int c = min(c0 + G * j, C - 1);
+      gv[j] = gyb[(int64_t)c * P];
+      xv[j] = s.row(b, c, P)[p];
+      wv[j] = w[c];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int c = c0 + G * j;
+      if (c < C) {
+        const float g = live ? gv[j] : 0.f;     // dead pixels contribute zeros
+        const float xh = (xv[j] - mean) * rstd;
+        if (live) {
+          const float v = rstd * (g * wv[j] - m1 - xh * m2);
+          if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v;
+          else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
+        }
+        float a = g * xh, d = g;
+#pragma unroll
+        for (int o = NPB / 2; o > 0; o >>= 1) {
+          a += __shfl_xor(a, o, NPB);
+          d += __shfl_xor(d, o, NPB);
+        }
+        if (px == 0) { pw[c] = a; pw[C + c] = d; }
+      }
+    }
+  }
+}
+
 // gw[c] += sum_k partial[k][0][c], gb[c] += sum_k partial[k][1][c]; grid (ceil(C/256), row chunks)
 __global__ void __launch_bounds__(256)
 channel_norm_bwd_fused_finish(const float* __restrict__ partial, float* __restrict__ gw,
@@ -287,14 +373,20 @@ int dw_chunks(int B, int C, int P) {
   return std::max(chunks, 1);
 }
 
+int g_norm_fwd_px = 32;   // pixels per forward workgroup (32 or 64); diagnostic knob
+int g_norm_bwd_reread = 1;  // backward: re-read x through L2 (two workgroups per CU) vs xhat parked in LDS
+
 int check_norm(const char* name, int B, int C1, int C2, int P) {
   PD_REQUIRE(B >= 0 && C1 >= 1 && C2 >= 0 && P >= 1, "%s: bad shape", name);
   PD_REQUIRE(C1 + C2 >= 2, "%s: needs at least two channels (unbiased variance)", name);
-  PD_REQUIRE((int64_t)B * ((P + NPX - 1) / NPX) < (1ll << 31), "%s: too large", name);
+  PD_REQUIRE((int64_t)B * ((P + 31) / 32) < (1ll << 31), "%s: too large", name);
   return 0;
 }
 
 }  // namespace
+
+extern "C" void paradis_debug_set_norm_fwd_px(int px) { g_norm_fwd_px = px == 64 ? 64 : 32; }
+extern "C" void paradis_debug_set_norm_bwd_reread(int on) { g_norm_bwd_reread = on ? 1 : 0; }
 
 extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
                                         const float* b, float* y, float* mean, float* rstd, int B,
@@ -304,15 +396,26 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
   PD_REQUIRE(C2 == 0 || x2 != nullptr, "channel_norm_fwd: x2 missing");
   if (B == 0) return 0;
   CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
-  const int tiles = (P + NPX - 1) / NPX, C = C1 + C2;
-  const dim3 grid((unsigned)((int64_t)B * tiles)), block(1024);
+  const int C = C1 + C2;
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 16 * 8)
-    hipLaunchKernelGGL(channel_norm_fwd_kernel<8>, grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
-  else if (C <= 16 * 72)
-    hipLaunchKernelGGL(channel_norm_fwd_kernel<72>, grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
-  else
-    hipLaunchKernelGGL(channel_norm_fwd_kernel<0>, grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+  const dim3 block(1024);
+  if (C <= 32 * 36 && g_norm_fwd_px == 32) {          // 32 pixels x 32 groups, two workgroups per CU
+    const int tiles = (P + 31) / 32;
+    const dim3 grid((unsigned)((int64_t)B * tiles));
+    if (C <= 32 * 4)
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+    else
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+  } else {
+    const int tiles = (P + NPX - 1) / NPX;
+    const dim3 grid((unsigned)((int64_t)B * tiles));
+    if (C <= 16 * 8)
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+    else if (C <= 16 * 72)
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+    else
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+  }
   PD_CHECK_LAUNCH("channel_norm_fwd");
   return 0;
 }
@@ -357,7 +460,10 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
       }
       configured = true;
     }
-    if (C <= 32 * 4)
+    if (g_norm_bwd_reread)
+      hipLaunchKernelGGL(channel_norm_bwd_reread_kernel, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, partial, P, tiles32);
+    else if (C <= 32 * 4)
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, NPB>), dim3(nblk), dim3(NPB * 32), lds, st, gy, s,
                          w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, partial, P, tiles32);
     else

@@ -15,26 +15,45 @@ constexpr int TH = 32, TW = 64;  // output tile; 256 threads: lane -> column, wa
 constexpr int RPT = 8;           // rows per thread
 
 // Stage a (TH+K-1) x (TW+K-1) tile, flat over the 256 threads (a row-per-wave variant measured
-// 25-30 % slower: the 68-wide rows leave most lanes of the second pass idle).
+// 25-30 % slower: the 68-wide rows leave most lanes of the second pass idle).  Loads are issued in
+// batches from clamped, always-valid addresses and selected afterwards: a load under a per-lane
+// condition makes the compiler wait for each one separately (one memory round trip per element).
 template <int K, bool GEO>
 __device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int H, int W,
                                            int ty0, int tx0) {
-  constexpr int P = (K - 1) / 2, LW = TW + K - 1, LH = TH + K - 1;
-  for (int i = threadIdx.x; i < LH * LW; i += 256) {
-    const int lr = i / LW, lc = i - lr * LW;
-    const int ii = ty0 + lr - P, jj = tx0 + lc - P;
-    float val = 0.f;
-    if (GEO) {
-      if (ii < H + P && jj < W + P) {
-        int r, c;
-        geo_src(ii, jj, H, W, r, c);
-        val = src[(int64_t)r * W + c];
+  constexpr int P = (K - 1) / 2, LW = TW + K - 1, LH = TH + K - 1, N = LH * LW, BATCH = 5;
+  for (int i0 = threadIdx.x; i0 < N; i0 += 256 * BATCH) {
+    float val[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = min(i0 + 256 * j, N - 1);
+      const int lr = i / LW, lc = i - lr * LW;
+      const int ii = ty0 + lr - P, jj = tx0 + lc - P;
+      bool valid;
+      int r, c;
+      if (GEO) {
+        valid = ii < H + P && jj < W + P;
+        geo_src(min(ii, H + P - 1), min(jj, W + P - 1), H, W, r, c);
+      } else {
+        valid = ii >= 0 && ii < H && jj >= 0 && jj < W;
+        r = min(max(ii, 0), H - 1); c = min(max(jj, 0), W - 1);
       }
-    } else {
-      if (ii >= 0 && ii < H && jj >= 0 && jj < W) val = src[(int64_t)ii * W + jj];
+      const float v = src[(int64_t)r * W + c];
+      val[j] = valid ? v : 0.f;
     }
-    tile[i] = val;
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j)
+      if (i0 + 256 * j < N) tile[i0 + 256 * j] = val[j];
   }
+}
+
+// the tile is the whole padded plane (W == TW, H <= TH, 16-byte aligned plane, even halo): plain
+// 16-byte copy of the interior, only the halo ring through the index map (common.h)
+template <int K>
+__device__ __forceinline__ void stage_any(float* tile, const float* __restrict__ src, int H, int W, int ty0,
+                                          int tx0, bool whole_vec4) {
+  if (whole_vec4) stage_plane_vec4(tile, src, H, W, (K - 1) / 2);
+  else stage_tile<K, true>(tile, src, H, W, ty0, tx0);
 }
 
 // FLIP=false: y = w (*) geo-padded x  (+bias).   FLIP=true: self-alias part of the data gradient.
@@ -68,13 +87,13 @@ template <int K>
 __global__ void __launch_bounds__(256)
 dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                       const float* __restrict__ bias, float* __restrict__ y, int C, int H, int W,
-                      int tiles_x, int tiles) {
+                      int tiles_x, int tiles, int whole_vec4) {
   __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
   const int64_t plane = blockIdx.x / tiles;
   const int t = blockIdx.x - plane * tiles;
   const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
   const int c = plane % C;
-  stage_tile<K, true>(tile, x + plane * (int64_t)H * W, H, W, ty0, tx0);
+  stage_any<K>(tile, x + plane * (int64_t)H * W, H, W, ty0, tx0, whole_vec4);
   __syncthreads();
   float acc[RPT];
   tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
@@ -100,7 +119,8 @@ dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
 template <int K>
 __global__ void __launch_bounds__(256)
 dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
-                        float* __restrict__ gx, int C, int H, int W, int tiles_x, int tiles) {
+                        float* __restrict__ gx, int C, int H, int W, int tiles_x, int tiles,
+                        int whole_vec4) {
   constexpr int P = (K - 1) / 2, LW = TW + K - 1;
   __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
   const int64_t plane = blockIdx.x / tiles;
@@ -109,7 +129,7 @@ dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
   const int c = plane % C;
   const float* g = gy + plane * (int64_t)H * W;
   const float* wc = w + (int64_t)c * K * K;
-  stage_tile<K, true>(tile, g, H, W, ty0, tx0);
+  stage_any<K>(tile, g, H, W, ty0, tx0, whole_vec4);
   __syncthreads();
   const int xl = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RPT;
   float wr[K * K];
@@ -157,21 +177,19 @@ dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
     const int yy = ty0 + r0 + o;
     if (yy >= H) break;
     float extra = 0.f;
-    // mirrored pole rows: E'[0][jj] = gy[0][jj + W/2], E'[H-1][jj] = gy[H-1][jj + W/2]
-    if (yy >= 1 && yy <= P) {
-      const int a = P - yy;             // dr = -yy
+    // mirrored pole rows: E'[0][jj] = gy[0][jj + W/2], E'[H-1][jj] = gy[H-1][jj + W/2].  When the
+    // plane is a single tile both pole rows are in LDS (tile rows P and H-1+P, column + P).
+    const bool south = yy >= 1 && yy <= P, north = yy >= H - 1 - P && yy <= H - 2;
+    if (south || north) {
+      const int a = south ? P - yy : P + (H - 1 - yy);   // dr = -yy  resp.  H-1-yy
+      const int prow = south ? 0 : H - 1;
+#pragma unroll
       for (int b = 0; b < K; ++b) {     // dc = P - b
         int col = xx + P - b + half;
-        col %= W; if (col < 0) col += W;
-        extra += wc[a * K + b] * g[col];
-      }
-    }
-    if (yy >= H - 1 - P && yy <= H - 2) {
-      const int a = P + (H - 1 - yy);   // dr = H-1-yy
-      for (int b = 0; b < K; ++b) {
-        int col = xx + P - b + half;
-        col %= W; if (col < 0) col += W;
-        extra += wc[a * K + b] * g[(int64_t)(H - 1) * W + col];
+        if (col >= W) col -= W;          // xx + P - b + W/2 lies in [-P+W/2, W + P + W/2)
+        if (col >= W) col -= W;
+        const float pv = tiles == 1 ? tile[(prow + P) * LW + col + P] : g[(int64_t)prow * W + col];
+        extra += wc[a * K + b] * pv;   // (wc, not the register copy: a is not a compile-time index)
       }
     }
     gp[(int64_t)yy * W + xx] = acc[o] + extra;
@@ -183,7 +201,7 @@ template <int K>
 __global__ void __launch_bounds__(256)
 dwconv_geo_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                         float* __restrict__ partial, int B, int C, int H, int W, int tiles_x,
-                        int tiles, int chunks) {
+                        int tiles, int chunks, int whole_vec4) {
   constexpr int LW = TW + K - 1, NW = K * K + 1;
   __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
   __shared__ float red[4][NW];
@@ -199,7 +217,7 @@ dwconv_geo_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
     const int64_t plane = (int64_t)n * C + c;
     __syncthreads();
-    stage_tile<K, true>(tile, x + plane * (int64_t)H * W, H, W, ty0, tx0);
+    stage_any<K>(tile, x + plane * (int64_t)H * W, H, W, ty0, tx0, whole_vec4);
     __syncthreads();
     float g[RPT];
     const int xx = tx0 + xl;
@@ -361,6 +379,12 @@ int wgrad_chunks(int B, int C, int tiles) {
 
 }  // namespace
 
+// whole padded plane == one tile and the 16-byte staging path applies (even halo: k = 5)
+static int whole_plane_vec4(const float* src, int H, int W, int k) {
+  return k == 5 && W == TW && H <= TH && ((int64_t)H * W) % 4 == 0 &&
+         (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+}
+
 #define DISPATCH_K(k, CALL)          \
   switch (k) {                       \
     case 3: { constexpr int KK = 3; CALL; } break; \
@@ -375,7 +399,8 @@ extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const floa
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
   const unsigned grid = (unsigned)((int64_t)B * C * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_fwd_kernel<KK>, dim3(grid), dim3(256), 0,
-                                   (hipStream_t)stream, x, w, bias, y, C, H, W, tx, tiles));
+                                   (hipStream_t)stream, x, w, bias, y, C, H, W, tx, tiles,
+                                   whole_plane_vec4(x, H, W, k)));
   PD_CHECK_LAUNCH("dwconv_geo_fwd");
   return 0;
 }
@@ -387,7 +412,8 @@ extern "C" int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* 
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
   const unsigned grid = (unsigned)((int64_t)B * C * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_dgrad_kernel<KK>, dim3(grid), dim3(256), 0,
-                                   (hipStream_t)stream, gy, w, gx, C, H, W, tx, tiles));
+                                   (hipStream_t)stream, gy, w, gx, C, H, W, tx, tiles,
+                                   whole_plane_vec4(gy, H, W, k)));
   PD_CHECK_LAUNCH("dwconv_geo_dgrad");
   return 0;
 }
@@ -407,7 +433,7 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
   float* partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_wgrad_kernel<KK>, dim3(C * chunks), dim3(256), 0, st, gy,
-                                   x, partial, B, C, H, W, tx, tiles, chunks));
+                                   x, partial, B, C, H, W, tx, tiles, chunks, whole_plane_vec4(x, H, W, k)));
   const int n = C * (k * k + 1);
   hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias,
                      C, k * k, chunks);
