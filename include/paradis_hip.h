@@ -174,6 +174,13 @@ int paradis_copy_channels(const float* src, int64_t src_bs, float* dst, int64_t 
 /* f3: AdamW update of one tensor, torch.optim.AdamW operation order (reference trainer.py:327-335) */
 int paradis_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same update for a whole parameter group in one launch.  Device tables: ptrs[4][n_tensors]
+ * (addresses of p, g, m, v as int64), numel[n_tensors], and one entry per chunk of
+ * paradis_adamw_chunk() elements: chunk_tensor[n_chunks], chunk_off[n_chunks]. */
+int paradis_adamw_chunk(void);
+int paradis_adamw_multi(const int64_t* ptrs, const int64_t* numel, const int* chunk_tensor,
+                        const int64_t* chunk_off, int n_tensors, int n_chunks, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, void* stream);
 
 /* ---- diagnostics (process-global tunables used by tools/ and tests/; not needed in production)
  * advect: force the tiled schedule (1) / automatic choice (-1 or 0); halo of the tiled window (0..16)

@@ -73,6 +73,8 @@ SIGNATURES = {
     "paradis_scale": (I, [P, P, P, L, P]),
     "paradis_copy_channels": (I, [P, L, P, L, I, L, P]),
     "paradis_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, P]),
+    "paradis_adamw_chunk": (I, []),
+    "paradis_adamw_multi": (I, [P, P, P, P, I, I, F, F, F, F, F, I, P]),
     "paradis_debug_set_norm_fwd_px": (None, [I]),
     "paradis_debug_set_norm_bwd_reread": (None, [I]),
     "paradis_debug_set_advect_gmem": (None, [I]),

@@ -43,14 +43,18 @@ def test_concat_channels_and_grad():
 def test_adamw_kernel_matches_torch():
     from paradis_model_amd.optim import AdamW
     torch.manual_seed(0)
-    ps = [torch.randn(1000), torch.randn(37, 5), torch.randn(3)]
-    gs = [[torch.randn_like(p) * (10.0 ** (i - 1)) for p in ps] for i in range(3)]
+    # several tensors (one launch per group), one longer than a chunk of the fused kernel
+    ps = [torch.randn(1000), torch.randn(37, 5), torch.randn(3), torch.randn(70001)]
+    gs = [[torch.randn_like(p) * (10.0 ** (i - 1)) for p in ps] for i in range(4)]
     ref = [torch.nn.Parameter(p.clone()) for p in ps]
     mine = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
     kw = dict(lr=5e-4, weight_decay=1e-2, betas=(0.9, 0.95))
     o_ref, o_mine = torch.optim.AdamW(ref, **kw), AdamW(mine, **kw)
-    for step in range(3):
-        for r, m, gq in zip(ref, mine, gs[step]):
+    for step in range(4):
+        for i, (r, m, gq) in enumerate(zip(ref, mine, gs[step])):
+            if step == 2 and i == 1:      # a parameter without a gradient: its step count falls behind
+                r.grad = m.grad = None    # and the group takes the per-tensor path from then on
+                continue
             r.grad, m.grad = gq.clone(), gq.clone().cuda()
         o_ref.step(); o_mine.step()
     for r, m in zip(ref, mine):
