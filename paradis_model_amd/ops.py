@@ -510,7 +510,10 @@ class _Pointwise(torch.autograd.Function):
         ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape,
                     x_act if x_pre is not None else 0, bool(defer_act_grad))
         if defer_act_grad:
+            # z carries no gradient; without this autograd would materialise a full-size zero tensor
+            # for it on every backward (24 fills of [B,896,H,W] per training step)
             ctx.mark_non_differentiable(z)
+            ctx.set_materialize_grads(False)
             return y, z
         return y
 
