@@ -110,12 +110,15 @@ int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w, c
                              int B, int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs,
                              float eps, void* stream);
 size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P);
-/* gx1/gx2 receive the slices of the input gradient (gx2 may be NULL); gw,gb [C]. */
+/* gx1/gx2 receive the slices of the input gradient (gx2 may be NULL); gw,gb [C].
+ * addend1 (optional, [B,C1,P] with batch stride add1_bs) is added to gx1: the gradient that reaches
+ * x1 through the residual connection around the block (paradis.py:246,253), so autograd's separate
+ * accumulation pass disappears. */
 int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2, const float* w,
                              const float* mean, const float* rstd, float* gx1, float* gx2,
                              float* gw, float* gb, int B, int C1, int C2, int P,
                              int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs, int64_t gx2_bs,
-                             void* workspace, void* stream);
+                             const float* addend1, int64_t add1_bs, void* workspace, void* stream);
 
 /* ---- a9: GlobalBias map (reference model/blocks.py:188-196).
  * m8[Cin,H,W] = sum_r A[c,r] U[r,h] V[r,w];  map[Co,H,W] = Pw[Co,Cin] m8 (or map = m8 if Pw NULL). */

@@ -56,7 +56,7 @@ SIGNATURES = {
     "paradis_pw_gemm_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, P, P]),
     "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
     "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),
-    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, P]),
+    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P]),
     "paradis_global_bias_map_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "paradis_global_bias_map_bwd_ws_bytes": (S, [I, I, I, I, I]),
     "paradis_global_bias_map_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),

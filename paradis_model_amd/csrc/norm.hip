@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(1024)
 channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                            float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                           int64_t gbs2, int P, int tiles) {
+                           int64_t gbs2, const float* __restrict__ add1, int64_t abs1, int P, int tiles) {
   __shared__ float red[2][16][NPX];
   __shared__ float stat[2][NPX];
   const int C = s.C1 + s.C2;
@@ -147,7 +147,7 @@ channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* 
     const float gh = gyb[(int64_t)c * P] * w[c];
     const float xh = (s.row(b, c, P)[p] - mean) * rstd;
     const float v = rstd * (gh - m1 - xh * m2);
-    if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v;
+    if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
     else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
   }
 }
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(NPB * 32)
 channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                              int64_t gbs2, float* __restrict__ partial, int P, int tiles) {
+                              int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][32][NPB] reduce + [C][NPB] xhat
   float (*red)[32][NPB] = reinterpret_cast<float (*)[32][NPB]>(lds);
   float* xs = lds + 2 * 32 * NPB;
@@ -252,7 +252,7 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
       const float xh = xs[c * NPB + px];
       if (live) {
         const float v = rstd * (g[i] * w[c] - m1 - xh * m2);
-        if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v;
+        if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
         else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
       }
       float a = g[i] * xh, d = g[i];       // dead pixels hold zeros
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(512)
 channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                               int64_t gbs2, float* __restrict__ partial, int P, int tiles) {
+                               int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles) {
   constexpr int NPB = 32, G = 16;
   __shared__ float red[2][G][NPB];
   const int C = s.C1 + s.C2;
@@ -335,7 +335,7 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
         const float xh = (xv[j] - mean) * rstd;
         if (live) {
           const float v = rstd * (g * wv[j] - m1 - xh * m2);
-          if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v;
+          if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
           else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
         }
         float a = g * xh, d = g;
@@ -430,7 +430,8 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
                                         const float* w, const float* mean, const float* rstd,
                                         float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
                                         int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
-                                        int64_t gx2_bs, void* workspace, void* stream) {
+                                        int64_t gx2_bs, const float* addend1, int64_t add1_bs,
+                                        void* workspace, void* stream) {
   if (int e = check_norm("channel_norm_bwd", B, C1, C2, P)) return e;
   PD_REQUIRE(workspace != nullptr, "channel_norm_bwd: workspace required");
   const int C = C1 + C2;
@@ -462,13 +463,13 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     }
     if (g_norm_bwd_reread)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
-                         rstd, gx1, gx2, gx1_bs, gx2_bs, partial, P, tiles32);
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else if (C <= 32 * 4)
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, NPB>), dim3(nblk), dim3(NPB * 32), lds, st, gy, s,
-                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, partial, P, tiles32);
+                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<36, NPB>), dim3(nblk), dim3(NPB * 32), lds, st, gy, s,
-                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, partial, P, tiles32);
+                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     if (hipMemsetAsync(gw, 0, C * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(gb, 0, C * sizeof(float), st) != hipSuccess) {
       paradis_set_error("channel_norm_bwd: memset failed");
@@ -482,7 +483,7 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   }
   const int tiles = (P + NPX - 1) / NPX;
   hipLaunchKernelGGL(channel_norm_bwd_dx_kernel, dim3((unsigned)((int64_t)B * tiles)), dim3(1024), 0, st,
-                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, P, tiles);
+                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, P, tiles);
   const int chunks = dw_chunks(B, C, P);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(channel_norm_bwd_dw_kernel, dim3(C * chunks), dim3(256), 0, st, gy, s, mean, rstd,

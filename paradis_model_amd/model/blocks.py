@@ -112,9 +112,13 @@ class ChannelNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(input_dim), requires_grad=True)
         self.bias = nn.Parameter(torch.zeros(input_dim), requires_grad=True)
 
-    def forward(self, x, x_extra=None):
+    def forward(self, x, x_extra=None, with_skip: bool = False):
         """``x_extra``: optional second tensor treated as concatenated after ``x`` along channels
-        (the reaction block's cat([hidden, hidden_static]) without materialising it)."""
+        (the reaction block's cat([hidden, hidden_static]) without materialising it).
+        ``with_skip``: also return ``x`` for a residual branch; its gradient is then added inside
+        the backward kernel (no separate accumulation pass)."""
+        if with_skip:
+            return ops.channel_norm_skip(x, self.weight, self.bias, self.eps, x_extra)
         return ops.channel_norm(x, self.weight, self.bias, self.eps, x_extra)
 
 
@@ -226,10 +230,16 @@ class GMBlock(nn.Sequential):
         super().__init__(OrderedDict(children))
         init_module_convs(self, last_conv_scale=0.1)
 
-    def forward(self, x, residual=None, x_extra=None):
+    def forward(self, x, residual=None, x_extra=None, return_skip: bool = False):
+        """``return_skip``: also return the block input for other consumers (``(out, x)``); with a
+        leading ChannelNorm the gradients of all those consumers are summed inside its backward
+        kernel.  The same happens automatically when ``residual`` is the block input itself."""
         mods = list(self.children())
         n = len(mods)
         i = 0
+        skip, x_in = None, x
+        fuse_skip = (n > 0 and isinstance(mods[0], ChannelNorm) and torch.is_grad_enabled()
+                     and x.requires_grad and (return_skip or residual is x))
         if x_extra is not None and not (n and isinstance(mods[0], ChannelNorm)):
             x = torch.cat([x, x_extra], dim=1)
             x_extra = None
@@ -237,7 +247,13 @@ class GMBlock(nn.Sequential):
         while i < n:
             m = mods[i]
             if isinstance(m, ChannelNorm):
-                x = m(x, x_extra)
+                if i == 0 and fuse_skip:
+                    res_is_x = residual is x
+                    x, skip = m(x, x_extra, with_skip=True)
+                    if res_is_x:
+                        residual = skip
+                else:
+                    x = m(x, x_extra)
                 x_extra = None
                 i += 1
             elif isinstance(m, (CLinear, SepConv)):
@@ -275,4 +291,6 @@ class GMBlock(nn.Sequential):
                 i += 1
         if residual is not None:
             x = ops.add(x, residual)
+        if return_skip:
+            return x, (skip if skip is not None else x_in)
         return x

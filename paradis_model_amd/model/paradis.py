@@ -158,7 +158,9 @@ class Paradis(nn.Module):
     # ------------------------------------------------------------------ one ADR update
     def _layer_step(self, i: int, hidden: torch.Tensor, hidden_static: torch.Tensor) -> torch.Tensor:
         # velocities: channels [0,K) = u, [K,2K) = v  (reference: .view(B,2,K,H,W))
-        velocities = self.velocity_nets[i](hidden)
+        # (the block also hands back its input: the gradients of the three consumers of `hidden` -
+        #  velocity net, advection, blend - meet inside the leading ChannelNorm's backward kernel)
+        velocities, hidden = self.velocity_nets[i](hidden, return_skip=True)
 
         # transport, gated per latent channel:  h + sigmoid(alpha_i) * (A(h) - h)
         advected = self.advection[i].forward_velocities(hidden, velocities, self.dt)

@@ -329,8 +329,9 @@ def upsample_lonp(x, nlat: int, nlon: int):
 # ---------------------------------------------------------------------------
 class _ChannelNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, eps):
+    def forward(ctx, x1, x2, weight, bias, eps, with_skip):
         require_hip(x1, x2, weight, bias)
+        x1_in = x1
         x1, bs1 = _plane_view(x1)
         B, C1, H, W = x1.shape
         C2, bs2 = 0, 0
@@ -347,14 +348,24 @@ class _ChannelNorm(torch.autograd.Function):
                                            stream_ptr()), "channel_norm_fwd")
         ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight, mean, rstd)
         ctx.meta = (C1, C2, bs1, bs2, H, W)
+        if with_skip:
+            # second output = x1 itself: consumers of the residual path take it from here, so both
+            # gradients of x1 arrive at this node and are summed inside the backward kernel
+            ctx.set_materialize_grads(False)
+            return y, x1_in
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x1, x2, weight, mean, rstd = ctx.saved_tensors
         C1, C2, bs1, bs2, H, W = ctx.meta
         B, P, C = x1.shape[0], H * W, C1 + C2
+        if gy is None:          # only the skip path was used
+            return gskip, None, None, None, None, None
         gy = gy.contiguous()
+        add, add_bs = None, 0
+        if gskip is not None:
+            add, add_bs = _plane_view(gskip)
         gx1 = torch.empty(B, C1, H, W, dtype=gy.dtype, device=gy.device)
         gx2 = torch.empty(B, C2, H, W, dtype=gy.dtype, device=gy.device) if C2 else None
         gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
@@ -362,14 +373,21 @@ class _ChannelNorm(torch.autograd.Function):
         ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
         check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight),
                                            dptr(mean), dptr(rstd), dptr(gx1), dptr(gx2), dptr(gw),
-                                           dptr(gb), B, C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(ws),
-                                           stream_ptr()), "channel_norm_bwd")
-        return gx1, gx2, gw, gb, None
+                                           dptr(gb), B, C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add),
+                                           add_bs, dptr(ws), stream_ptr()), "channel_norm_bwd")
+        return gx1, gx2, gw, gb, None, None
 
 
 def channel_norm(x, weight, bias, eps: float = 1e-5, x_extra=None):
     """ChannelNorm over channels of ``x`` (and, virtually concatenated after them, ``x_extra``)."""
-    return _ChannelNorm.apply(x, x_extra, weight, bias, float(eps))
+    return _ChannelNorm.apply(x, x_extra, weight, bias, float(eps), False)
+
+
+def channel_norm_skip(x, weight, bias, eps: float = 1e-5, x_extra=None):
+    """``(channel_norm(x), x)``: the second output is ``x`` for the residual branch around the block.
+    Its gradient is added to the normalisation's input gradient inside the backward kernel instead of
+    by a separate autograd accumulation pass."""
+    return _ChannelNorm.apply(x, x_extra, weight, bias, float(eps), True)
 
 
 # ---------------------------------------------------------------------------
