@@ -17,8 +17,18 @@ gbias_m8_kernel(const float* __restrict__ A, const float* __restrict__ U, const 
                 float* __restrict__ m8, int Cin, int R, int H, int W) {
   const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, c = blockIdx.z;
   if (w >= W) return;
+  // rank loop in batches of independent loads (one dependent load per iteration made this 50 us for
+  // 2 M multiply-adds); same summation order
   float acc = 0.f;
-  for (int r = 0; r < R; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
+  int r = 0;
+  for (; r + 8 <= R; r += 8) {
+    float a[8], u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = A[c * R + r + j]; u[j] = U[(r + j) * H + h]; v[j] = V[(r + j) * W + w]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += a[j] * u[j] * v[j];
+  }
+  for (; r < R; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
   m8[((int64_t)c * H + h) * W + w] = acc;
 }
 

@@ -273,6 +273,7 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
 // Infinity Cache, HBM traffic unchanged).  512 threads = 32 pixels x 16 channel groups, 4 KiB of LDS,
 // ~40 VGPRs: four workgroups share a CU, so loads, reductions and stores of different tiles overlap
 // (the register/LDS-resident version fits one workgroup per CU and runs its phases back to back).
+template <bool HAS_ADD>
 __global__ void __launch_bounds__(512)
 channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -319,13 +320,14 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
   const float m1 = red[0][0][px] / (float)C, m2 = red[1][0][px] / (float)(C - 1);
   float* pw = partial + (int64_t)blockIdx.x * 2 * C;
   for (int c0 = grp; c0 < C; c0 += G * U) {
-    float gv[U], xv[U], wv[U];
+    float gv[U], xv[U], wv[U], av[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const int c = min(c0 + G * j, C - 1);
       gv[j] = gyb[(int64_t)c * P];
       xv[j] = s.row(b, c, P)[p];
       wv[j] = w[c];
+      av[j] = HAS_ADD ? add1[(int64_t)b * abs1 + (int64_t)min(c, s.C1 - 1) * P + p] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -335,7 +337,7 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
         const float xh = (xv[j] - mean) * rstd;
         if (live) {
           const float v = rstd * (g * wv[j] - m1 - xh * m2);
-          if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
+          if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + av[j];
           else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
         }
         float a = g * xh, d = g;
@@ -461,8 +463,11 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
       }
       configured = true;
     }
-    if (g_norm_bwd_reread)
-      hipLaunchKernelGGL(channel_norm_bwd_reread_kernel, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
+    if (g_norm_bwd_reread && addend1)
+      hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<true>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
+    else if (g_norm_bwd_reread)
+      hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<false>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
                          rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else if (C <= 32 * 4)
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, NPB>), dim3(nblk), dim3(NPB * 32), lds, st, gy, s,
