@@ -157,6 +157,30 @@ def test_channel_norm(ops, B, C, H, W):
         _cmp(d.grad, t.grad, BWD, n)
 
 
+def test_channel_norm_skip_output_fuses_residual_gradient(ops):
+    """(y, x) = channel_norm_skip(x): the gradient arriving through the second output (the residual
+    branch around a block) is added inside the backward kernel; same numbers as norm + autograd add."""
+    B, C, H, W, Ce = 2, 96, 8, 16, 24
+    x, xe = seeded(1, B, C, H, W), seeded(2, B, Ce, H, W)
+    w, b = seeded(3, C + Ce, scale=0.5) + 1.0, seeded(4, C + Ce, scale=0.1)
+    ct_y, ct_s = seeded(5, B, C + Ce, H, W), seeded(6, B, C, H, W)
+    xr, xer, wr, br = (t.clone().requires_grad_(True) for t in (x, xe, w, b))
+    y = O.channel_norm(torch.cat([xr, xer], 1), wr, br)
+    (y * ct_y).sum().add((xr * ct_s).sum()).backward()
+    xd, xed, wd, bd = (_dev(t) for t in (x, xe, w, b))
+    yd, skip = ops.channel_norm_skip(xd, wd, bd, 1e-5, xed)
+    assert skip.data_ptr() == xd.data_ptr()
+    ((yd * ct_y.cuda()).sum() + (skip * ct_s.cuda()).sum()).backward()
+    _cmp(yd, y, FWD, "y")
+    for name, d, r in (("gx", xd, xr), ("gx_extra", xed, xer), ("gw", wd, wr), ("gb", bd, br)):
+        _cmp(d.grad, r.grad, BWD, name)
+    # only the skip output used: the gradient passes straight through
+    xd2 = _dev(x)
+    _, skip2 = ops.channel_norm_skip(xd2, _dev(w[:C]), _dev(b[:C]), 1e-5, None)
+    (skip2 * ct_s.cuda()).sum().backward()
+    assert torch.equal(xd2.grad.cpu(), ct_s)
+
+
 def test_channel_norm_virtual_concat_and_golden(ops):
     x1, x2 = seeded(1, 2, 24, 8, 16), seeded(2, 2, 8, 8, 16, scale=2.0)
     w, b = 1.0 + seeded(3, 32, scale=0.1), seeded(4, 32, scale=0.1)
