@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--forward-only", action="store_true",
                     help="inference forward under no_grad (BASELINE configs[4]); value = samples/s")
     ap.add_argument("--checkpoint", action="store_true", help="per-layer activation checkpointing")
+    ap.add_argument("--optimizer", default="adamw", choices=["adamw", "muon", "normuon"],
+                    help="adamw = the measured configuration (SURVEY 8d); normuon = the reference's shipped default")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
@@ -152,6 +154,7 @@ def main():
         B = args.batch
     cfg = default_config()
     cfg.compute.gradient_checkpointing = bool(args.checkpoint)
+    cfg.training.optimizer.name = args.optimizer
     lay = feature_layout(cfg)
     lat_deg, lg, og = make_grids(nlat, nlon, poles)
     torch.manual_seed(cfg.init.seed)
@@ -203,7 +206,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
-                   "optimizer": "adamw", "parallelism": f"dp{world}",
+                   "optimizer": args.optimizer, "parallelism": f"dp{world}",
                    "mode": "forward-only" if args.forward_only else "train",
                    "activation_checkpointing": bool(args.checkpoint),
                    "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,

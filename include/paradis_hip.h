@@ -199,6 +199,22 @@ void paradis_debug_set_gemm_stagger(int units);
 void paradis_debug_set_gemm_dma(int stages);
 void paradis_debug_set_wgrad_dma(int stages);
 
+/* ---- f3 (second half): Muon / NorMuon step on T same-shaped weight matrices w_t[rows, cols] (conv
+ * weights flattened to [out, in*kh*kw]), the reference's default optimiser for Conv/Linear weights
+ * (trainer.py:24-64,337-364; `dion` package, un-vendored and un-pinned: restated from its published
+ * algorithm - momentum, Frobenius normalisation, 5 quintic Newton-Schulz iterations on the wide
+ * orientation, NorMuon's per-neuron second-moment normalisation, decoupled weight decay).
+ * ptrs: DEVICE table [4][table_stride] of addresses (int64) of w, g, m (momentum [rows*cols]) and
+ * v (NorMuon per-row state [rows]); lr_adj: the shape-adjusted learning rate. */
+size_t paradis_muon_ws_bytes(int T, int rows, int cols);
+int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, int rows, int cols, float lr,
+                      float lr_adj, float mu, float beta2, float weight_decay, float eps, int nesterov,
+                      int normuon, void* workspace, void* stream);
+/* Plain batched GEMM C_b[M,N] = A_b[M,K] B_b[K,N] (row-major; AT = optional [K,M] transposes of A_b,
+ * enabling the LDS-DMA kernel) used by the Newton-Schulz iteration. */
+int paradis_bgemm(const float* A, const float* AT, const float* B, float* C, int nbatch, int M, int K, int N,
+                  int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs, void* stream);
+
 /* ---- f4: data feed on the device --------------------------------------------------------------
  * Forcings of B series of T consecutive timestamps each, every series as the dataset assembles one
  * sample (reference data/era5_dataset.py:587-621; data/forcings/time_vars.py:6-40;

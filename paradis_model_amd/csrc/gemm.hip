@@ -697,6 +697,37 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const floa
   return 0;
 }
 
+// Plain batched GEMM  C_b[M,N] = A_b[M,K] B_b[K,N]  (row-major, batch strides in elements) on the same
+// kernels; AT (optional) = the [K,M] transposes of A_b with batch stride at_bs, which lets the LDS-DMA
+// kernel run.  Used by the Newton-Schulz iteration of the Muon step (muon.hip): same-shape weight
+// matrices are stacked so that one launch fills the chip (a single 896^3 product is 49 tiles).
+extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, float* C, int nbatch, int M,
+                             int K, int N, int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs,
+                             void* stream) {
+  PD_REQUIRE(nbatch >= 0 && M >= 1 && K >= 1 && N >= 1, "bgemm: bad shape");
+  if (nbatch == 0) return 0;
+  GemmArgs g{};
+  g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.lda = K; g.ldb = N; g.ldc = N;
+  g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs; g.nbatch = nbatch; g.inner = 0;
+  g.stagger = g_stagger;
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nbatch;
+  PD_REQUIRE(tiles < (1ll << 31), "bgemm: too many tiles");
+  const int grid = (int)tiles;
+  if (AT != nullptr) {
+    GemmArgs d = g;
+    d.A = AT; d.lda = M; d.a_bs = at_bs;
+    if (dma_eligible(d)) {
+      launch_gemm_dma(d, grid, (hipStream_t)stream);
+      PD_CHECK_LAUNCH("bgemm(dma)");
+      return 0;
+    }
+  }
+  if (int e = launch_gemm<true, false>(g, grid, (hipStream_t)stream)) return e;
+  PD_CHECK_LAUNCH("bgemm");
+  return 0;
+}
+
 extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const float* zpre,
                                      const float* addend, float* dX, int B, int M, int K, int N,
                                      int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,

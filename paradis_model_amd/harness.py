@@ -119,7 +119,20 @@ class TrainStep:
         o = cfg.training.optimizer
         params = [p for p in model.parameters() if p.requires_grad]
         on_hip = bool(params and params[0].is_cuda)
-        if on_hip and fused is None:
+        name = o.get("name", "adamw")
+        if "muon" in name:
+            # reference trainer.py:337-364 (dion.Muon / dion.NorMuon over build_param_groups)
+            if not on_hip:
+                raise RuntimeError("Muon/NorMuon run on the HIP device only")
+            from . import optim
+            inner = model.module if hasattr(model, "module") else model
+            groups = optim.build_param_groups(inner, lr=o.lr, weight_decay=o.weight_decay, optimizer_name=name)
+            cls = {"muon": optim.Muon, "normuon": optim.NorMuon}.get(name)
+            if cls is None:
+                raise ValueError(f"Optimizer {name} not supported. Choose between normuon|muon")
+            self.opt = cls(groups, lr=o.lr, weight_decay=o.weight_decay, betas=(o.beta1, o.beta2),
+                           use_triton=True)
+        elif on_hip and fused is None:
             from .optim import AdamW   # HIP kernel, torch.optim.AdamW semantics
             self.opt = AdamW(params, lr=o.lr, weight_decay=o.weight_decay, betas=(o.beta1, o.beta2))
         else:

@@ -2,6 +2,8 @@
 ``torch.optim.AdamW(params, lr, weight_decay, betas)``).  Same update rule and operation order as
 ``torch.optim.AdamW`` (decoupled weight decay, bias-corrected moments, eps added after the sqrt);
 state-dict layout compatible with it (``step``, ``exp_avg``, ``exp_avg_sq``)."""
+import ctypes
+
 import torch
 
 from ._lib import check, dptr, lib, require_hip, stream_ptr
@@ -87,3 +89,168 @@ class AdamW(torch.optim.Optimizer):
         check(lib.paradis_adamw_multi(dptr(c["ptrs"]), dptr(c["numel"]), dptr(c["chunk_tensor"]),
                                       dptr(c["chunk_off"]), T, c["n_chunks"], group["lr"], b1, b2, group["eps"],
                                       group["weight_decay"], step, st), "adamw_multi")
+
+
+# ---------------------------------------------------------------------------------------------
+# Muon / NorMuon (the reference's default optimiser family, trainer.py:337-364, from `dion`)
+# ---------------------------------------------------------------------------------------------
+def build_param_groups(model, lr, weight_decay, optimizer_name):
+    """Parameter grouping of reference trainer.py:24-64: weights of Linear/Conv modules go to the
+    Muon-family algorithm (flattened to 2-D), their biases and every other parameter to AdamW."""
+    from torch import nn
+    muon_params, adamw_params, seen = [], [], set()
+    for _, module in model.named_modules():
+        if isinstance(module, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d)):
+            if getattr(module, "weight", None) is not None and module.weight.requires_grad:
+                muon_params.append(module.weight)
+                seen.add(id(module.weight))
+            if getattr(module, "bias", None) is not None and module.bias.requires_grad:
+                adamw_params.append(module.bias)
+                seen.add(id(module.bias))
+    for _, p in model.named_parameters():
+        if not p.requires_grad or id(p) in seen:
+            continue
+        adamw_params.append(p)
+        seen.add(id(p))
+    return [dict(params=muon_params, algorithm=optimizer_name, lr=lr, weight_decay=weight_decay, flatten=True),
+            dict(params=adamw_params, algorithm="adamw", lr=lr, weight_decay=weight_decay)]
+
+
+def _adjusted_lr(lr, shape, adjust):
+    import math
+    fan_out, fan_in = shape[0], math.prod(shape[1:])
+    if adjust is None:
+        return lr
+    if adjust == "spectral_norm":
+        return lr * math.sqrt(fan_out / fan_in)
+    if adjust == "rms_norm":
+        return lr * 0.2 * math.sqrt(max(fan_out, fan_in))
+    raise ValueError(f"unknown adjust_lr {adjust!r}")
+
+
+class Muon(AdamW):
+    """Muon with the constructor of ``dion.Muon`` as the reference calls it (trainer.py:347-354):
+    parameter groups carry ``algorithm`` ("muon" / "normuon" for 2-D-flattened weights, "adamw" for
+    the rest, see ``build_param_groups``).  The matrix update runs in one C-ABI call per weight
+    (``paradis_muon_step``: fp32 MFMA Newton-Schulz, no Triton); AdamW groups use the fused kernel
+    of the base class.  ``dion`` is neither vendored nor pinned by the reference: the algorithm is
+    restated from its published form (oracle/muon_oracle.py), parity unpinned."""
+
+    _NORMUON = False
+    _DEFAULT_ADJUST = "spectral_norm"
+
+    def __init__(self, params, lr=0.01, mu=0.95, betas=(0.9, 0.95), weight_decay=0.01, epsilon=1e-8,
+                 nesterov=False, adjust_lr="default", flatten=False, use_triton=False, muon_beta2=0.95):
+        del use_triton   # accepted for signature compatibility; there is no Triton on this path
+        if adjust_lr == "default":
+            adjust_lr = self._DEFAULT_ADJUST
+        params = list(params)
+        if params and not isinstance(params[0], dict):
+            params = [dict(params=params, algorithm="normuon" if self._NORMUON else "muon")]
+        for gdict in params:
+            gdict.setdefault("algorithm", "normuon" if self._NORMUON else "muon")
+        super().__init__(params, lr=lr, betas=betas, eps=epsilon, weight_decay=weight_decay)
+        for group in self.param_groups:
+            group.setdefault("mu", mu)
+            group.setdefault("nesterov", nesterov)
+            group.setdefault("adjust_lr", adjust_lr)
+            group.setdefault("flatten", flatten)
+            group.setdefault("muon_beta2", muon_beta2)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        adamw_groups = [g for g in self.param_groups if g["algorithm"] == "adamw"]
+        matrix_groups = [g for g in self.param_groups if g["algorithm"] != "adamw"]
+        for gi, group in enumerate(matrix_groups):
+            if group["algorithm"] not in ("muon", "normuon"):
+                raise ValueError(f"unknown algorithm {group['algorithm']!r}")
+            self._step_matrix_group(gi, group)
+        if adamw_groups:
+            saved = self.param_groups
+            self.param_groups = adamw_groups
+            try:
+                AdamW.step(self)
+            finally:
+                self.param_groups = saved
+        return loss
+
+    def _step_matrix_group(self, gi, group):
+        """Same-shaped matrices are updated together (one ``paradis_muon_step`` per shape: the batched
+        Newton-Schulz GEMMs fill the chip).  One device table of the w / g / momentum / variance
+        addresses serves all shapes; the gradient addresses are refreshed each step through a pinned
+        staging buffer (no host synchronisation)."""
+        normuon = group["algorithm"] == "normuon"
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            return
+        for p in params:
+            require_hip(p, p.grad)
+            if p.dim() < 2:
+                raise ValueError("Muon parameters must be matrices (use an adamw group for the rest)")
+            if p.dim() > 2 and not group["flatten"]:
+                raise ValueError("conv weights need flatten=True (reference trainer.py:54)")
+            if not p.is_contiguous():
+                raise ValueError("Muon: non-contiguous parameter")
+            state = self.state[p]
+            if not state:
+                state["step"] = 0
+                state["momentum"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if normuon:
+                    state["variance_neuron"] = torch.zeros(p.shape[0], 1, dtype=p.dtype, device=p.device)
+            state["step"] += 1
+        dev = params[0].device
+        key = tuple(id(p) for p in params)
+        cache = self.__dict__.setdefault("_muon_cache", {})
+        c = cache.get(gi)
+        if c is None or c["key"] != key:
+            by_shape = {}
+            for p in params:
+                by_shape.setdefault((p.shape[0], p.numel() // p.shape[0], tuple(p.shape)), []).append(p)
+            order, shapes = [], []
+            for (rows, cols, full), ps in by_shape.items():
+                shapes.append((rows, cols, full, len(order), len(ps)))
+                order.extend(ps)
+            T = len(order)
+            host = torch.zeros(4 * T, dtype=torch.int64).pin_memory()
+            for t, p in enumerate(order):
+                host[t] = p.data_ptr()
+                host[2 * T + t] = self.state[p]["momentum"].data_ptr()
+                if normuon:
+                    host[3 * T + t] = self.state[p]["variance_neuron"].data_ptr()
+            ws_bytes = max(lib.paradis_muon_ws_bytes(n, rows, cols) for rows, cols, _, _, n in shapes)
+            c = cache[gi] = dict(key=key, order=order, shapes=shapes, T=T, host=host,
+                                 table=torch.empty(4 * T, dtype=torch.int64, device=dev),
+                                 ws=torch.empty(ws_bytes // 4 + 64, dtype=torch.float32, device=dev))
+        T, host = c["T"], c["host"]
+        if c.get("pending") is not None:
+            c["pending"].synchronize()
+        grads = []
+        for p in c["order"]:
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            grads.append(g)          # keep alive until the kernels are queued
+        host[T:2 * T] = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64)
+        c["table"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        c["pending"] = ev
+        st = stream_ptr()
+        lr = group["lr"]
+        base = c["table"].data_ptr()
+        for rows, cols, full, off, n in c["shapes"]:
+            check(lib.paradis_muon_step(ctypes.c_void_p(base + 8 * off), T, n, rows, cols, lr,
+                                        _adjusted_lr(lr, full, group["adjust_lr"]), group["mu"],
+                                        group["muon_beta2"], group["weight_decay"], group["eps"],
+                                        int(bool(group["nesterov"])), int(normuon), dptr(c["ws"]), st),
+                  "muon_step")
+
+
+class NorMuon(Muon):
+    """``dion.NorMuon`` as called at reference trainer.py:355-362 (the shipped default,
+    config/paradis_settings.yaml:117): Muon + per-neuron second-moment normalisation."""
+
+    _NORMUON = True
+    _DEFAULT_ADJUST = "rms_norm"
