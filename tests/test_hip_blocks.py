@@ -101,7 +101,8 @@ def test_clinear_golden(ops):
 
 # ----------------------------------------------------------------------------------- depthwise
 @pytest.mark.parametrize("k", [3, 5, 7])
-@pytest.mark.parametrize("B,C,H,W", [(2, 6, 12, 16), (2, 5, 33, 64), (1, 3, 70, 130), (2, 4, 9, 8)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 6, 12, 16), (2, 5, 33, 64), (1, 3, 70, 130), (2, 4, 9, 8),
+                                     (2, 6, 32, 64), (3, 5, 16, 64)])   # last two: whole-plane 16-byte staging
 @pytest.mark.parametrize("bias", [False, True])
 def test_dwconv_geo(ops, k, B, C, H, W, bias):
     if (k - 1) // 2 > H - 2 or k - 1 > W:
