@@ -40,12 +40,19 @@ namespace {
 constexpr float TWO_PI_F = 6.283185307179586f;
 constexpr float CLAMP_HI = 0.9999999f;  // float(1 - 1e-7), as torch.clamp converts its python bound
 constexpr float KA = -0.75f;
-constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule
+constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
+#ifndef ADV_TILE_HF
+#define ADV_TILE_HF 64
+#endif
+// forward tile height: a taller tile amortises the halo (window cells per arrival point 2.6 at 16
+// rows, 1.9 at 32, 1.5 at 64 with a halo of 8); the forward window is 4 B/cell, so LDS is not the
+// limit.  Measured at 128x256: 1.64 / 1.42 / 1.23 ms per launch for 16 / 32 / 64 rows
+constexpr int TILE_HF = ADV_TILE_HF;
 // threads per tile in the tiled schedule: the window fixes the LDS per workgroup, so waves per SIMD
 // come from the workgroup size.  Backward (12 B/cell, 2 workgroups per CU): at 256 threads it ran 1.7
 // waves per SIMD at 29 % VALU issue, 512 threads measured 6.9 -> 5.6 ms at 128x256; the forward
 // (4 B/cell) has the occupancy already and is 5-10 % faster with 256.
-constexpr int TILED_THREADS_FWD = 256, TILED_THREADS_BWD = 512;
+constexpr int TILED_THREADS_FWD = TILE_HF >= 32 ? 512 : 256, TILED_THREADS_BWD = 512;
 #ifndef ADV_UNROLL
 #define ADV_UNROLL 4
 #endif
@@ -361,11 +368,11 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
   const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
   float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
 
-  const int ty0 = WHOLE ? 0 : (tile / tiles_x) * TILE_H, tx0 = WHOLE ? 0 : (tile % tiles_x) * TILE_W;
-  const int th = WHOLE ? H : min(TILE_H, H - ty0), tw = WHOLE ? W : min(TILE_W, W - tx0);
+  const int ty0 = WHOLE ? 0 : (tile / tiles_x) * TILE_HF, tx0 = WHOLE ? 0 : (tile % tiles_x) * TILE_W;
+  const int th = WHOLE ? H : min(TILE_HF, H - ty0), tw = WHOLE ? W : min(TILE_W, W - tx0);
   Window w;
   if (WHOLE) { w.wy0 = 0; w.wx0 = 0; w.WH = Hp; w.WW = Wp; }
-  else { w.wy0 = ty0 + p - halo; w.wx0 = tx0 + p - halo; w.WH = TILE_H + 2 * halo + NT; w.WW = TILE_W + 2 * halo + NT; }
+  else { w.wy0 = ty0 + p - halo; w.wx0 = tx0 + p - halo; w.WH = TILE_HF + 2 * halo + NT; w.WW = TILE_W + 2 * halo + NT; }
   float* win = smem;                       // [WH*WW]
   float* pole_out = smem + w.WH * w.WW;    // [2*W]  (WHOLE only)
 
@@ -893,10 +900,10 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   float* fmeans = (float*)workspace;
   const int mean_blocks = (planes * 2 * 64 + 255) / 256;
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, field, fmeans, planes, K, H, W, f_bs);
-  const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H, tiles = tx * ty;
+  const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_HF - 1) / TILE_HF, tiles = tx * ty;
   PD_REQUIRE((int64_t)planes * tiles < (1ll << 31), "sl_advect_fwd: too many tiles");
   const int halo = g_halo;
-  const size_t lds = (size_t)(TILE_H + 2 * halo + NT) * (TILE_W + 2 * halo + NT) * sizeof(float);
+  const size_t lds = (size_t)(TILE_HF + 2 * halo + NT) * (TILE_W + 2 * halo + NT) * sizeof(float);
   PD_REQUIRE(lds <= 160 * 1024, "sl_advect_fwd: window does not fit LDS");
   static bool reserved = false;
   if (!reserved) {
