@@ -40,7 +40,13 @@ namespace {
 constexpr float TWO_PI_F = 6.283185307179586f;
 constexpr float CLAMP_HI = 0.9999999f;  // float(1 - 1e-7), as torch.clamp converts its python bound
 constexpr float KA = -0.75f;
-constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
+#ifndef ADV_TILE_HB
+#define ADV_TILE_HB 16
+#endif
+#ifndef ADV_THREADS_B
+#define ADV_THREADS_B 512
+#endif
+constexpr int TILE_H = ADV_TILE_HB, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
 #ifndef ADV_TILE_HF
 #define ADV_TILE_HF 64
 #endif
@@ -52,7 +58,7 @@ constexpr int TILE_HF = ADV_TILE_HF;
 // come from the workgroup size.  Backward (12 B/cell, 2 workgroups per CU): at 256 threads it ran 1.7
 // waves per SIMD at 29 % VALU issue, 512 threads measured 6.9 -> 5.6 ms at 128x256; the forward
 // (4 B/cell) has the occupancy already and is 5-10 % faster with 256.
-constexpr int TILED_THREADS_FWD = TILE_HF >= 32 ? 512 : 256, TILED_THREADS_BWD = 512;
+constexpr int TILED_THREADS_FWD = TILE_HF >= 32 ? 512 : 256, TILED_THREADS_BWD = ADV_THREADS_B;
 #ifndef ADV_UNROLL
 #define ADV_UNROLL 4
 #endif
