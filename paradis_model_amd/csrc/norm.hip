@@ -216,21 +216,34 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
   const bool live = p < P;
   const float mean = live ? mean_in[(int64_t)b * P + p] : 0.f;
   const float rstd = live ? rstd_in[(int64_t)b * P + p] : 0.f;
-  const float* gyb = gy + (int64_t)b * C * P + p;
   float g[MAXC];
   float s1 = 0.f, s2 = 0.f;
+  // loads in batches from clamped (always valid) addresses, selected afterwards: a load under a
+  // per-lane condition is waited for on its own
+  const int pc = min(p, P - 1);
+  const float* gyc = gy + (int64_t)b * C * P + pc;
+  constexpr int CH = MAXC % 6 == 0 ? 6 : 4;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = grp + 32 * i;
-    if (c < C) {
-      g[i] = live ? gyb[(int64_t)c * P] : 0.f;
-      const float xh = live ? (s.row(b, c, P)[p] - mean) * rstd : 0.f;
-      xs[c * NPB + px] = xh;
-      const float gh = g[i] * w[c];
-      s1 += gh;
-      s2 += gh * xh;
-    } else {
-      g[i] = 0.f;
+  for (int i0 = 0; i0 < MAXC; i0 += CH) {
+    float xv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = min(grp + 32 * (i0 + j), C - 1);
+      g[i0 + j] = gyc[(int64_t)c * P];
+      xv[j] = s.row(b, c, P)[pc];
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = grp + 32 * (i0 + j);
+      const bool on = live && c < C;
+      g[i0 + j] = on ? g[i0 + j] : 0.f;
+      if (c < C) {
+        const float xh = on ? (xv[j] - mean) * rstd : 0.f;
+        xs[c * NPB + px] = xh;
+        const float gh = g[i0 + j] * w[c];
+        s1 += gh;
+        s2 += gh * xh;
+      }
     }
   }
   red[0][grp][px] = s1;
@@ -447,33 +460,38 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     return 0;
   }
   CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
+  int nblk = 0;
   if (C <= 32 * 36 && (int64_t)B * ((P + 31) / 32) < (1ll << 31)) {
-    constexpr int NPB = 32;   // (16-pixel tiles, two workgroups per CU, measured slower: 417 vs 392 us)
-    const int tiles32 = (P + NPB - 1) / NPB, nblk = B * tiles32;
+    // g_norm_bwd_reread: 1 = stream-twice kernel (default; in the training step 231.6 vs 235.2 ms),
+    // 0 = gy in registers + xhat in LDS, one workgroup per CU (half the HBM traffic, phases serialised).
+    // (16-pixel tiles of the resident kernel, two workgroups per CU: 587 vs 365 us - not kept.)
+    const int NPBr = 32;
+    const int tiles32 = (P + NPBr - 1) / NPBr;
+    nblk = B * tiles32;
     float* partial = (float*)workspace;
-    const size_t lds = (size_t)(2 * 32 * NPB + C * NPB) * sizeof(float);
+    const size_t lds = (size_t)(2 * 32 * NPBr + C * NPBr) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channel_norm_bwd_fused_kernel<36, NPB>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channel_norm_bwd_fused_kernel<36, 32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&channel_norm_bwd_fused_kernel<4, NPB>),
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&channel_norm_bwd_fused_kernel<4, 32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         paradis_set_error("channel_norm_bwd: cannot reserve LDS");
         return 2;
       }
       configured = true;
     }
-    if (g_norm_bwd_reread && addend1)
+    if (g_norm_bwd_reread == 1 && addend1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<true>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
                          rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
-    else if (g_norm_bwd_reread)
+    else if (g_norm_bwd_reread == 1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<false>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
                          rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else if (C <= 32 * 4)
-      hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, NPB>), dim3(nblk), dim3(NPB * 32), lds, st, gy, s,
+      hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
                          w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else
-      hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<36, NPB>), dim3(nblk), dim3(NPB * 32), lds, st, gy, s,
+      hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<36, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
                          w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     if (hipMemsetAsync(gw, 0, C * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(gb, 0, C * sizeof(float), st) != hipSuccess) {
