@@ -34,6 +34,19 @@ WORKLOADS = {
 }
 
 
+def pmc_mfma_busy():
+    """Matrix-pipe busy fraction of the GEMM kernels from the newest committed PMC summary
+    (profiles/*_mfma_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), same bench
+    command under rocprofv3 --pmc); {kernel: fraction} or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_busy.json")), key=os.path.getmtime)
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    return {k: v for k, v in data.items() if "gemm" in k} or None
+
+
 def pmc_traffic(substr: str):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/*_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes with the gfx950 2x read-side correction of
@@ -227,7 +240,8 @@ def main():
                                "traffic": pmc_traffic("pw_gemm"),
                                "launches": n, "avg_launch_ms": ms / n,
                                "flops_per_launch": flops / n,
-                               "share_of_step": ms / (1e3 * elapsed)}
+                               "share_of_step": ms / (1e3 * elapsed),
+                               "mfma_busy_pmc": pmc_mfma_busy()}
         for key, name in (("sl_advect_fwd", "roofline_advect_fwd"), ("sl_advect_bwd", "roofline_advect_bwd")):
             if key in s:
                 r = s[key]
