@@ -434,21 +434,34 @@ pw_gemm_dma_kernel(GemmArgs g) {
   for (int t = 0; t < T; ++t) {
     // tile t must have landed; up to S-2 younger tiles (4 DMAs each per wave) stay in flight
     const int pending = min(S - 2, T - 1 - t);
+#ifndef DMA_NO_BARRIER   // diagnostic ablations (tools/gemm_variants.py): DMA_NO_BARRIER / _ISSUE / _LDSREAD / _EPILOGUE
     if (pending >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else if (pending == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     // the stage of tile t-1 is free now (every wave has passed its MFMAs): refill it
+#ifndef DMA_NO_ISSUE
     if (t + S - 1 < T) issue(t + S - 1);
+#endif
     const float* As = lds + (t % S) * (2 * DTILE) + wm * 64 + li + lh * BM;
     const float* Bs = As - wm * 64 + DTILE + wn * 64;
+#ifdef DMA_NO_LDSREAD
+    float a0 = 1.0f + t, a1 = 2.0f, b0 = 3.0f, b1 = 0.5f + lane;
+    (void)As; (void)Bs;
+#else
     float a0 = As[0], a1 = As[32], b0 = Bs[0], b1 = Bs[32];
+#endif
 #pragma unroll
     for (int kk = 0; kk < DBK / 2; ++kk) {
       float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+#ifdef DMA_NO_LDSREAD
+      na0 = a0 + 1.f; na1 = a1; nb0 = b0; nb1 = b1;
+#else
       if (kk + 1 < DBK / 2) {
         na0 = As[(2 * kk + 2) * BM]; na1 = As[(2 * kk + 2) * BM + 32];
         nb0 = Bs[(2 * kk + 2) * BN]; nb1 = Bs[(2 * kk + 2) * BN + 32];
       }
+#endif
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -456,7 +469,11 @@ pw_gemm_dma_kernel(GemmArgs g) {
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
   }
+#ifdef DMA_NO_EPILOGUE
+  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) g.C[0] = 1.f;
+#else
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+#endif
 }
 
 // ======================================================================================

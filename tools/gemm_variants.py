@@ -12,7 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "paradis_model_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "variants")
-VARIANTS = {"base": [], "no_stage": ["-DGEMM_NO_STAGE"],
+VARIANTS = {"base": [], "base_dma": [], "dma_no_barrier": ["-DDMA_NO_BARRIER"], "dma_no_issue": ["-DDMA_NO_ISSUE"],
+            "dma_no_ldsread": ["-DDMA_NO_LDSREAD"], "dma_no_epilogue": ["-DDMA_NO_EPILOGUE"],
+            "dma_mfma_only": ["-DDMA_NO_BARRIER", "-DDMA_NO_ISSUE", "-DDMA_NO_LDSREAD", "-DDMA_NO_EPILOGUE"],
+            "dma_no_bar_issue": ["-DDMA_NO_BARRIER", "-DDMA_NO_ISSUE"],
+            "no_stage": ["-DGEMM_NO_STAGE"],
             "no_stage_no_barrier": ["-DGEMM_NO_STAGE", "-DGEMM_NO_BARRIER"],
             "mfma_only": ["-DGEMM_NO_STAGE", "-DGEMM_NO_BARRIER", "-DGEMM_NO_LDSREAD"],
             "no_barrier": ["-DGEMM_NO_BARRIER"], "no_ldsstore": ["-DGEMM_NO_LDSSTORE"],
@@ -26,7 +30,7 @@ def build():
         so = os.path.join(OUT, f"libgemm_{name}.so")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
                "-munsafe-fp-atomics", "-shared", *flags, os.path.join(CSRC, "gemm.hip"),
-               os.path.join(CSRC, "error.hip"), "-o", so]
+               os.path.join(CSRC, "error.hip"), os.path.join(CSRC, "misc.hip"), "-o", so]
         subprocess.run(cmd, check=True)
 
 
@@ -40,6 +44,7 @@ def main():
     w = torch.randn(Co, Ci, device="cuda") / 32
     x = torch.randn(B, Ci, P, device="cuda")
     y = torch.empty(B, Co, P, device="cuda")
+    wt = w.t().contiguous()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     flops = 2.0 * B * Co * Ci * P
@@ -57,9 +62,14 @@ def main():
       print("workgroups per CU:", wg)
       for rnd in range(2):
         for name, L in libs.items():
+            if os.environ.get("GEMM_VARIANTS") and name not in os.environ["GEMM_VARIANTS"].split(","):
+                continue
             if name not in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") and wg != 4:
                 continue
-            fn = lambda: L.paradis_pw_gemm_fwd(p(w), None, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
+            # dma_* variants exercise the LDS-DMA kernel (transposed weights supplied), the others the
+            # register-staged kernel
+            wt_arg = p(wt) if name.startswith("dma_") or name == "base_dma" else None
+            fn = lambda: L.paradis_pw_gemm_fwd(p(w), wt_arg, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
             assert fn() == 0
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
