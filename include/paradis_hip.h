@@ -81,10 +81,22 @@ int paradis_avgpool_geo_bwd(const float* gy, float* gx, int64_t planes, int H, i
 int paradis_upsample_lonp_fwd(const float* x, float* y, int64_t planes, int Hc, int Wc, int H, int W, void* stream);
 int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc, int Wc, int H, int W, void* stream);
 
-/* ---- a6: CLinear / pointwise half of SepConv (reference model/blocks.py:86,110): per-sample GEMM
- * on FP32 MFMA.  Y[b] = epi( W[M,K] * X[b][K,N] ),  epi(v) = res + act(v + bias[m] + map[m,n]).
- * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value. */
+/* ---- a6: CLinear / pointwise half of SepConv (reference model/blocks.py:86,110): per-sample GEMM.
+ * Y[b] = epi( W[M,K] * X[b][K,N] ),  epi(v) = res + act(v + bias[m] + map[m,n]).
+ * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value.
+ *
+ * Two arithmetic paths, both fp32 in / fp32 accumulate / fp32 out:
+ *   - exact: v_mfma_f32_32x32x2_f32 (an fmaf chain over k);
+ *   - split: each fp32 operand is decomposed exactly into three bf16 terms and the product is
+ *     accumulated from the six partial products >= 2^-16 on v_mfma_f32_32x32x16_bf16 (relative
+ *     truncation 2^-23 per product, fewer accumulation roundings: error vs fp64 not above the exact
+ *     path's).  Selected per call by passing the split weight image (fwd, dgrad) / split != 0 (wgrad). */
+size_t paradis_pw_gemm_split_bytes(int M, int K);   /* bytes of the split image of an [M,K] A operand */
+/* split image of A = W[M,K] (transpose 0; out: split_bytes(M,K)) or of A = W^T (transpose 1; out:
+ * split_bytes(K,M)) from row-major W[M,K] */
+int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, void* out, void* stream);
 int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
+                        const void* Wsplit /* optional split image of Wt (takes precedence), or NULL */,
                         const float* X, const float* bias, const float* map,
                         const float* m8 /* [cin,N] */, const float* pwT /* [cin,M] */, int cin,
                         /* ^ optional low-rank bias applied on the fly: + sum_c pwT[c,m]*m8[c,n] (GlobalBias
@@ -92,15 +104,17 @@ int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
                         int act, void* stream);
-/* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend) */
-int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const float* zpre, const float* addend,
-                          float* dX, int B, int M, int K, int N, int64_t dy_bs, int64_t z_bs,
-                          int64_t add_bs, int64_t dx_bs, int act, void* stream);
+/* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend);
+ * WTsplit: optional split image of W^T (paradis_pw_gemm_split_weights(..., transpose=1)), or NULL */
+int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const float* dY, const float* zpre,
+                          const float* addend, float* dX, int B, int M, int K, int N, int64_t dy_bs,
+                          int64_t z_bs, int64_t add_bs, int64_t dx_bs, int act, void* stream);
 /* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; gbias[M] = sum_{b,n} dY (optional, NULL to skip; fused
- * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes */
+ * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes;
+ * split != 0 asks for the bf16-split path (used when N % 16 == 0 and the rows are 16-B aligned) */
 size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N);
 int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias,
-                          int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs,
+                          int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs, int split,
                           void* workspace, void* stream);
 
 /* ---- a8: ChannelNorm (reference model/blocks.py:118-134): per-pixel, unbiased variance.

@@ -596,6 +596,301 @@ pw_gemm_wgrad_dma_kernel(GemmArgs g) {
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
+// ======================================================================================
+// Split-bf16 kernels: the same fp32 GEMMs on the bf16 matrix pipe (16x the f32 MFMA rate).
+// Every fp32 operand value x is written as h + m + l with h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m): three bf16 numbers carry 3 x 8 = 24 significand bits, so the split is exact.
+// a*b is accumulated in fp32 from the six partial products of weight >= 2^-16,
+//     ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm        (dropped: am*bl, al*bm, al*bl <= 2^-23 |ab|)
+// v_mfma_f32_32x32x16_bf16 forms the 8x8-bit products exactly and accumulates in fp32, 6/16 roundings
+// per k instead of the f32 MFMA's 1: the measured error against fp64 is below the f32 kernels'
+// (tests/test_hip_gemm_split.py).  Non-finite inputs come out as NaN (Inf - Inf in the split).
+//
+// LDS image of a 128 x 16 operand tile: [split 3][k-half 2][row 128] chunks of 16 B = 8 bf16
+// (k = 8*half + 0..7), so that one ds_read_b128 per lane (row = lane&31, half = lane>>5) is the
+// MFMA operand.  Weights are split once per call into that image in global memory
+// (split_weights_kernel) and move by LDS-DMA; activations are split in registers while staged.
+// 2 stages x 24 KiB => 3 workgroups per CU.
+// ======================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SBK = 16;                  // k depth of a tile = one bf16 MFMA
+constexpr int SCH = 128;                 // chunks per k-half row of an unpadded image
+constexpr int SIMG = 3 * 2 * SCH;        // chunks per operand per stage (12 KiB)
+constexpr int SCHP = 128 + 8;            // padded variant (wgrad: lane pairs write both k-halves of a row)
+constexpr int SIMGP = 3 * 2 * SCHP;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32, a in the low half
+}
+
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = pack_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = pack_bf16(r0, r1);
+  l = pack_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& h, uint4& m, uint4& l) {
+  split_pair(x[0], x[1], h.x, m.x, l.x);
+  split_pair(x[2], x[3], h.y, m.y, l.y);
+  split_pair(x[4], x[5], h.z, m.z, l.z);
+  split_pair(x[6], x[7], h.w, m.w, l.w);
+}
+
+// Image of A[m,k] = W[m*rs + k*cs] (rs/cs select W or W^T), zero padded to [MT*128, KT*16]:
+// out[((mt*KT + kt)*3 + s)*256 + half*128 + row] ; one thread per (mt, kt, half, row).
+__global__ void __launch_bounds__(256)
+split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
+                     int64_t w_bs, int64_t out_bs, uint4* __restrict__ out) {
+  const float* Wb = W + (int64_t)blockIdx.y * w_bs;
+  uint4* ob = out + (int64_t)blockIdx.y * out_bs;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+    const int row = (int)(u & 127), half = (int)((u >> 7) & 1);
+    const int64_t tile = u >> 8;
+    const int kt = (int)(tile % KT), mt = (int)(tile / KT);
+    const int m = mt * BM + row;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kt * SBK + half * 8 + j;
+      x[j] = (m < M && k < K) ? Wb[(int64_t)m * rs + (int64_t)k * cs] : 0.f;
+    }
+    uint4 h, mm, l;
+    split8(x, h, mm, l);
+    uint4* o = ob + tile * SIMG + half * SCH + row;
+    o[0] = h; o[2 * SCH] = mm; o[4 * SCH] = l;
+  }
+}
+
+#define SPLIT_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+// six partial products of one 32x32 block pair, smallest first
+#define SPLIT_BLOCK(AH, AM, AL, BH, BM_, BL, C) \
+  SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AL, BH, C); SPLIT_MFMA(AH, BL, C); \
+  SPLIT_MFMA(AM, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C)
+
+// one k-tile: fragments of both operands from the images at As/Bs (chunk pointers at this lane's
+// row of block 0, k-half lh), plane stride PA/PB chunks ...
+struct SplitFrags { uint4 a[3][2], b[3][2]; };
+template <int PA, int PB>
+__device__ __forceinline__ void split_tile_read(const uint4* As, const uint4* Bs, SplitFrags& f) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    f.a[s][0] = As[s * PA]; f.a[s][1] = As[s * PA + 32];
+    f.b[s][0] = Bs[s * PB]; f.b[s][1] = Bs[s * PB + 32];
+  }
+}
+// ... then the 24 MFMAs
+__device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      SPLIT_BLOCK(f.a[0][tm], f.a[1][tm], f.a[2][tm], f.b[0][tn], f.b[1][tn], f.b[2][tn], acc[tm][tn]);
+    }
+}
+
+// fwd / dgrad:  C_b = epi( A . B_b ),  A = split weight image (g.A, batch stride g.a_bs chunks),
+// B_b[K,N] fp32 with n contiguous
+__global__ void __launch_bounds__(256, 3)
+pw_gemm_split_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  uint4* img = reinterpret_cast<uint4*>(lds);        // [2 stages][A|B][SIMG]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T = (g.K + SBK - 1) / SBK;
+
+  const uint4* Ag = reinterpret_cast<const uint4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
+  // k-half staged by this thread's wave (waves 0,1 -> 0; 2,3 -> 1): row addresses stay scalar
+  const int bh = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const float* Bb = g.B + (int64_t)bz * g.b_bs;
+  const int bn = min(n0 + (tid & 127), g.N - 1);
+
+  float xb[8];
+  auto issueA = [&](int t, int st) {
+    const uint4* a = Ag + (int64_t)t * SIMG;
+    uint4* la = img + st * 2 * SIMG + wave * 64;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a + i * 256), (lds_ptr_t)(la + i * 256), 16, 0, 0);
+  };
+  // loads only (no use of the values here: a use would put an s_waitcnt vmcnt(0) in front of the MFMAs)
+  auto fetchB = [&](int t) {
+    const int k0 = t * SBK + bh * 8;
+    if (k0 + 8 <= g.K) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = (Bb + (int64_t)(k0 + j) * g.ldb)[bn];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = (Bb + (int64_t)min(k0 + j, g.K - 1) * g.ldb)[bn];
+    }
+  };
+  auto storeB = [&](int t, int st) {
+    const int valid = g.K - (t * SBK + bh * 8);     // rows beyond K are zero (the weight image is zero there too,
+    if (valid < 8) {                                //  but 0 * garbage could be NaN)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = (j < valid) ? xb[j] : 0.f;
+    }
+    uint4 h, m, l;
+    split8(xb, h, m, l);
+    uint4* o = img + (st * 2 + 1) * SIMG + bh * SCH + (tid & 127);
+    o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issueA(0, 0);
+  fetchB(0);
+  storeB(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    // diagnostic ablations (tools/gemm_variants.py): SPLIT_NO_FETCH / _DMA / _LDSREAD / _STORE / _BARRIER / _EPILOGUE
+#ifndef SPLIT_NO_FETCH
+    if (t + 1 < T) fetchB(t + 1);
+#endif
+    const uint4* As = img + cur * 2 * SIMG + lh * SCH + wm * 64 + li;
+    const uint4* Bs = img + (cur * 2 + 1) * SIMG + lh * SCH + wn * 64 + li;
+    SplitFrags f;
+#ifdef SPLIT_NO_LDSREAD
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+      for (int i_ = 0; i_ < 2; ++i_) {
+        f.a[s_][i_] = make_uint4(0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u);
+        f.b[s_][i_] = make_uint4(0x3f803f80u, 0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + s_);
+      }
+    (void)As; (void)Bs;
+#else
+    split_tile_read<2 * SCH, 2 * SCH>(As, Bs, f);
+#endif
+    // The weight DMA goes after the fragment reads: the compiler waits for every pending LDS-DMA
+    // (vmcnt) in front of a ds_read that follows it, which would also wait for fetchB's loads.
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef SPLIT_NO_DMA
+    if (t + 1 < T) issueA(t + 1, cur ^ 1);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    split_tile_mfma(f, acc);
+#ifndef SPLIT_NO_STORE
+    if (t + 1 < T) storeB(t + 1, cur ^ 1);
+#endif
+#ifndef SPLIT_NO_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA'd weight tile has landed
+    __syncthreads();
+#endif
+  }
+#ifdef SPLIT_NO_EPILOGUE
+  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] + xb[0] == 123.456f) g.C[0] = 1.f;
+  return;
+#endif
+  gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+}
+
+// wgrad: dW[M,N'] = sum over (sample, p) A[m][p] B[n][p], both operands p-contiguous fp32, both split
+// in registers.  Thread t stages 8 consecutive p of row t>>1 (k-half t&1) of each operand.
+// Needs K % 16 == 0 and 16-B aligned rows (host-checked; otherwise the f32 kernels run).
+__global__ void __launch_bounds__(256, 3)
+pw_gemm_wgrad_split_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  uint4* img = reinterpret_cast<uint4*>(lds);        // [2 stages][A|B][SIMGP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = g.K / SBK;
+  const int64_t total = (int64_t)g.inner * KT;
+  const int t_begin = (int)(total * bz / g.nbatch);
+  const int T = (int)(total * (bz + 1) / g.nbatch) - t_begin;
+
+  const int srow = tid >> 1, sh = tid & 1;
+  const float* Ag = g.A + (int64_t)min(m0 + srow, g.M - 1) * g.lda + sh * 8;
+  const float* Bg = g.B + (int64_t)min(n0 + srow, g.N - 1) * g.ldb + sh * 8;
+
+  float4 ra[2], rb[2];
+  auto fetch = [&](int t) {
+    const int tt = t_begin + t;
+    const int ib = tt / KT, kt = tt - ib * KT;
+    const float* a = Ag + (int64_t)ib * g.a_is + (int64_t)kt * SBK;
+    const float* b = Bg + (int64_t)ib * g.b_is + (int64_t)kt * SBK;
+    ra[0] = *reinterpret_cast<const float4*>(a); ra[1] = *reinterpret_cast<const float4*>(a + 4);
+    rb[0] = *reinterpret_cast<const float4*>(b); rb[1] = *reinterpret_cast<const float4*>(b + 4);
+  };
+  const bool do_rowsum = g.rowsum != nullptr && nt == 0;
+  float rs = 0.f;
+  auto store = [&](int st) {
+    const float xa[8] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w, ra[1].x, ra[1].y, ra[1].z, ra[1].w};
+    const float xb[8] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w, rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+    if (do_rowsum) rs += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+    uint4 h, m, l;
+    split8(xa, h, m, l);
+    uint4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
+    o[0] = h; o[2 * SCHP] = m; o[4 * SCHP] = l;
+    split8(xb, h, m, l);
+    o += SIMGP;
+    o[0] = h; o[2 * SCHP] = m; o[4 * SCHP] = l;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (T > 0) { fetch(0); store(0); }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < T) fetch(t + 1);
+    const uint4* As = img + cur * 2 * SIMGP + lh * SCHP + wm * 64 + li;
+    const uint4* Bs = img + (cur * 2 + 1) * SIMGP + lh * SCHP + wn * 64 + li;
+    SplitFrags f;
+    split_tile_read<2 * SCHP, 2 * SCHP>(As, Bs, f);
+    split_tile_mfma(f, acc);
+    if (t + 1 < T) store(cur ^ 1);
+    __syncthreads();
+  }
+  if (do_rowsum) {
+    rs += __shfl_xor(rs, 1, 64);
+    const int m = m0 + srow;
+    if (sh == 0 && m < g.M) g.rowsum[(int64_t)bz * g.M + m] = rs;
+  }
+  gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+}
+
 __global__ void __launch_bounds__(256)
 slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -607,20 +902,23 @@ slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int
 
 int slots() { return 256 * g_wg_per_cu; }
 
-bool wgrad_dma_ok(int N, int64_t dy_bs, int64_t x_bs, const void* a, const void* b) {
+// both operands p-contiguous with whole, 16-B aligned 16-float chunks (LDS-DMA and split kernels)
+bool wgrad_vec_layout(int N, int64_t dy_bs, int64_t x_bs, const void* a, const void* b) {
   auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return g_wgrad_dma_stages >= 2 && N % DBK == 0 && (dy_bs & 3) == 0 && (x_bs & 3) == 0 && a16(a) && a16(b);
+  return N % DBK == 0 && (dy_bs & 3) == 0 && (x_bs & 3) == 0 && a16(a) && a16(b);
+}
+bool wgrad_dma_ok(int N, int64_t dy_bs, int64_t x_bs, const void* a, const void* b) {
+  return g_wgrad_dma_stages >= 2 && wgrad_vec_layout(N, dy_bs, x_bs, a, b);
 }
 
 // number of k-range splits: one round of resident workgroups over the CUs
-int wgrad_splits(int B, int M, int K, int N, bool dma) {
+int wgrad_splits(int B, int M, int K, int N, int bk, int wg_per_cu) {
   const int tiles = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
-  const int bk = dma ? DBK : g_bk;
   const int64_t total_kt = (int64_t)B * ((N + bk - 1) / bk);
-  const int wg_per_cu = dma ? (g_wgrad_dma_stages == 2 ? 4 : 3) : g_wg_per_cu;
   int s = 256 * wg_per_cu / tiles;
   return (int)std::max<int64_t>(1, std::min<int64_t>(s, total_kt));
 }
+int wgrad_dma_wgs() { return g_wgrad_dma_stages == 2 ? 4 : 3; }
 
 template <bool A_KC, bool B_KC, int BK>
 int launch_gemm_bk(const GemmArgs& g, int grid, hipStream_t st) {
@@ -663,6 +961,12 @@ int launch_gemm(const GemmArgs& g, int grid, hipStream_t st) {
                     : launch_gemm_bk<A_KC, B_KC, 16>(g, grid, st);
 }
 
+constexpr size_t SPLIT_LDS = (size_t)2 * 2 * SIMG * 16, SPLIT_LDS_WGRAD = (size_t)2 * 2 * SIMGP * 16;
+
+int64_t split_image_chunks(int M, int K) {
+  return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * SIMG;
+}
+
 int check_gemm(const char* name, int B, int M, int K, int N) {
   PD_REQUIRE(B >= 0 && M >= 1 && K >= 1 && N >= 1, "%s: bad shape B=%d M=%d K=%d N=%d", name, B, M, K, N);
   const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * std::max(B, 1);
@@ -681,7 +985,27 @@ extern "C" void paradis_debug_set_gemm_stagger(int units) { g_stagger = units < 
 extern "C" void paradis_debug_set_gemm_dma(int stages) { g_dma_stages = stages < 2 ? 0 : (stages > 4 ? 4 : stages); }
 extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = stages < 2 ? 0 : (stages > 3 ? 3 : stages); }
 
-extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const float* X,
+extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K) {
+  return M >= 1 && K >= 1 ? (size_t)split_image_chunks(M, K) * 16 : 0;
+}
+
+// Split image (h/m/l bf16 planes, tile order) of A = W[M,K] (transpose = 0) or of A = W^T[K,M]
+// (transpose = 1, from the same row-major W[M,K]); out holds split_bytes(M,K) resp. split_bytes(K,M).
+extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, void* out,
+                                             void* stream) {
+  PD_REQUIRE(W != nullptr && out != nullptr && M >= 1 && K >= 1, "pw_gemm_split_weights: bad arguments");
+  const int AM = transpose ? K : M, AK = transpose ? M : K;
+  const int KT = (AK + SBK - 1) / SBK;
+  const int64_t units = (int64_t)((AM + BM - 1) / BM) * KT * 256;
+  const int blocks = (int)std::min<int64_t>((units + 255) / 256, 4096);
+  hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
+                     (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units,
+                     (int64_t)0, (int64_t)0, (uint4*)out);
+  PD_CHECK_LAUNCH("pw_gemm_split_weights");
+  return 0;
+}
+
+extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void* Wsplit, const float* X,
                                    const float* bias, const float* map, const float* m8,
                                    const float* pwT, int cin, const float* res, float* Y, float* zpre,
                                    int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
@@ -700,6 +1024,13 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const floa
   g.zout_bs = (int64_t)M * N; g.act = act;
   g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  if (Wsplit != nullptr) {   // bf16-split image of the weights: split kernel (any shape)
+    GemmArgs d = g;
+    d.A = (const float*)Wsplit; d.a_bs = 0;
+    hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, (hipStream_t)stream, d);
+    PD_CHECK_LAUNCH("pw_gemm_fwd(split)");
+    return 0;
+  }
   if (WtT != nullptr) {   // weights also supplied as [K,M]: row-contiguous A operand -> LDS-DMA kernel
     GemmArgs d = g;
     d.A = WtT; d.lda = M;
@@ -745,7 +1076,7 @@ extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, f
   return 0;
 }
 
-extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const float* zpre,
+extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const float* dY, const float* zpre,
                                      const float* addend, float* dX, int B, int M, int K, int N,
                                      int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
                                      int act, void* stream) {
@@ -760,6 +1091,13 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const flo
   g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
   g.stagger = g_stagger;
   const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
+  if (WTsplit != nullptr) {   // bf16-split image of W^T
+    GemmArgs d = g;
+    d.A = (const float*)WTsplit; d.a_bs = 0;
+    hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, (hipStream_t)stream, d);
+    PD_CHECK_LAUNCH("pw_gemm_dgrad(split)");
+    return 0;
+  }
   if (dma_eligible(g)) {
     launch_gemm_dma(g, grid, (hipStream_t)stream);
     PD_CHECK_LAUNCH("pw_gemm_dgrad(dma)");
@@ -771,8 +1109,9 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const float* dY, const flo
 }
 
 extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
-  const int S = std::max(wgrad_splits(std::max(B, 1), M, K, N, true),
-                         wgrad_splits(std::max(B, 1), M, K, N, false));
+  const int b = std::max(B, 1);
+  const int S = std::max({wgrad_splits(b, M, K, N, DBK, wgrad_dma_wgs()), wgrad_splits(b, M, K, N, g_bk, g_wg_per_cu),
+                          wgrad_splits(b, M, K, N, SBK, 3)});
   return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256;   // slabs + row-sum partials
 }
 
@@ -780,8 +1119,8 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
                                   int64_t dz_bs, void* stream);
 
 extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias, int B,
-                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, void* workspace,
-                                     void* stream) {
+                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, int split,
+                                     void* workspace, void* stream) {
   // dW[M,K] = sum_b dY[b][M,N] . X[b][K,N]^T : GEMM with M'=M, N'=K, K'=N, reduced over samples.
   if (int e = check_gemm("pw_gemm_wgrad", 1, M, N, K)) return e;
   hipStream_t st = (hipStream_t)stream;
@@ -790,8 +1129,12 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
     if (gbias && hipMemsetAsync(gbias, 0, (size_t)M * sizeof(float), st) != hipSuccess) return 2;
     return 0;
   }
-  const bool dma = wgrad_dma_ok(N, dy_bs, x_bs, dY, X);
-  const int S = wgrad_splits(B, M, K, N, dma);
+  // split != 0: both operands go through the bf16 split (same layout requirements as the LDS-DMA kernel)
+  const bool use_split = split != 0 && wgrad_vec_layout(N, dy_bs, x_bs, dY, X);
+  const bool dma = use_split || wgrad_dma_ok(N, dy_bs, x_bs, dY, X);   // "dma" = kernels with fused row sums
+  const int S = use_split ? wgrad_splits(B, M, K, N, SBK, 3)
+                          : dma ? wgrad_splits(B, M, K, N, DBK, wgrad_dma_wgs())
+                                : wgrad_splits(B, M, K, N, g_bk, g_wg_per_cu);
   PD_REQUIRE(workspace != nullptr, "pw_gemm_wgrad: workspace required");
   float* rowsum_ws = (float*)workspace + (size_t)S * M * K;   // [S][M], behind the slabs
   if (gbias && !dma) {   // register-staged kernel has no fused row sums: separate reduction pass
@@ -806,7 +1149,9 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.stagger = g_stagger;
   g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-  if (dma) {
+  if (use_split) {
+    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel, dim3(grid), dim3(256), SPLIT_LDS_WGRAD, st, g);
+  } else if (dma) {
     const size_t bytes = (size_t)g_wgrad_dma_stages * 2 * DTILE * sizeof(float);
     if (g_wgrad_dma_stages == 2)
       hipLaunchKernelGGL(pw_gemm_wgrad_dma_kernel<2>, dim3(grid), dim3(256), bytes, st, g);

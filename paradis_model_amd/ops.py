@@ -6,6 +6,7 @@ no CPU path (``_lib.require_hip`` raises).  Reference call sites are cited per o
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -474,6 +475,20 @@ def global_bias_m8(A, U, V):
 #     y = residual + act(W x + bias + bias_map)
 # (reference model/blocks.py:86,110 + :196 + activation + the residual adds of paradis.py:246,253)
 # ---------------------------------------------------------------------------
+# Arithmetic of the pointwise GEMMs (include/paradis_hip.h, a6): True = bf16-split products on the
+# bf16 matrix pipe (fp32 in/accumulate/out, error vs fp64 not above the exact path's: see
+# tests/test_hip_gemm_split.py), False = exact f32 MFMA chain.  PARADIS_GEMM=exact selects the latter.
+GEMM_SPLIT = os.environ.get("PARADIS_GEMM", "split") != "exact"
+
+
+def _split_weights(w2: torch.Tensor, Co: int, Ci: int, transpose: bool) -> torch.Tensor:
+    nbytes = lib.paradis_pw_gemm_split_bytes(Ci, Co) if transpose else lib.paradis_pw_gemm_split_bytes(Co, Ci)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w2.device)
+    check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, dptr(out), stream_ptr()),
+          "pw_gemm_split_weights")
+    return out
+
+
 class _Pointwise(torch.autograd.Function):
     """y = residual + act(W x + bias + bias_map).
 
@@ -511,12 +526,16 @@ class _Pointwise(torch.autograd.Function):
             assert Co % 4 == 0 and cin <= 16, "fused GlobalBias projection needs Co % 4 == 0 and <= 16 bias channels"
             pwt = pw.t().contiguous()   # [cin, Co]: four consecutive output rows per 16-byte load
         z = torch.empty_like(y) if need_z else None
-        # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
-        w2t = None
-        if Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
+        w2t = wsp = None
+        split = GEMM_SPLIT
+        if split:
+            # bf16-split image of the weights (h/m/l planes in tile order) for the split-MFMA kernel
+            wsp = _split_weights(w2, Co, Ci, transpose=False)
+        elif Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
+            # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
             w2t = torch.empty(Ci, Co, dtype=x.dtype, device=x.device)
             check(lib.paradis_transpose(dptr(w2), dptr(w2t), Co, Ci, stream_ptr()), "transpose")
-        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(x), dptr(bias),
+        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), dptr(x), dptr(bias),
                   dptr(bmap), dptr(m8), dptr(pwt) if cin else None, cin, dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs,
                   res_bs, Co * P, act, stream_ptr())
         if x_pre is not None:
@@ -526,7 +545,7 @@ class _Pointwise(torch.autograd.Function):
                               m8 if pw is not None else x.new_empty(0),
                               pw if pw is not None else x.new_empty(0))
         ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape,
-                    x_act if x_pre is not None else 0, bool(defer_act_grad))
+                    x_act if x_pre is not None else 0, bool(defer_act_grad), split)
         if defer_act_grad:
             # z carries no gradient; without this autograd would materialise a full-size zero tensor
             # for it on every backward (24 fills of [B,896,H,W] per training step)
@@ -538,7 +557,7 @@ class _Pointwise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *unused):
         x, w2, z, x_pre, m8, pw = ctx.saved_tensors
-        x_bs, act, has_bias, has_map, has_res, wshape, x_act, deferred = ctx.meta
+        x_bs, act, has_bias, has_map, has_res, wshape, x_act, deferred, split = ctx.meta
         has_proj = pw.numel() > 0
         B, Ci, H, W = x.shape
         Co, P = w2.shape[0], H * W
@@ -554,7 +573,8 @@ class _Pointwise(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, Ci, H, W, dtype=gy.dtype, device=gy.device)
             zmul = x_pre if x_act != 0 else None
-            _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(dz), dptr(zmul), None, dptr(gx),
+            wtsp = _split_weights(w2, Co, Ci, transpose=True) if split else None
+            _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), dptr(dz), dptr(zmul), None, dptr(gx),
                       B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P, x_act, st)
         want_b = has_bias and ctx.needs_input_grad[2]
         want_p = has_proj and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10])
@@ -566,7 +586,7 @@ class _Pointwise(torch.autograd.Function):
                 gb = torch.empty(Co, dtype=gy.dtype, device=gy.device)
                 want_b = False
             _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), dptr(gb), B, Co,
-                      Ci, P, Co * P, x_bs, dptr(ws), st)
+                      Ci, P, Co * P, x_bs, 1 if split else 0, dptr(ws), st)
             gw = gw.reshape(wshape)
         if want_b or want_m:
             gb = torch.empty(Co, dtype=gy.dtype, device=gy.device) if want_b else None

@@ -1,0 +1,112 @@
+"""The bf16-split pointwise GEMMs (fp32 in / fp32 accumulate / fp32 out on the bf16 matrix pipe) against
+the exact f32-MFMA kernels and an fp64 evaluation of the same product.
+
+Claim under test (include/paradis_hip.h, a6): the split path is an fp32 GEMM, not a reduced-precision one:
+its error against fp64 is not above the exact f32 chain's.  Bounds written here:
+  * max |split - fp64| / max |fp64|  <=  1.25 x the same figure of the exact kernel + 1e-7, and
+  * <= 2e-6 absolutely (an fp32 dot product of length <= 1024 with |x|,|w| ~ 1 sits at ~3e-7)."""
+import pytest
+import torch
+
+from tests._util import seeded
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # B, Ci, Co, H, W
+    (2, 10, 7, 12, 16),        # one ragged tile, K < 16
+    (2, 186, 64, 16, 32),      # K % 16 != 0 (the input projection's 186 channels)
+    (3, 128, 97, 32, 64),      # M ragged
+    (1, 256, 384, 17, 32),     # N = 544: ragged n tile, still N % 16 == 0
+    (2, 130, 258, 9, 20),      # N = 180: weight-gradient falls back to the exact kernel (N % 16 != 0)
+    (2, 1024, 896, 32, 64),    # the default model's widest GEMM
+]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from paradis_model_amd import ops as _ops
+    return _ops
+
+
+def _run(ops, split, x, w, b, res, ct, act):
+    keep = ops.GEMM_SPLIT
+    ops.GEMM_SPLIT = split
+    try:
+        ds = [t.detach().clone().cuda().requires_grad_(True) for t in (x, w, b, res)]
+        y = ops.pointwise(ds[0], ds[1], ds[2], None, ds[3], act)
+        y.backward(ct.cuda())
+        torch.cuda.synchronize()
+        return [y.detach()] + [d.grad for d in ds[:3]]
+    finally:
+        ops.GEMM_SPLIT = keep
+
+
+def _fp64(x, w, b, res, ct, act):
+    ts = [t.detach().clone().cuda().double().requires_grad_(True) for t in (x, w, b, res)]
+    z = torch.einsum("oc,bchw->bohw", ts[1], ts[0]) + ts[2].view(1, -1, 1, 1)
+    if act == "SiLU":
+        z = torch.nn.functional.silu(z)
+    elif act == "GELU":
+        z = torch.nn.functional.gelu(z)
+    y = z + ts[3]
+    y.backward(ct.cuda().double())
+    return [y.detach()] + [t.grad for t in ts[:3]]
+
+
+def _err(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", SHAPES)
+@pytest.mark.parametrize("act", [None, "SiLU"])
+def test_split_not_less_accurate_than_exact_f32(ops, B, Ci, Co, H, W, act):
+    x = seeded(1, B, Ci, H, W)
+    w = seeded(2, Co, Ci, scale=Ci ** -0.5)
+    b = seeded(3, Co, scale=0.1)
+    res = seeded(5, B, Co, H, W)
+    ct = seeded(6, B, Co, H, W)
+    ref = _fp64(x, w, b, res, ct, act)
+    exact = _run(ops, False, x, w, b, res, ct, act)
+    split = _run(ops, True, x, w, b, res, ct, act)
+    for name, s, e, r in zip(("y", "gx", "gw", "gb"), split, exact, ref):
+        es, ee = _err(s, r), _err(e, r)
+        assert es <= 1.25 * ee + 1e-7, (name, es, ee)
+        assert es <= 2e-6, (name, es)
+
+
+def test_split_exactness_on_bf16_representable_inputs(ops):
+    """Inputs that are exactly bf16 numbers with small integer values make every partial product and
+    every partial sum exact in fp32: both paths must then agree bit for bit with integer arithmetic."""
+    g = torch.Generator().manual_seed(7)
+    B, Ci, Co, H, W = 2, 64, 48, 8, 16
+    x = torch.randint(-8, 9, (B, Ci, H, W), generator=g).float()
+    w = torch.randint(-8, 9, (Co, Ci), generator=g).float()
+    b = torch.zeros(Co)
+    res = torch.zeros(B, Co, H, W)
+    ct = torch.randint(-4, 5, (B, Co, H, W), generator=g).float()
+    ref = _fp64(x, w, b, res, ct, None)
+    for mode in (True, False):
+        got = _run(ops, mode, x, w, b, res, ct, None)
+        for name, a, r in zip(("y", "gx", "gw"), got, ref):
+            assert torch.equal(a.double(), r), (mode, name)
+
+
+def test_split_handles_wide_dynamic_range(ops):
+    """Operands spanning 12 decades: the h/m/l terms keep fp32's exponent range (bf16 has the same
+    8 exponent bits), so nothing under- or overflows in the split."""
+    g = torch.Generator().manual_seed(11)
+    B, Ci, Co, H, W = 1, 96, 64, 8, 16
+    mag = 10.0 ** (torch.rand(B, Ci, H, W, generator=g) * 12 - 6)
+    x = torch.randn(B, Ci, H, W, generator=g) * mag
+    w = torch.randn(Co, Ci, generator=g) * 10.0 ** (torch.rand(Co, Ci, generator=g) * 6 - 3)
+    b = torch.zeros(Co)
+    res = torch.zeros(B, Co, H, W)
+    ct = torch.randn(B, Co, H, W, generator=g)
+    ref = _fp64(x, w, b, res, ct, None)
+    exact = _run(ops, False, x, w, b, res, ct, None)
+    split = _run(ops, True, x, w, b, res, ct, None)
+    for name, s, e, r in zip(("y", "gx", "gw"), split, exact, ref):
+        # element-wise relative to the fp64 magnitude scale of each output row/column is too strict
+        # for cancelling sums; compare the two paths on the same max-normalised figure
+        es, ee = _err(s, r), _err(e, r)
+        assert es <= 1.25 * ee + 1e-7, (name, es, ee)

@@ -13,12 +13,13 @@ from paradis_model_amd import _lib  # noqa: E402
 from paradis_model_amd._lib import dptr, lib, stream_ptr  # noqa: E402
 
 B, P = 32, 2048
+ACCURACY = os.environ.get("GEMM_ACCURACY", "1") == "1"
 SHAPES = [(1024, 186), (384, 1024), (1536, 384), (768, 1024), (1024, 768), (1024, 1024), (896, 1152),
           (896, 896), (1024, 896), (768, 768), (97, 768)]   # (Co, Ci)
-# (bk, workgroups/CU of the register-staged kernel, LDS-DMA ring depth [0 = off])
-CONFIGS = [(16, 4, 0), (16, 4, 2), (16, 4, 3), (16, 4, 4)] if len(sys.argv) < 2 else \
+# (bk, workgroups/CU of the register-staged kernel, LDS-DMA ring depth [0 = off], bf16-split [0/1])
+CONFIGS = [(16, 4, 3, 0), (16, 4, 3, 1)] if len(sys.argv) < 2 else \
     [tuple(map(int, a.split(","))) for a in sys.argv[1:]]
-CONFIGS = [c if len(c) == 3 else (*c, 0) for c in CONFIGS]
+CONFIGS = [(tuple(c) + (0, 0))[:4] for c in CONFIGS]
 lib.paradis_debug_set_gemm_dma.argtypes = [ctypes.c_int]
 lib.paradis_debug_set_wgrad_dma.argtypes = [ctypes.c_int]
 lib.paradis_debug_set_gemm.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -49,21 +50,35 @@ def main():
         ws = torch.empty(64 << 20, device="cuda")
         flops = 2.0 * B * Co * Ci * P
         line = f"Co={Co:5d} Ci={Ci:5d} |"
+        ref = None
         for cfg in CONFIGS:
             lib.paradis_debug_set_gemm(cfg[0], cfg[1])
             lib.paradis_debug_set_gemm_dma(cfg[2])
             lib.paradis_debug_set_wgrad_dma(cfg[2] if cfg[2] <= 3 else 3)
             use_t = cfg[2] >= 2
+            wsp = wtsp = None
+            if cfg[3]:
+                wsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Co, Ci), dtype=torch.uint8, device="cuda")
+                wtsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Ci, Co), dtype=torch.uint8, device="cuda")
+                lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, dptr(wsp), st)
+                lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 1, dptr(wtsp), st)
             t = {}
-            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
-            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
-            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, dptr(ws), st))
+            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(wsp), dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
+            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(wtsp), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
+            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, cfg[3], dptr(ws), st))
+            if ACCURACY:   # max error / max |exact| against fp64 on two samples
+                if ref is None:
+                    xd, dyd, wd = x[:2].double(), dy[:2].double(), w.double()
+                    ref = (wd @ xd, wd.t() @ dyd, torch.einsum("bmp,bkp->mk", dy.double(), x.double()))
+                errs = [float(((a.double() - r).abs().max() / r.abs().max()))
+                        for a, r in ((y[:2], ref[0]), (dx[:2], ref[1]), (dw, ref[2]))]
+                line += "  err " + " ".join(f"{e:.1e}" for e in errs)
             for k in t:
                 tot[cfg][k] += t[k]
-            line += "  bk%d/wg%d/dma%d: " % cfg + " ".join(f"{k[0]}{flops / t[k] / 1e6:6.1f}" for k in ("fwd", "dgrad", "wgrad"))
+            line += "  bk%d/wg%d/dma%d/split%d: " % cfg + " ".join(f"{k[0]}{flops / t[k] / 1e6:6.1f}" for k in ("fwd", "dgrad", "wgrad"))
         print(line, flush=True)
     for cfg in CONFIGS:
-        print("total us bk%d/wg%d/dma%d:" % cfg, {k: round(v) for k, v in tot[cfg].items()}, "sum", round(sum(tot[cfg].values())))
+        print("total us bk%d/wg%d/dma%d/split%d:" % cfg, {k: round(v) for k, v in tot[cfg].items()}, "sum", round(sum(tot[cfg].values())))
 
 
 if __name__ == "__main__":

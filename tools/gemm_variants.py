@@ -21,15 +21,25 @@ VARIANTS = {"base": [], "base_dma": [], "dma_no_barrier": ["-DDMA_NO_BARRIER"], 
             "mfma_only": ["-DGEMM_NO_STAGE", "-DGEMM_NO_BARRIER", "-DGEMM_NO_LDSREAD"],
             "no_barrier": ["-DGEMM_NO_BARRIER"], "no_ldsstore": ["-DGEMM_NO_LDSSTORE"],
             "no_gload": ["-DGEMM_NO_GLOAD"], "unguarded": ["-DGEMM_UNGUARDED"],
-            "unguarded_no_ldsstore": ["-DGEMM_UNGUARDED", "-DGEMM_NO_LDSSTORE"]}
+            "unguarded_no_ldsstore": ["-DGEMM_UNGUARDED", "-DGEMM_NO_LDSSTORE"],
+            "split_base": [], "split_no_fetch": ["-DSPLIT_NO_FETCH"], "split_no_dma": ["-DSPLIT_NO_DMA"],
+            "split_no_ldsread": ["-DSPLIT_NO_LDSREAD"], "split_no_store": ["-DSPLIT_NO_STORE"],
+            "split_no_barrier": ["-DSPLIT_NO_BARRIER"], "split_no_epilogue": ["-DSPLIT_NO_EPILOGUE"],
+            "split_no_global": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA"],
+            "split_no_global_store": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA", "-DSPLIT_NO_STORE"],
+            "split_mfma_only": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA", "-DSPLIT_NO_STORE", "-DSPLIT_NO_LDSREAD",
+                                "-DSPLIT_NO_BARRIER", "-DSPLIT_NO_EPILOGUE"]}
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
+    only = os.environ.get("GEMM_VARIANTS")
     for name, flags in VARIANTS.items():
+        if only and not (name in only.split(",") or (only == "split" and name.startswith("split_"))):
+            continue
         so = os.path.join(OUT, f"libgemm_{name}.so")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
-               "-munsafe-fp-atomics", "-shared", *flags, os.path.join(CSRC, "gemm.hip"),
+               "-munsafe-fp-atomics", "-fno-slp-vectorize", "-shared", *flags, os.path.join(CSRC, "gemm.hip"),
                os.path.join(CSRC, "error.hip"), os.path.join(CSRC, "misc.hip"), "-o", so]
         subprocess.run(cmd, check=True)
 
@@ -49,7 +59,11 @@ def main():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     flops = 2.0 * B * Co * Ci * P
     libs = {}
-    for name in VARIANTS:
+    only = os.environ.get("GEMM_VARIANTS")
+    names = [n for n in VARIANTS if not only or n in only.split(",") or (only == "split" and n.startswith("split_"))]
+    wsp = torch.empty(_lib.lib.paradis_pw_gemm_split_bytes(Co, Ci), dtype=torch.uint8, device="cuda")
+    _lib.lib.paradis_pw_gemm_split_weights(p(w), Co, Ci, 0, p(wsp), st)
+    for name in names:
         L = ctypes.CDLL(os.path.join(OUT, f"libgemm_{name}.so"))
         L.paradis_pw_gemm_fwd.argtypes = _lib.SIGNATURES["paradis_pw_gemm_fwd"][1]
         libs[name] = L
@@ -62,14 +76,13 @@ def main():
       print("workgroups per CU:", wg)
       for rnd in range(2):
         for name, L in libs.items():
-            if os.environ.get("GEMM_VARIANTS") and name not in os.environ["GEMM_VARIANTS"].split(","):
-                continue
-            if name not in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") and wg != 4:
+            if name not in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") and wg != 4 and not name.startswith("split_"):
                 continue
             # dma_* variants exercise the LDS-DMA kernel (transposed weights supplied), the others the
             # register-staged kernel
             wt_arg = p(wt) if name.startswith("dma_") or name == "base_dma" else None
-            fn = lambda: L.paradis_pw_gemm_fwd(p(w), wt_arg, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
+            sp_arg = p(wsp) if name.startswith("split_") else None
+            fn = lambda: L.paradis_pw_gemm_fwd(p(w), wt_arg, sp_arg, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
             assert fn() == 0
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
