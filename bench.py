@@ -6,8 +6,9 @@ One "step" = forward (S=1 rollout step) + ParadisLoss + backward + AdamW on one 
 ERA5-shaped batch of 32 samples per GPU (configs[1]: 32x64 grid, default 60 M-parameter model,
 fp32).  N>1: one process per GPU (torchrun), batch-sharded DDP over RCCL, weak scaling.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = FP32-MFMA pointwise GEMM, timed
-live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the pointwise GEMMs: fp32 in /
+fp32 accumulate / fp32 out, by default as exact 3-way bf16 splits on the bf16 matrix pipe, with
+--gemm exact on the f32 MFMA; timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the
 reference path, timed on the host cores on a bounded sample).
 """
 import argparse
@@ -23,6 +24,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak (no xf32 on gfx950)
+# bf16-split GEMMs execute 6 bf16 partial products per fp32 product on the 2.5 PFLOP/s dense bf16 pipe:
+# the ceiling in algorithmic (fp32-equivalent) FLOP/s is a sixth of it
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+SPLIT_PRODUCTS = 6
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 WORKLOADS = {
@@ -139,11 +144,13 @@ def main():
     ap.add_argument("--checkpoint", action="store_true", help="per-layer activation checkpointing")
     ap.add_argument("--optimizer", default="adamw", choices=["adamw", "muon", "normuon"],
                     help="adamw = the measured configuration (SURVEY 8d); normuon = the reference's shipped default")
+    ap.add_argument("--gemm", default=os.environ.get("PARADIS_GEMM", "split"), choices=["split", "exact"],
+                    help="pointwise GEMM arithmetic: exact 3-way bf16 split on the bf16 MFMA (default) or f32 MFMA")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
 
-    from paradis_model_amd import _lib
+    from paradis_model_amd import _lib, ops
     from paradis_model_amd.config import default_config, feature_layout, stub_datamodule
     from paradis_model_amd.harness import (TrainStep, barrier, init_distributed, make_grids,
                                            max_over_ranks, synthetic_batch, wrap_ddp)
@@ -152,6 +159,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    ops.GEMM_SPLIT = args.gemm == "split"
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
@@ -220,6 +228,8 @@ def main():
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
                    "optimizer": args.optimizer, "parallelism": f"dp{world}",
+                   "gemm_arithmetic": ("fp32 via exact 3-way bf16 split on bf16 MFMA, fp32 accumulate"
+                                       if args.gemm == "split" else "fp32 MFMA"),
                    "mode": "forward-only" if args.forward_only else "train",
                    "activation_checkpointing": bool(args.checkpoint),
                    "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
@@ -233,10 +243,18 @@ def main():
             ms = sum(g["ms"] for g in gem)
             n = sum(g["launches"] for g in gem)
             ach = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, "
-                                         "v_mfma_f32_32x32x2_f32)",
-                               "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+            if args.gemm == "split":
+                kname = ("pw_gemm_split_kernel/pw_gemm_wgrad_split_kernel (fwd+dgrad+wgrad; fp32 operands as "
+                         "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
+                peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS
+            else:
+                kname = "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)"
+                peak = MFMA_F32_PEAK_TFLOPS
+            out["roofline"] = {"kernel": kname,
+                               "bound": "mfma", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak,
+                               "flops": "algorithmic 2*M*N*K per GEMM (fp32-equivalent)"
+                                        + ("; executed bf16 MFMA rate = 6x achieved, peak = 2500/6" if args.gemm == "split" else ""),
                                "traffic": pmc_traffic("pw_gemm"),
                                "launches": n, "avg_launch_ms": ms / n,
                                "flops_per_launch": flops / n,

@@ -615,6 +615,10 @@ pw_gemm_wgrad_dma_kernel(GemmArgs g) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// LDS images are accessed through a clang vector type, not HIP's u32x4 struct: behind a struct-typed
+// ds_read the compiler inserts an s_waitcnt vmcnt for every LDS-DMA still in flight (alias rule),
+// which would serialise the DMA rings; vector-typed reads do not get that wait.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SBK = 16;                  // k depth of a tile = one bf16 MFMA
 constexpr int SCH = 128;                 // chunks per k-half row of an unpadded image
@@ -634,20 +638,22 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
   l = pack_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
 }
 
-__device__ __forceinline__ void split8(const float (&x)[8], uint4& h, uint4& m, uint4& l) {
-  split_pair(x[0], x[1], h.x, m.x, l.x);
-  split_pair(x[2], x[3], h.y, m.y, l.y);
-  split_pair(x[4], x[5], h.z, m.z, l.z);
-  split_pair(x[6], x[7], h.w, m.w, l.w);
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split_pair(x[2 * i], x[2 * i + 1], hh[i], mm[i], ll[i]);
+  h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+  m = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+  l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
 }
 
 // Image of A[m,k] = W[m*rs + k*cs] (rs/cs select W or W^T), zero padded to [MT*128, KT*16]:
 // out[((mt*KT + kt)*3 + s)*256 + half*128 + row] ; one thread per (mt, kt, half, row).
 __global__ void __launch_bounds__(256)
 split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
-                     int64_t w_bs, int64_t out_bs, uint4* __restrict__ out) {
+                     int64_t w_bs, int64_t out_bs, u32x4* __restrict__ out) {
   const float* Wb = W + (int64_t)blockIdx.y * w_bs;
-  uint4* ob = out + (int64_t)blockIdx.y * out_bs;
+  u32x4* ob = out + (int64_t)blockIdx.y * out_bs;
   for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
     const int row = (int)(u & 127), half = (int)((u >> 7) & 1);
     const int64_t tile = u >> 8;
@@ -659,9 +665,9 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
       const int k = kt * SBK + half * 8 + j;
       x[j] = (m < M && k < K) ? Wb[(int64_t)m * rs + (int64_t)k * cs] : 0.f;
     }
-    uint4 h, mm, l;
+    u32x4 h, mm, l;
     split8(x, h, mm, l);
-    uint4* o = ob + tile * SIMG + half * SCH + row;
+    u32x4* o = ob + tile * SIMG + half * SCH + row;
     o[0] = h; o[2 * SCH] = mm; o[4 * SCH] = l;
   }
 }
@@ -674,9 +680,9 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 
 // one k-tile: fragments of both operands from the images at As/Bs (chunk pointers at this lane's
 // row of block 0, k-half lh), plane stride PA/PB chunks ...
-struct SplitFrags { uint4 a[3][2], b[3][2]; };
+struct SplitFrags { u32x4 a[3][2], b[3][2]; };
 template <int PA, int PB>
-__device__ __forceinline__ void split_tile_read(const uint4* As, const uint4* Bs, SplitFrags& f) {
+__device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs, SplitFrags& f) {
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     f.a[s][0] = As[s * PA]; f.a[s][1] = As[s * PA + 32];
@@ -694,11 +700,19 @@ __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&ac
 }
 
 // fwd / dgrad:  C_b = epi( A . B_b ),  A = split weight image (g.A, batch stride g.a_bs chunks),
-// B_b[K,N] fp32 with n contiguous
-__global__ void __launch_bounds__(256, 3)
+// B_b[K,N] fp32 with n contiguous.
+//
+// Pipeline per k-tile t (one barrier per tile, two LDS stages):
+//   fragment reads of t  ->  weight DMA of t+1, activation loads of t+2 (registers, two sets used
+//   alternately: the loop is unrolled by two so that each set is a fixed register range)  ->
+//   the 24 MFMAs of t with the bf16 split of t+1's activations interleaved between them
+//   (sched_group_barrier: the VALU work issues in the shadow of the MFMAs of the same wave)  ->
+//   ds_write of t+1  ->  s_waitcnt vmcnt(8): the DMA has landed, the loads of t+2 stay in flight.
+//
+__global__ void __launch_bounds__(256, 2)
 pw_gemm_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  uint4* img = reinterpret_cast<uint4*>(lds);        // [2 stages][A|B][SIMG]
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A|B][SIMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -714,42 +728,39 @@ pw_gemm_split_kernel(GemmArgs g) {
   const int m0 = mt * BM, n0 = nt * BN;
   const int T = (g.K + SBK - 1) / SBK;
 
-  const uint4* Ag = reinterpret_cast<const uint4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
   // k-half staged by this thread's wave (waves 0,1 -> 0; 2,3 -> 1): row addresses stay scalar
   const int bh = __builtin_amdgcn_readfirstlane(tid >> 7);
   const float* Bb = g.B + (int64_t)bz * g.b_bs;
   const int bn = min(n0 + (tid & 127), g.N - 1);
 
-  float xb[8];
-  auto issueA = [&](int t, int st) {
-    const uint4* a = Ag + (int64_t)t * SIMG;
-    uint4* la = img + st * 2 * SIMG + wave * 64;
+  float xb[2][8];
+  auto issueA = [&](int t, int st) __attribute__((always_inline)) {
+    const u32x4* a = Ag + (int64_t)t * SIMG;
+    u32x4* la = img + st * 2 * SIMG + wave * 64;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a + i * 256), (lds_ptr_t)(la + i * 256), 16, 0, 0);
   };
-  // loads only (no use of the values here: a use would put an s_waitcnt vmcnt(0) in front of the MFMAs)
-  auto fetchB = [&](int t) {
+  // loads only (no use of the values here: a use would put an s_waitcnt vmcnt(0) in front of the MFMAs);
+  // scalar row pointer that stops advancing at row K-1 (rows beyond K are zeroed before the split)
+  auto fetchB = [&](int t, float (&x)[8]) __attribute__((always_inline)) {
     const int k0 = t * SBK + bh * 8;
-    if (k0 + 8 <= g.K) {
+    const float* p = Bb + (int64_t)min(k0, g.K - 1) * g.ldb;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xb[j] = (Bb + (int64_t)(k0 + j) * g.ldb)[bn];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xb[j] = (Bb + (int64_t)min(k0 + j, g.K - 1) * g.ldb)[bn];
+    for (int j = 0; j < 8; ++j) {
+      x[j] = p[bn];
+      p += (k0 + j + 1 < g.K) ? g.ldb : 0;
     }
   };
-  auto storeB = [&](int t, int st) {
-    const int valid = g.K - (t * SBK + bh * 8);     // rows beyond K are zero (the weight image is zero there too,
-    if (valid < 8) {                                //  but 0 * garbage could be NaN)
+  // rows beyond K are zero (the weight image is zero there too, but 0 * garbage could be NaN); branch-free
+  // so that the split stays in the basic block of the MFMAs it is interleaved with
+  auto zero_tail = [&](int t, float (&x)[8]) __attribute__((always_inline)) {
+    const int valid = g.K - (t * SBK + bh * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xb[j] = (j < valid) ? xb[j] : 0.f;
-    }
-    uint4 h, m, l;
-    split8(xb, h, m, l);
-    uint4* o = img + (st * 2 + 1) * SIMG + bh * SCH + (tid & 127);
-    o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+    for (int j = 0; j < 8; ++j) x[j] = (j < valid) ? x[j] : 0.f;
   };
+  u32x4* const Bst = img + SIMG + bh * SCH + (tid & 127);   // this thread's chunk in the B image of stage 0
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -760,50 +771,76 @@ pw_gemm_split_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   issueA(0, 0);
-  fetchB(0);
-  storeB(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  fetchB(0, xb[0]);
+  if (T > 1) fetchB(1, xb[1]);
+  {
+    zero_tail(0, xb[0]);
+    u32x4 h, m, l;
+    split8(xb[0], h, m, l);
+    Bst[0] = h; Bst[2 * SCH] = m; Bst[4 * SCH] = l;
+  }
+  if (T > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < T; ++t) {
-    const int cur = t & 1;
-    // diagnostic ablations (tools/gemm_variants.py): SPLIT_NO_FETCH / _DMA / _LDSREAD / _STORE / _BARRIER / _EPILOGUE
-#ifndef SPLIT_NO_FETCH
-    if (t + 1 < T) fetchB(t + 1);
-#endif
-    const uint4* As = img + cur * 2 * SIMG + lh * SCH + wm * 64 + li;
-    const uint4* Bs = img + (cur * 2 + 1) * SIMG + lh * SCH + wn * 64 + li;
+  // diagnostic ablations (tools/gemm_variants.py): SPLIT_NO_FETCH / _DMA / _LDSREAD / _STORE / _BARRIER / _EPILOGUE / _INTERLEAVE
+  auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
+    const u32x4* As = img + cur * 2 * SIMG + lh * SCH + wm * 64 + li;
+    const u32x4* Bs = img + (cur * 2 + 1) * SIMG + lh * SCH + wn * 64 + li;
     SplitFrags f;
 #ifdef SPLIT_NO_LDSREAD
 #pragma unroll
     for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
       for (int i_ = 0; i_ < 2; ++i_) {
-        f.a[s_][i_] = make_uint4(0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u);
-        f.b[s_][i_] = make_uint4(0x3f803f80u, 0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + s_);
+        f.a[s_][i_] = (u32x4){0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u};
+        f.b[s_][i_] = (u32x4){0x3f803f80u, 0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + (uint32_t)s_};
       }
     (void)As; (void)Bs;
 #else
     split_tile_read<2 * SCH, 2 * SCH>(As, Bs, f);
 #endif
     // The weight DMA goes after the fragment reads: the compiler waits for every pending LDS-DMA
-    // (vmcnt) in front of a ds_read that follows it, which would also wait for fetchB's loads.
+    // (vmcnt) in front of a ds_read that follows it.
     __builtin_amdgcn_sched_barrier(0);
 #ifndef SPLIT_NO_DMA
     if (t + 1 < T) issueA(t + 1, cur ^ 1);
 #endif
-    __builtin_amdgcn_sched_barrier(0);
-    split_tile_mfma(f, acc);
-#ifndef SPLIT_NO_STORE
-    if (t + 1 < T) storeB(t + 1, cur ^ 1);
+#ifndef SPLIT_NO_FETCH
+    if (t + 2 < T) fetchB(t + 2, xload);
 #endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < T) {
+      split_tile_mfma(f, acc);
+#ifndef SPLIT_NO_STORE
+      zero_tail(t + 1, xsplit);
+      u32x4 h, m, l;
+      split8(xsplit, h, m, l);
+#ifndef SPLIT_NO_INTERLEAVE
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU of the split
+      }
+#endif
+      u32x4* o = Bst + (cur ^ 1) * 2 * SIMG;
+      o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+#endif
+    } else {
+      split_tile_mfma(f, acc);
+    }
 #ifndef SPLIT_NO_BARRIER
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA'd weight tile has landed
+    if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // DMA of t+1 landed; loads of t+2 in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, 0, xb[0], xb[1]);
+    if (t + 1 < T) step(t + 1, 1, xb[1], xb[0]);
   }
 #ifdef SPLIT_NO_EPILOGUE
-  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] + xb[0] == 123.456f) g.C[0] = 1.f;
+  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] + xb[0][0] + xb[1][0] == 123.456f) g.C[0] = 1.f;
   return;
 #endif
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
@@ -815,7 +852,7 @@ pw_gemm_split_kernel(GemmArgs g) {
 __global__ void __launch_bounds__(256, 3)
 pw_gemm_wgrad_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  uint4* img = reinterpret_cast<uint4*>(lds);        // [2 stages][A|B][SIMGP]
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A|B][SIMGP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -853,9 +890,9 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     const float xa[8] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w, ra[1].x, ra[1].y, ra[1].z, ra[1].w};
     const float xb[8] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w, rb[1].x, rb[1].y, rb[1].z, rb[1].w};
     if (do_rowsum) rs += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
-    uint4 h, m, l;
+    u32x4 h, m, l;
     split8(xa, h, m, l);
-    uint4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
+    u32x4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
     o[0] = h; o[2 * SCHP] = m; o[4 * SCHP] = l;
     split8(xb, h, m, l);
     o += SIMGP;
@@ -875,8 +912,8 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1;
     if (t + 1 < T) fetch(t + 1);
-    const uint4* As = img + cur * 2 * SIMGP + lh * SCHP + wm * 64 + li;
-    const uint4* Bs = img + (cur * 2 + 1) * SIMGP + lh * SCHP + wn * 64 + li;
+    const u32x4* As = img + cur * 2 * SIMGP + lh * SCHP + wm * 64 + li;
+    const u32x4* Bs = img + (cur * 2 + 1) * SIMGP + lh * SCHP + wn * 64 + li;
     SplitFrags f;
     split_tile_read<2 * SCHP, 2 * SCHP>(As, Bs, f);
     split_tile_mfma(f, acc);
@@ -967,6 +1004,11 @@ int64_t split_image_chunks(int M, int K) {
   return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * SIMG;
 }
 
+int launch_split(const GemmArgs& d, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, st, d);
+  return 0;
+}
+
 int check_gemm(const char* name, int B, int M, int K, int N) {
   PD_REQUIRE(B >= 0 && M >= 1 && K >= 1 && N >= 1, "%s: bad shape B=%d M=%d K=%d N=%d", name, B, M, K, N);
   const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * std::max(B, 1);
@@ -1000,7 +1042,7 @@ extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int t
   const int blocks = (int)std::min<int64_t>((units + 255) / 256, 4096);
   hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
                      (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units,
-                     (int64_t)0, (int64_t)0, (uint4*)out);
+                     (int64_t)0, (int64_t)0, (u32x4*)out);
   PD_CHECK_LAUNCH("pw_gemm_split_weights");
   return 0;
 }
@@ -1027,7 +1069,7 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
   if (Wsplit != nullptr) {   // bf16-split image of the weights: split kernel (any shape)
     GemmArgs d = g;
     d.A = (const float*)Wsplit; d.a_bs = 0;
-    hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, (hipStream_t)stream, d);
+    if (int e = launch_split(d, grid, (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("pw_gemm_fwd(split)");
     return 0;
   }
@@ -1094,7 +1136,7 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const
   if (WTsplit != nullptr) {   // bf16-split image of W^T
     GemmArgs d = g;
     d.A = (const float*)WTsplit; d.a_bs = 0;
-    hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, (hipStream_t)stream, d);
+    if (int e = launch_split(d, grid, (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("pw_gemm_dgrad(split)");
     return 0;
   }
