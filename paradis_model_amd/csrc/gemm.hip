@@ -1004,7 +1004,8 @@ int64_t split_image_chunks(int M, int K) {
   return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * SIMG;
 }
 
-int launch_split(const GemmArgs& d, int grid, hipStream_t st) {
+int launch_split(const GemmArgs& d, hipStream_t st) {
+  const int grid = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.nbatch;
   hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, st, d);
   return 0;
 }
@@ -1069,7 +1070,7 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
   if (Wsplit != nullptr) {   // bf16-split image of the weights: split kernel (any shape)
     GemmArgs d = g;
     d.A = (const float*)Wsplit; d.a_bs = 0;
-    if (int e = launch_split(d, grid, (hipStream_t)stream)) return e;
+    if (int e = launch_split(d, (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("pw_gemm_fwd(split)");
     return 0;
   }
@@ -1136,7 +1137,7 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const
   if (WTsplit != nullptr) {   // bf16-split image of W^T
     GemmArgs d = g;
     d.A = (const float*)WTsplit; d.a_bs = 0;
-    if (int e = launch_split(d, grid, (hipStream_t)stream)) return e;
+    if (int e = launch_split(d, (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("pw_gemm_dgrad(split)");
     return 0;
   }

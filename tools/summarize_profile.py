@@ -59,30 +59,41 @@ json.dump(traffic, open(os.path.join(DST, f"{TAG}_traffic.json"), "w"), indent=1
 
 # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs) against
 # GRBM_GUI_ACTIVE (summed over the 8 XCDs) x 256 CUs x 4 SIMDs
-mfma = {}
+mfma, clock = {}, {}
 path = one("mfma/**/*_counter_collection.csv")
 if path:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(path)):
-        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        a = agg[short(r["Kernel_Name"])]
+        a[r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            a["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     for k, c in agg.items():
         if c.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
             mfma[k] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
-    mfma = {k: round(v, 4) for k, v in mfma.items() if v >= 0.005}
+            # effective shader clock held during the kernel (MI355X_MICROARCH.md, DVFS give-back):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; reads high on dispatches shorter than ~0.3 ms
+            if c["_ns"] > 0:
+                clock[k] = c["GRBM_GUI_ACTIVE"] / 8.0 / c["_ns"]
+    keep = {k for k, v in mfma.items() if v >= 0.005}
+    mfma = {k: round(v, 4) for k, v in mfma.items() if k in keep}
+    clock = {k: round(v, 3) for k, v in clock.items() if k in keep}
     json.dump(mfma, open(os.path.join(DST, f"{TAG}_mfma_busy.json"), "w"), indent=1, sort_keys=True)
+    json.dump(clock, open(os.path.join(DST, f"{TAG}_mfma_clock_ghz.json"), "w"), indent=1, sort_keys=True)
 
 tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
 with open(os.path.join(DST, f"{TAG}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary {TAG}\n\ncommand: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
             f"--no-kernel-events` (4 training steps traced)\n\n")
-    f.write("| kernel | calls | total ms | avg us | % | HBM MB/launch (PMC, corrected) | MFMA busy (PMC) |\n"
-            "|---|---|---|---|---|---|---|\n")
+    f.write("| kernel | calls | total ms | avg us | % | HBM MB/launch (PMC, corrected) | MFMA busy (PMC) | clock GHz (PMC pass) |\n"
+            "|---|---|---|---|---|---|---|---|\n")
     for r in rows[:30]:
         k = short(r["Name"])
         hb = traffic.get(k, {}).get("hbm_bytes_per_launch")
         f.write(f"| `{k}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
                 f"{float(r['AverageNs']) / 1e3:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f} | "
                 f"{'' if hb is None else f'{hb / 1e6:.1f}'} | "
-                f"{'' if k not in mfma or mfma[k] < 0.005 else f'{100 * mfma[k]:.0f} %'} |\n")
+                f"{'' if k not in mfma or mfma[k] < 0.005 else f'{100 * mfma[k]:.0f} %'} | "
+                f"{'' if k not in clock else f'{clock[k]:.2f}'} |\n")
     f.write(f"\ntotal kernel time: {tot / 1e6:.1f} ms\n")
 print("wrote profiles for", TAG)
