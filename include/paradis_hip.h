@@ -223,11 +223,13 @@ void paradis_debug_set_wgrad_dma(int stages);
 size_t paradis_muon_ws_bytes(int T, int rows, int cols);
 int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, int rows, int cols, float lr,
                       float lr_adj, float mu, float beta2, float weight_decay, float eps, int nesterov,
-                      int normuon, void* workspace, void* stream);
+                      int normuon, int split /* Newton-Schulz products on the bf16-split GEMM */,
+                      void* workspace, void* stream);
 /* Plain batched GEMM C_b[M,N] = A_b[M,K] B_b[K,N] (row-major; AT = optional [K,M] transposes of A_b,
- * enabling the LDS-DMA kernel) used by the Newton-Schulz iteration. */
+ * enabling the LDS-DMA kernel; split_ws = optional nbatch * paradis_pw_gemm_split_bytes(M,K) bytes of
+ * scratch selecting the bf16-split arithmetic) used by the Newton-Schulz iteration. */
 int paradis_bgemm(const float* A, const float* AT, const float* B, float* C, int nbatch, int M, int K, int N,
-                  int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs, void* stream);
+                  int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs, void* split_ws, void* stream);
 
 /* ---- f4: data feed on the device --------------------------------------------------------------
  * Forcings of B series of T consecutive timestamps each, every series as the dataset assembles one

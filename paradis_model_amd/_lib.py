@@ -76,8 +76,8 @@ SIGNATURES = {
     "paradis_copy_channels": (I, [P, L, P, L, I, L, P]),
     "paradis_adamw_step": (I, [P, P, P, P, L, F, F, F, F, F, I, P]),
     "paradis_muon_ws_bytes": (S, [I, I, I]),
-    "paradis_muon_step": (I, [P, I, I, I, I, F, F, F, F, F, F, I, I, P, P]),
-    "paradis_bgemm": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P]),
+    "paradis_muon_step": (I, [P, I, I, I, I, F, F, F, F, F, F, I, I, I, P, P]),
+    "paradis_bgemm": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P, P]),
     "paradis_adamw_chunk": (I, []),
     "paradis_adamw_multi": (I, [P, P, P, P, I, I, F, F, F, F, F, I, P]),
     "paradis_debug_set_norm_fwd_px": (None, [I]),

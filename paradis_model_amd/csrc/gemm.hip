@@ -1090,11 +1090,12 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
 
 // Plain batched GEMM  C_b[M,N] = A_b[M,K] B_b[K,N]  (row-major, batch strides in elements) on the same
 // kernels; AT (optional) = the [K,M] transposes of A_b with batch stride at_bs, which lets the LDS-DMA
-// kernel run.  Used by the Newton-Schulz iteration of the Muon step (muon.hip): same-shape weight
+// kernel run; split_ws (optional, nbatch * paradis_pw_gemm_split_bytes(M,K) bytes) selects the bf16-split
+// arithmetic instead (the A matrices are split into it first).  Used by the Newton-Schulz iteration of the Muon step (muon.hip): same-shape weight
 // matrices are stacked so that one launch fills the chip (a single 896^3 product is 49 tiles).
 extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, float* C, int nbatch, int M,
                              int K, int N, int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs,
-                             void* stream) {
+                             void* split_ws, void* stream) {
   PD_REQUIRE(nbatch >= 0 && M >= 1 && K >= 1 && N >= 1, "bgemm: bad shape");
   if (nbatch == 0) return 0;
   GemmArgs g{};
@@ -1105,6 +1106,19 @@ extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, f
   const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nbatch;
   PD_REQUIRE(tiles < (1ll << 31), "bgemm: too many tiles");
   const int grid = (int)tiles;
+  if (split_ws != nullptr) {   // bf16-split path: images of the nbatch A matrices in split_ws
+    PD_REQUIRE(nbatch <= 65535, "bgemm: too many batches for the split path");
+    const int KT = (K + SBK - 1) / SBK;
+    const int64_t chunks = split_image_chunks(M, K), units = (int64_t)((M + BM - 1) / BM) * KT * 256;
+    const int blocks = (int)std::min<int64_t>((units + 255) / 256, 1024);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, nbatch), dim3(256), 0, (hipStream_t)stream, A,
+                       (int64_t)K, (int64_t)1, M, K, KT, units, a_bs, chunks, (u32x4*)split_ws);
+    GemmArgs d = g;
+    d.A = (const float*)split_ws; d.a_bs = chunks;
+    if (int e = launch_split(d, (hipStream_t)stream)) return e;
+    PD_CHECK_LAUNCH("bgemm(split)");
+    return 0;
+  }
   if (AT != nullptr) {
     GemmArgs d = g;
     d.A = AT; d.lda = M; d.a_bs = at_bs;

@@ -8,7 +8,8 @@
 //   NorMuon only: v <- beta2 v + (1-beta2) rowmean(X^2);  X <- X / (sqrt(v)+1e-8), rescaled to the
 //                 Frobenius norm it had before
 //   W <- W (1 - lr wd) - lr_adj X
-// dion runs the iteration in bf16 through Triton; here it is fp32 on the FP32 MFMA GEMM of gemm.hip
+// dion runs the iteration in bf16 through Triton; here it is fp32 on the GEMMs of gemm.hip (exact f32 MFMA
+// or the bf16-split arithmetic, as the caller's pointwise GEMMs)
 // (a X + B X is computed as (B + a I) X, so the GEMM needs no scaled epilogue).  All scalars (norms)
 // stay on the device: no host synchronisation.
 #include <math.h>
@@ -16,7 +17,8 @@
 
 extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, float* C, int nbatch, int M,
                              int K, int N, int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs,
-                             void* stream);
+                             void* split_ws, void* stream);
+extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K);
 
 namespace {
 
@@ -155,8 +157,10 @@ inline size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
 extern "C" size_t paradis_muon_ws_bytes(int T, int rows, int cols) {
   if (T <= 0 || rows <= 0 || cols <= 0) return 256;
   const size_t n = (size_t)rows * cols, m = (size_t)std::min(rows, cols);
-  // U, X, XT, Xnew (T x n each), A, A2, B' (T x m x m each), scalars
-  return ((up64(n * T)) * 4 + up64(m * m * T) * 3 + up64(3 * (size_t)T) + 64) * sizeof(float);
+  // U, X, XT, Xnew (T x n each), A, A2, B' (T x m x m each), scalars; then the bf16-split images of the
+  // left operands of the Newton-Schulz products (T x [m, max(rows, cols)], 256-B aligned)
+  const size_t floats = (up64(n * T)) * 4 + up64(m * m * T) * 3 + up64(3 * (size_t)T) + 64;
+  return floats * sizeof(float) + (size_t)T * paradis_pw_gemm_split_bytes((int)m, std::max(rows, cols)) + 256;
 }
 
 // One Muon (normuon = 0) or NorMuon (normuon = 1) step on T same-shaped weight matrices w_t[rows, cols]
@@ -165,7 +169,7 @@ extern "C" size_t paradis_muon_ws_bytes(int T, int rows, int cols) {
 // Muon), this group's entries first.  lr_adj = the shape-adjusted learning rate.
 extern "C" int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, int rows, int cols, float lr,
                                  float lr_adj, float mu, float beta2, float weight_decay, float eps,
-                                 int nesterov, int normuon, void* workspace, void* stream) {
+                                 int nesterov, int normuon, int split, void* workspace, void* stream) {
   PD_REQUIRE(T >= 0 && rows >= 1 && cols >= 1 && table_stride >= T, "muon_step: bad shape");
   if (T == 0) return 0;
   PD_REQUIRE(ptrs != nullptr && workspace != nullptr, "muon_step: table / workspace required");
@@ -185,6 +189,10 @@ extern "C" int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, i
   float* A2 = ws;                ws += up64((size_t)mm * T);
   float* Bp = ws;                ws += up64((size_t)mm * T);
   float* sc = ws;                // [T] sum u^2, then [2T] NorMuon sums
+  ws += up64(3 * (size_t)T) + 64;
+  // split != 0: the three products of every iteration run on the bf16-split GEMM (gemm.hip); the images
+  // of their left operands ([M,K] or [M,M], K >= M) live behind the float workspace
+  void* img = split ? (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
   if (hipMemsetAsync(sc, 0, 3 * (size_t)T * sizeof(float), st) != hipSuccess) {
     paradis_set_error("muon_step: memset failed");
     return 2;
@@ -207,12 +215,12 @@ extern "C" int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, i
     transpose(cur, XT, M, K);                                                                           // XT [K, M]
     // A = X X^T : [M,K] x [K,M].  The transposed left operand each product needs for the LDS-DMA kernel
     // is at hand: X^T here, and A and B' below are symmetric.
-    if (int e = paradis_bgemm(cur, XT, XT, A, T, M, K, M, n, n, n, mm, stream)) return e;
-    if (int e = paradis_bgemm(A, A, A, A2, T, M, M, M, mm, mm, mm, mm, stream)) return e;
+    if (int e = paradis_bgemm(cur, XT, XT, A, T, M, K, M, n, n, n, mm, img, stream)) return e;
+    if (int e = paradis_bgemm(A, A, A, A2, T, M, M, M, mm, mm, mm, mm, img, stream)) return e;
     hipLaunchKernelGGL(muon_poly_kernel, dim3(blocks(mm), T), dim3(256), 0, st, (const float*)A, (const float*)A2,
                        Bp, M, NS_A[it], NS_B[it], NS_C[it]);
     // X <- (b A + c A^2 + a I) X : [M,M] x [M,K]
-    if (int e = paradis_bgemm(Bp, Bp, cur, nxt, T, M, M, K, mm, mm, n, n, stream)) return e;
+    if (int e = paradis_bgemm(Bp, Bp, cur, nxt, T, M, M, K, mm, mm, n, n, img, stream)) return e;
     std::swap(cur, nxt);
   }
   // cur = orthogonalised updates in the wide orientation; element (r, c) of the [rows, cols] matrix is

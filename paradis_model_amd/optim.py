@@ -6,6 +6,7 @@ import ctypes
 
 import torch
 
+from . import ops
 from ._lib import check, dptr, lib, require_hip, stream_ptr
 
 
@@ -132,7 +133,7 @@ class Muon(AdamW):
     """Muon with the constructor of ``dion.Muon`` as the reference calls it (trainer.py:347-354):
     parameter groups carry ``algorithm`` ("muon" / "normuon" for 2-D-flattened weights, "adamw" for
     the rest, see ``build_param_groups``).  The matrix update runs in one C-ABI call per weight
-    (``paradis_muon_step``: fp32 MFMA Newton-Schulz, no Triton); AdamW groups use the fused kernel
+    (``paradis_muon_step``: fp32 Newton-Schulz on the GEMMs of ``ops`` - bf16-split or exact f32 MFMA as ``ops.GEMM_SPLIT`` says - no Triton); AdamW groups use the fused kernel
     of the base class.  ``dion`` is neither vendored nor pinned by the reference: the algorithm is
     restated from its published form (oracle/muon_oracle.py), parity unpinned."""
 
@@ -244,7 +245,8 @@ class Muon(AdamW):
             check(lib.paradis_muon_step(ctypes.c_void_p(base + 8 * off), T, n, rows, cols, lr,
                                         _adjusted_lr(lr, full, group["adjust_lr"]), group["mu"],
                                         group["muon_beta2"], group["weight_decay"], group["eps"],
-                                        int(bool(group["nesterov"])), int(normuon), dptr(c["ws"]), st),
+                                        int(bool(group["nesterov"])), int(normuon),
+                                        1 if ops.GEMM_SPLIT else 0, dptr(c["ws"]), st),
                   "muon_step")
 
 

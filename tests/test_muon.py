@@ -47,19 +47,22 @@ def test_param_groups_mirror_reference_rule():
 def test_abi_validation_without_gpu():
     from paradis_model_amd import _lib
     L = _lib.lib
-    assert L.paradis_muon_step(None, 2, 2, 0, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, None, None) == 1
-    assert L.paradis_muon_step(None, 1, 2, 4, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, None, None) == 1   # stride < T
-    assert L.paradis_muon_step(None, 2, 2, 4, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, None, None) == 1
+    assert L.paradis_muon_step(None, 2, 2, 0, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, 0, None, None) == 1
+    assert L.paradis_muon_step(None, 1, 2, 4, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, 0, None, None) == 1   # stride < T
+    assert L.paradis_muon_step(None, 2, 2, 4, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, 0, None, None) == 1
     assert "workspace" in _lib.last_error()
-    assert L.paradis_muon_step(None, 2, 0, 4, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, None, None) == 0    # empty group
+    assert L.paradis_muon_step(None, 2, 0, 4, 4, 0.1, 0.1, 0.95, 0.95, 0.0, 1e-8, 0, 0, 0, None, None) == 0    # empty group
     assert L.paradis_muon_ws_bytes(3, 64, 48) >= 3 * (4 * 64 * 48 + 3 * 48 * 48) * 4
-    assert L.paradis_bgemm(None, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None) == 1
+    assert L.paradis_bgemm(None, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None, None) == 1
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cls_name,nesterov", [("Muon", False), ("Muon", True), ("NorMuon", False)])
-def test_hip_step_vs_oracle(cls_name, nesterov):
-    from paradis_model_amd import optim
+@pytest.mark.parametrize("split", [True, False])
+def test_hip_step_vs_oracle(cls_name, nesterov, split, monkeypatch):
+    """Both arithmetics of the Newton-Schulz products (bf16-split / exact f32 MFMA) against the oracle."""
+    from paradis_model_amd import ops, optim
+    monkeypatch.setattr(ops, "GEMM_SPLIT", split)
     torch.manual_seed(1)
     # two matrices share a shape (stacked in one launch); wide, tall, conv, depthwise, ragged
     shapes = [(64, 48), (48, 64), (64, 48), (32, 16, 1, 1), (40, 1, 3, 3), (20, 8), (130, 258)]
