@@ -146,6 +146,8 @@ def main():
                     help="adamw = the measured configuration (SURVEY 8d); normuon = the reference's shipped default")
     ap.add_argument("--gemm", default=os.environ.get("PARADIS_GEMM", "split"), choices=["split", "exact"],
                     help="pointwise GEMM arithmetic: exact 3-way bf16 split on the bf16 MFMA (default) or f32 MFMA")
+    ap.add_argument("--no-exact-leg", action="store_true",
+                    help="skip the second timed loop with the exact f32-MFMA GEMMs (reported as exact_f32_gemm)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
@@ -211,6 +213,25 @@ def main():
     _lib.PROFILER = None
     elapsed = max_over_ranks(elapsed, dev)
 
+    # The same K steps with the exact f32-MFMA GEMMs, timed the same way and reported beside the headline
+    # (`value` is the default arithmetic: fp32 through the bf16 split).
+    exact = None
+    if args.gemm == "split" and not args.no_exact_leg:
+        ops.GEMM_SPLIT = False
+        for _ in range(min(args.warmup, 2)):
+            step(batch)
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(batch)
+        torch.cuda.synchronize()
+        barrier()
+        e_exact = max_over_ranks(time.perf_counter() - t1, dev)
+        ops.GEMM_SPLIT = True
+        exact = {"value": world * B * args.steps / e_exact, "unit": "samples/s",
+                 "ms_per_step": 1e3 * e_exact / args.steps, "gemm_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+
     metric = "training samples/sec (whole node) on 5.625deg ERA5 grid, 1/2/4/8 MI355X"
     try:   # use BASELINE.json's exact wording when the file travels with the repo
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
@@ -268,6 +289,8 @@ def main():
                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
                              "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
                              "bytes_per_launch": r["work"] / r["launches"]}
+    if exact is not None:
+        out["exact_f32_gemm"] = exact
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=8)
     if rank == 0:

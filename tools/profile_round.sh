@@ -6,7 +6,7 @@
 # Summaries are then written by tools/summarize_profile.py into profiles/.
 TAG=${1:-r01}
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events"
+CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-exact-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/stats -- $CMD > $R/gpurun_out/prof_$TAG.stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_$TAG/fetch -- $CMD > $R/gpurun_out/prof_$TAG.fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_$TAG/write -- $CMD > $R/gpurun_out/prof_$TAG.write.log 2>&1

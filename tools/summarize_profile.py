@@ -84,7 +84,7 @@ if path:
 tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
 with open(os.path.join(DST, f"{TAG}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary {TAG}\n\ncommand: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-            f"--no-kernel-events` (4 training steps traced)\n\n")
+            f"--no-kernel-events --no-exact-leg` (4 training steps traced)\n\n")
     f.write("| kernel | calls | total ms | avg us | % | HBM MB/launch (PMC, corrected) | MFMA busy (PMC) | clock GHz (PMC pass) |\n"
             "|---|---|---|---|---|---|---|---|\n")
     for r in rows[:30]:
