@@ -673,7 +673,18 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 }
 
 #define SPLIT_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
-// six partial products of one 32x32 block pair, smallest first
+// The six partial products of one 32x32 block, smallest first within a block and ordered so that
+// consecutive MFMAs share an operand register (snaking FWD / REV over the four blocks of a wave tile).
+// Against an order that changes both operands at every instruction (SPLIT_ORDER=0) this measured +0.5 %,
+// i.e. nothing, once the A/B alternated the variants (tools/gemm_variants.py: a fixed order of variants
+// shows 3-5 % in favour of whichever runs later).
+#define SPLIT_FWD(AH, AM, AL, BH, BM_, BL, C) \
+  SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AM, BH, C); SPLIT_MFMA(AL, BH, C); \
+  SPLIT_MFMA(AH, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BL, C)
+#define SPLIT_REV(AH, AM, AL, BH, BM_, BL, C) \
+  SPLIT_MFMA(AH, BL, C); SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C); \
+  SPLIT_MFMA(AL, BH, C);  SPLIT_MFMA(AM, BH, C); SPLIT_MFMA(AM, BM_, C)
+// diagnostic order: both operands change at every instruction
 #define SPLIT_BLOCK(AH, AM, AL, BH, BM_, BL, C) \
   SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AL, BH, C); SPLIT_MFMA(AH, BL, C); \
   SPLIT_MFMA(AM, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C)
@@ -691,12 +702,19 @@ __device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs
 }
 // ... then the 24 MFMAs
 __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&acc)[2][2]) {
+#if defined(SPLIT_ORDER) && SPLIT_ORDER == 0
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       SPLIT_BLOCK(f.a[0][tm], f.a[1][tm], f.a[2][tm], f.b[0][tn], f.b[1][tn], f.b[2][tn], acc[tm][tn]);
     }
+#else
+  SPLIT_FWD(f.a[0][0], f.a[1][0], f.a[2][0], f.b[0][0], f.b[1][0], f.b[2][0], acc[0][0]);
+  SPLIT_REV(f.a[0][0], f.a[1][0], f.a[2][0], f.b[0][1], f.b[1][1], f.b[2][1], acc[0][1]);
+  SPLIT_FWD(f.a[0][1], f.a[1][1], f.a[2][1], f.b[0][1], f.b[1][1], f.b[2][1], acc[1][1]);
+  SPLIT_REV(f.a[0][1], f.a[1][1], f.a[2][1], f.b[0][0], f.b[1][0], f.b[2][0], acc[1][0]);
+#endif
 }
 
 // fwd / dgrad:  C_b = epi( A . B_b ),  A = split weight image (g.A, batch stride g.a_bs chunks),

@@ -26,6 +26,7 @@ VARIANTS = {"base": [], "base_dma": [], "dma_no_barrier": ["-DDMA_NO_BARRIER"], 
             "split_no_ldsread": ["-DSPLIT_NO_LDSREAD"], "split_no_store": ["-DSPLIT_NO_STORE"],
             "split_no_barrier": ["-DSPLIT_NO_BARRIER"], "split_no_epilogue": ["-DSPLIT_NO_EPILOGUE"],
             "split_no_interleave": ["-DSPLIT_NO_INTERLEAVE"],
+            "split_order0": ["-DSPLIT_ORDER=0"],
             "split_no_global": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA"],
             "split_no_global_store": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA", "-DSPLIT_NO_STORE"],
             "split_mfma_only": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA", "-DSPLIT_NO_STORE", "-DSPLIT_NO_LDSREAD",
@@ -71,29 +72,37 @@ def main():
     occ = [int(a) for a in sys.argv[1:]] or [4]
     for name, L in libs.items():
         L.paradis_debug_set_gemm.argtypes = [ctypes.c_int, ctypes.c_int]
+    rounds = int(os.environ.get("GEMM_ROUNDS", "8"))
     for wg in occ:
-      for L in libs.values():
-          L.paradis_debug_set_gemm(16, wg)
-      print("workgroups per CU:", wg)
-      for rnd in range(2):
-        for name, L in libs.items():
-            if name not in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") and wg != 4 and not name.startswith("split_"):
-                continue
-            # dma_* variants exercise the LDS-DMA kernel (transposed weights supplied), the others the
-            # register-staged kernel
-            wt_arg = p(wt) if name.startswith("dma_") or name == "base_dma" else None
-            sp_arg = p(wsp) if name.startswith("split_") else None
-            fn = lambda: L.paradis_pw_gemm_fwd(p(w), wt_arg, sp_arg, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
-            assert fn() == 0
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                fn()
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / 5 * 1e3
-            if rnd:
-                print(f"{name:22s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF")
+        for L in libs.values():
+            L.paradis_debug_set_gemm(16, wg)
+        print("workgroups per CU:", wg, "(median of", rounds, "alternating rounds of 10 launches; the order inside a"
+              " round is rotated: a variant's rate depends on what ran just before it)")
+        sel = [n for n in libs if n in ("base", "no_stage", "mfma_only", "no_gload", "unguarded") or wg == 4
+               or n.startswith("split_")]
+        times = {n: [] for n in sel}
+        for rnd in range(rounds + 1):
+            order = sel[rnd % len(sel):] + sel[:rnd % len(sel)]
+            for name in order:
+                L = libs[name]
+                # dma_* variants exercise the LDS-DMA kernel (transposed weights supplied), split_* the bf16-split
+                # kernel (weight image supplied), the others the register-staged kernel
+                wt_arg = p(wt) if name.startswith("dma_") or name == "base_dma" else None
+                sp_arg = p(wsp) if name.startswith("split_") else None
+                fn = lambda: L.paradis_pw_gemm_fwd(p(w), wt_arg, sp_arg, p(x), None, None, None, None, 0, None, p(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
+                assert fn() == 0
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                if rnd:
+                    times[name].append(e0.elapsed_time(e1) / 10 * 1e3)
+        for name in sel:
+            t = sorted(times[name])
+            us = t[len(t) // 2]
+            print(f"{name:22s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF   (min {t[0]:.1f}, max {t[-1]:.1f})")
 
 
 if __name__ == "__main__":
