@@ -673,18 +673,10 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 }
 
 #define SPLIT_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
-// The six partial products of one 32x32 block, smallest first within a block and ordered so that
-// consecutive MFMAs share an operand register (snaking FWD / REV over the four blocks of a wave tile).
-// Against an order that changes both operands at every instruction (SPLIT_ORDER=0) this measured +0.5 %,
-// i.e. nothing, once the A/B alternated the variants (tools/gemm_variants.py: a fixed order of variants
-// shows 3-5 % in favour of whichever runs later).
-#define SPLIT_FWD(AH, AM, AL, BH, BM_, BL, C) \
-  SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AM, BH, C); SPLIT_MFMA(AL, BH, C); \
-  SPLIT_MFMA(AH, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BL, C)
-#define SPLIT_REV(AH, AM, AL, BH, BM_, BL, C) \
-  SPLIT_MFMA(AH, BL, C); SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C); \
-  SPLIT_MFMA(AL, BH, C);  SPLIT_MFMA(AM, BH, C); SPLIT_MFMA(AM, BM_, C)
-// diagnostic order: both operands change at every instruction
+// The six partial products of one 32x32 block, smallest first.  (An order in which consecutive MFMAs
+// share an operand register, snaking over the four blocks of a wave tile, measured +0.5 % - nothing -
+// once the A/B alternated the variants; tools/gemm_variants.py: a fixed order of variants shows 3-5 %
+// in favour of whichever runs later.)
 #define SPLIT_BLOCK(AH, AM, AL, BH, BM_, BL, C) \
   SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AL, BH, C); SPLIT_MFMA(AH, BL, C); \
   SPLIT_MFMA(AM, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C)
@@ -702,19 +694,12 @@ __device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs
 }
 // ... then the 24 MFMAs
 __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&acc)[2][2]) {
-#if defined(SPLIT_ORDER) && SPLIT_ORDER == 0
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       SPLIT_BLOCK(f.a[0][tm], f.a[1][tm], f.a[2][tm], f.b[0][tn], f.b[1][tn], f.b[2][tn], acc[tm][tn]);
     }
-#else
-  SPLIT_FWD(f.a[0][0], f.a[1][0], f.a[2][0], f.b[0][0], f.b[1][0], f.b[2][0], acc[0][0]);
-  SPLIT_REV(f.a[0][0], f.a[1][0], f.a[2][0], f.b[0][1], f.b[1][1], f.b[2][1], acc[0][1]);
-  SPLIT_FWD(f.a[0][1], f.a[1][1], f.a[2][1], f.b[0][1], f.b[1][1], f.b[2][1], acc[1][1]);
-  SPLIT_REV(f.a[0][1], f.a[1][1], f.a[2][1], f.b[0][0], f.b[1][0], f.b[2][0], acc[1][0]);
-#endif
 }
 
 // fwd / dgrad:  C_b = epi( A . B_b ),  A = split weight image (g.A, batch stride g.a_bs chunks),
@@ -727,7 +712,7 @@ __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&ac
 //   (sched_group_barrier: the VALU work issues in the shadow of the MFMAs of the same wave)  ->
 //   ds_write of t+1  ->  s_waitcnt vmcnt(8): the DMA has landed, the loads of t+2 stay in flight.
 //
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 pw_gemm_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A|B][SIMG]
@@ -749,7 +734,13 @@ pw_gemm_split_kernel(GemmArgs g) {
   const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
   // k-half staged by this thread's wave (waves 0,1 -> 0; 2,3 -> 1): row addresses stay scalar
   const int bh = __builtin_amdgcn_readfirstlane(tid >> 7);
-  const float* Bb = g.B + (int64_t)bz * g.b_bs;
+  // (uniform, but derived from integer divisions done on the vector unit: pin it to scalar registers)
+  const float* Bb;
+  {
+    const uint64_t a = reinterpret_cast<uint64_t>(g.B + (int64_t)bz * g.b_bs);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    Bb = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  }
   const int bn = min(n0 + (tid & 127), g.N - 1);
 
   float xb[2][8];
@@ -760,24 +751,28 @@ pw_gemm_split_kernel(GemmArgs g) {
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a + i * 256), (lds_ptr_t)(la + i * 256), 16, 0, 0);
   };
-  // loads only (no use of the values here: a use would put an s_waitcnt vmcnt(0) in front of the MFMAs);
-  // scalar row pointer that stops advancing at row K-1 (rows beyond K are zeroed before the split)
+  // Activation loads are issued from inline asm (saddr form: scalar row base + 32-bit lane offset, no
+  // vector address arithmetic) so that the compiler does not account for them: on this loop its own
+  // bookkeeping degrades to s_waitcnt vmcnt(0) in front of the first use, which would also wait for the
+  // loads of the tile after and for the weight DMA just issued.  The waits are counted by hand (use_x).
+  // Rows beyond K re-read row K-1: they meet the zero padding of the weight image, and finite x 0 = 0
+  // (a non-finite row K-1 poisons every output anyway), so no zero-fill is needed.
+  const uint32_t boff = (uint32_t)bn * 4u;
   auto fetchB = [&](int t, float (&x)[8]) __attribute__((always_inline)) {
     const int k0 = t * SBK + bh * 8;
     const float* p = Bb + (int64_t)min(k0, g.K - 1) * g.ldb;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      x[j] = p[bn];
+      asm volatile("global_load_dword %0, %1, %2" : "=&v"(x[j]) : "v"(boff), "s"(p) : "memory");
       p += (k0 + j + 1 < g.K) ? g.ldb : 0;
     }
   };
-  // rows beyond K are zero (the weight image is zero there too, but 0 * garbage could be NaN); branch-free
-  // so that the split stays in the basic block of the MFMAs it is interleaved with
-  auto zero_tail = [&](int t, float (&x)[8]) __attribute__((always_inline)) {
-    const int valid = g.K - (t * SBK + bh * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (j < valid) ? x[j] : 0.f;
-  };
+  // Wait until at most N vector-memory operations issued after x's loads are outstanding.  x is an INPUT
+  // of the asm (an in/out operand lets the compiler copy the not-yet-landed registers in front of the
+  // wait), and a sched_barrier behind it keeps every read of x below.
+#define USE_X(x, N) do { asm volatile("s_waitcnt vmcnt(" #N ")" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), \
+                                      "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]) : "memory");                  \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
   u32x4* const Bst = img + SIMG + bh * SCH + (tid & 127);   // this thread's chunk in the B image of stage 0
 
   f32x16 acc[2][2];
@@ -790,16 +785,16 @@ pw_gemm_split_kernel(GemmArgs g) {
 
   issueA(0, 0);
   fetchB(0, xb[0]);
-  if (T > 1) fetchB(1, xb[1]);
+  if (T > 1) { fetchB(1, xb[1]); USE_X(xb[0], 8); } else { USE_X(xb[0], 0); }
   {
-    zero_tail(0, xb[0]);
     u32x4 h, m, l;
     split8(xb[0], h, m, l);
     Bst[0] = h; Bst[2 * SCH] = m; Bst[4 * SCH] = l;
   }
-  if (T > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // raw barriers with counted waits: __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier and
+  // would make every barrier wait for the activation loads that are meant to stay in flight
+  if (T > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // diagnostic ablations (tools/gemm_variants.py): SPLIT_NO_FETCH / _DMA / _LDSREAD / _STORE / _BARRIER / _EPILOGUE / _INTERLEAVE
   auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
@@ -827,11 +822,15 @@ pw_gemm_split_kernel(GemmArgs g) {
 #ifndef SPLIT_NO_FETCH
     if (t + 2 < T) fetchB(t + 2, xload);
 #endif
+    // xsplit (tile t+1) was loaded a step ago; younger: 3 DMA + 8 loads of this step when both were issued
+    if (t + 2 < T) USE_X(xsplit, 11);
+    else USE_X(xsplit, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < T) {
-      split_tile_mfma(f, acc);
+    // One basic block for every tile, the last included (its split writes a stage that nobody reads any
+    // more): a second copy of the MFMA block behind a branch costs 32 accumulator moves per tile.
+    split_tile_mfma(f, acc);
 #ifndef SPLIT_NO_STORE
-      zero_tail(t + 1, xsplit);
+    {
       u32x4 h, m, l;
       split8(xsplit, h, m, l);
 #ifndef SPLIT_NO_INTERLEAVE
@@ -843,14 +842,12 @@ pw_gemm_split_kernel(GemmArgs g) {
 #endif
       u32x4* o = Bst + (cur ^ 1) * 2 * SIMG;
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
-#endif
-    } else {
-      split_tile_mfma(f, acc);
     }
+#endif
 #ifndef SPLIT_NO_BARRIER
-    if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // DMA of t+1 landed; loads of t+2 in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // DMA of t+1 landed, own ds_writes done, loads of t+2 still in flight
+    if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
   };
   for (int t = 0; t < T; t += 2) {

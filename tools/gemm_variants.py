@@ -26,7 +26,6 @@ VARIANTS = {"base": [], "base_dma": [], "dma_no_barrier": ["-DDMA_NO_BARRIER"], 
             "split_no_ldsread": ["-DSPLIT_NO_LDSREAD"], "split_no_store": ["-DSPLIT_NO_STORE"],
             "split_no_barrier": ["-DSPLIT_NO_BARRIER"], "split_no_epilogue": ["-DSPLIT_NO_EPILOGUE"],
             "split_no_interleave": ["-DSPLIT_NO_INTERLEAVE"],
-            "split_order0": ["-DSPLIT_ORDER=0"],
             "split_no_global": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA"],
             "split_no_global_store": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA", "-DSPLIT_NO_STORE"],
             "split_mfma_only": ["-DSPLIT_NO_FETCH", "-DSPLIT_NO_DMA", "-DSPLIT_NO_STORE", "-DSPLIT_NO_LDSREAD",
