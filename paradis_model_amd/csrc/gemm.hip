@@ -743,7 +743,7 @@ pw_gemm_split_kernel(GemmArgs g) {
   }
   const int bn = min(n0 + (tid & 127), g.N - 1);
 
-  float xb[2][8];
+  float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
   auto issueA = [&](int t, int st) __attribute__((always_inline)) {
     const u32x4* a = Ag + (int64_t)t * SIMG;
     u32x4* la = img + st * 2 * SIMG + wave * 64;
@@ -864,6 +864,11 @@ pw_gemm_split_kernel(GemmArgs g) {
 // wgrad: dW[M,N'] = sum over (sample, p) A[m][p] B[n][p], both operands p-contiguous fp32, both split
 // in registers.  Thread t stages 8 consecutive p of row t>>1 (k-half t&1) of each operand.
 // Needs K % 16 == 0 and 16-B aligned rows (host-checked; otherwise the f32 kernels run).
+// Same pipeline as the fwd/dgrad kernel: loads two tiles ahead into alternating register sets (inline asm,
+// counted waits), the two splits of tile t+1 between the MFMAs of tile t, raw barriers, one MFMA block
+// per tile.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ void __launch_bounds__(256, 3)
 pw_gemm_wgrad_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -890,28 +895,39 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
   const float* Ag = g.A + (int64_t)min(m0 + srow, g.M - 1) * g.lda + sh * 8;
   const float* Bg = g.B + (int64_t)min(n0 + srow, g.N - 1) * g.ldb + sh * 8;
 
-  float4 ra[2], rb[2];
-  auto fetch = [&](int t) {
-    const int tt = t_begin + t;
-    const int ib = tt / KT, kt = tt - ib * KT;
-    const float* a = Ag + (int64_t)ib * g.a_is + (int64_t)kt * SBK;
-    const float* b = Bg + (int64_t)ib * g.b_is + (int64_t)kt * SBK;
-    ra[0] = *reinterpret_cast<const float4*>(a); ra[1] = *reinterpret_cast<const float4*>(a + 4);
-    rb[0] = *reinterpret_cast<const float4*>(b); rb[1] = *reinterpret_cast<const float4*>(b + 4);
+  // (sample, k-tile) of the next tile to fetch, advanced incrementally
+  int f_ib = t_begin / KT, f_kt = t_begin - f_ib * KT;
+  struct Regs { f32x4 a0, a1, b0, b1; };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Regs r0{zero4, zero4, zero4, zero4}, r1 = r0;   // defined values: the surplus split of a one-tile range reads r1
+  auto fetch = [&](Regs& r) __attribute__((always_inline)) {
+    const float* a = Ag + (int64_t)f_ib * g.a_is + (int64_t)f_kt * SBK;
+    const float* b = Bg + (int64_t)f_ib * g.b_is + (int64_t)f_kt * SBK;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.a0) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(r.a1) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.b0) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(r.b1) : "v"(b) : "memory");
+    if (++f_kt == KT) { f_kt = 0; ++f_ib; }
   };
+  // at most N younger vector-memory operations outstanding; registers as asm inputs (see USE_X)
+#define USE_R(r, N) do { asm volatile("s_waitcnt vmcnt(" #N ")" :: "v"(r.a0), "v"(r.a1), "v"(r.b0), "v"(r.b1) : "memory"); \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
   const bool do_rowsum = g.rowsum != nullptr && nt == 0;
   float rs = 0.f;
-  auto store = [&](int st) {
-    const float xa[8] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w, ra[1].x, ra[1].y, ra[1].z, ra[1].w};
-    const float xb[8] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w, rb[1].x, rb[1].y, rb[1].z, rb[1].w};
-    if (do_rowsum) rs += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
-    u32x4 h, m, l;
-    split8(xa, h, m, l);
+  auto split_store = [&](const Regs& r, int st, bool keep) __attribute__((always_inline)) {
+    const float xa[8] = {r.a0.x, r.a0.y, r.a0.z, r.a0.w, r.a1.x, r.a1.y, r.a1.z, r.a1.w};
+    const float xb[8] = {r.b0.x, r.b0.y, r.b0.z, r.b0.w, r.b1.x, r.b1.y, r.b1.z, r.b1.w};
+    // bias gradient: row sums of the staged dY values (a select, not a product: the surplus split of the
+    // last tile works on stale registers that may hold NaNs)
+    const float add = ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+    rs += keep ? add : 0.f;
+    u32x4 ha, ma, la, hb, mb, lb;
+    split8(xa, ha, ma, la);
+    split8(xb, hb, mb, lb);
     u32x4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
-    o[0] = h; o[2 * SCHP] = m; o[4 * SCHP] = l;
-    split8(xb, h, m, l);
+    o[0] = ha; o[2 * SCHP] = ma; o[4 * SCHP] = la;
     o += SIMGP;
-    o[0] = h; o[2 * SCHP] = m; o[4 * SCHP] = l;
+    o[0] = hb; o[2 * SCHP] = mb; o[4 * SCHP] = lb;
   };
 
   f32x16 acc[2][2];
@@ -922,19 +938,36 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (T > 0) { fetch(0); store(0); }
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < T) fetch(t + 1);
+  if (T > 0) {
+    fetch(r0);
+    if (T > 1) { fetch(r1); USE_R(r0, 4); } else { USE_R(r0, 0); }
+    split_store(r0, 0, do_rowsum);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
     const u32x4* As = img + cur * 2 * SIMGP + lh * SCHP + wm * 64 + li;
     const u32x4* Bs = img + (cur * 2 + 1) * SIMGP + lh * SCHP + wn * 64 + li;
     SplitFrags f;
     split_tile_read<2 * SCHP, 2 * SCHP>(As, Bs, f);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < T) { fetch(rload); USE_R(rsplit, 4); }
+    else USE_R(rsplit, 0);
+    // one basic block for every tile; the last tile's split is surplus (stage nobody reads, keep = 0)
     split_tile_mfma(f, acc);
-    if (t + 1 < T) store(cur ^ 1);
-    __syncthreads();
+    split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the two splits
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, 0, r0, r1);
+    if (t + 1 < T) step(t + 1, 1, r1, r0);
   }
+#undef USE_R
   if (do_rowsum) {
     rs += __shfl_xor(rs, 1, 64);
     const int m = m0 + srow;
