@@ -13,7 +13,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparadis_hip.so")
+# PARADIS_HIP_LIB: diagnostic override (A/B of two builds of the same ABI on one box, tools/ab_step.sh)
+LIB_PATH = os.environ.get("PARADIS_HIP_LIB") or os.path.join(_HERE, "libparadis_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -833,11 +833,12 @@ pw_gemm_split_kernel(GemmArgs g) {
     {
       u32x4 h, m, l;
       split8(xsplit, h, m, l);
-#ifndef SPLIT_NO_INTERLEAVE
+#ifndef SPLIT_NO_INTERLEAVE   // one MFMA : three VALU of the split.  Isolated 1024^2 launches run 2.8 % faster
+      // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
 #pragma unroll
       for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU of the split
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
 #endif
       u32x4* o = Bst + (cur ^ 1) * 2 * SIMG;
