@@ -712,10 +712,14 @@ __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&ac
 //   (sched_group_barrier: the VALU work issues in the shadow of the MFMAs of the same wave)  ->
 //   ds_write of t+1  ->  s_waitcnt vmcnt(8): the DMA has landed, the loads of t+2 stay in flight.
 //
-__global__ void __launch_bounds__(256, 3)
+#ifndef SPLIT_ASTAGES
+#define SPLIT_ASTAGES 2   // weight-image ring depth (2: DMA one tile ahead, 48 KiB, 3 WGs/CU; 4: three ahead, 72 KiB, 2 WGs/CU)
+#endif
+__global__ void __launch_bounds__(256, SPLIT_ASTAGES == 2 ? 3 : 2)
 pw_gemm_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A|B][SIMG]
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 activation stages][SIMG] | [SPLIT_ASTAGES weight stages][SIMG]
+  constexpr int SA = SPLIT_ASTAGES, DA = SA - 1;     // weight ring depth, DMA distance in tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -744,9 +748,9 @@ pw_gemm_split_kernel(GemmArgs g) {
   const int bn = min(n0 + (tid & 127), g.N - 1);
 
   float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
-  auto issueA = [&](int t, int st) __attribute__((always_inline)) {
+  auto issueA = [&](int t) __attribute__((always_inline)) {
     const u32x4* a = Ag + (int64_t)t * SIMG;
-    u32x4* la = img + st * 2 * SIMG + wave * 64;
+    u32x4* la = img + (2 + t % SA) * SIMG + wave * 64;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a + i * 256), (lds_ptr_t)(la + i * 256), 16, 0, 0);
@@ -773,7 +777,7 @@ pw_gemm_split_kernel(GemmArgs g) {
 #define USE_X(x, N) do { asm volatile("s_waitcnt vmcnt(" #N ")" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), \
                                       "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]) : "memory");                  \
                          __builtin_amdgcn_sched_barrier(0); } while (0)
-  u32x4* const Bst = img + SIMG + bh * SCH + (tid & 127);   // this thread's chunk in the B image of stage 0
+  u32x4* const Bst = img + bh * SCH + (tid & 127);   // this thread's chunk in the activation image of stage 0
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -783,9 +787,11 @@ pw_gemm_split_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  issueA(0, 0);
+  // prologue (once per 64-tile range: waited for in full)
+  for (int u = 0; u < DA && u < T; ++u) issueA(u);
   fetchB(0, xb[0]);
-  if (T > 1) { fetchB(1, xb[1]); USE_X(xb[0], 8); } else { USE_X(xb[0], 0); }
+  USE_X(xb[0], 0);
+  if (T > 1) fetchB(1, xb[1]);
   {
     u32x4 h, m, l;
     split8(xb[0], h, m, l);
@@ -798,8 +804,8 @@ pw_gemm_split_kernel(GemmArgs g) {
 
   // diagnostic ablations (tools/gemm_variants.py): SPLIT_NO_FETCH / _DMA / _LDSREAD / _STORE / _BARRIER / _EPILOGUE / _INTERLEAVE
   auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
-    const u32x4* As = img + cur * 2 * SIMG + lh * SCH + wm * 64 + li;
-    const u32x4* Bs = img + (cur * 2 + 1) * SIMG + lh * SCH + wn * 64 + li;
+    const u32x4* As = img + (2 + t % SA) * SIMG + lh * SCH + wm * 64 + li;
+    const u32x4* Bs = img + cur * SIMG + lh * SCH + wn * 64 + li;
     SplitFrags f;
 #ifdef SPLIT_NO_LDSREAD
 #pragma unroll
@@ -816,14 +822,16 @@ pw_gemm_split_kernel(GemmArgs g) {
     // The weight DMA goes after the fragment reads: the compiler waits for every pending LDS-DMA
     // (vmcnt) in front of a ds_read that follows it.
     __builtin_amdgcn_sched_barrier(0);
+    const bool dmaA = t + DA < T, ldB = t + 2 < T;
 #ifndef SPLIT_NO_DMA
-    if (t + 1 < T) issueA(t + 1, cur ^ 1);
+    if (dmaA) issueA(t + DA);
 #endif
 #ifndef SPLIT_NO_FETCH
-    if (t + 2 < T) fetchB(t + 2, xload);
+    if (ldB) fetchB(t + 2, xload);
 #endif
-    // xsplit (tile t+1) was loaded a step ago; younger: 3 DMA + 8 loads of this step when both were issued
-    if (t + 2 < T) USE_X(xsplit, 11);
+    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's 3 DMA and 8 loads
+    if (dmaA && ldB) USE_X(xsplit, 11);
+    else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
     __builtin_amdgcn_sched_barrier(0);
     // One basic block for every tile, the last included (its split writes a stage that nobody reads any
@@ -841,13 +849,14 @@ pw_gemm_split_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
 #endif
-      u32x4* o = Bst + (cur ^ 1) * 2 * SIMG;
+      u32x4* o = Bst + (cur ^ 1) * SIMG;
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
     }
 #endif
 #ifndef SPLIT_NO_BARRIER
-    // DMA of t+1 landed, own ds_writes done, loads of t+2 still in flight
-    if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // weight tile t+1 landed (its DMA is DA steps old: 8 loads of that step + 11 operations per step since
+    // are younger), own ds_writes done, the loads of t+2 and the younger DMAs still in flight
+    if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(8 + 11 * (DA - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
   };
@@ -957,11 +966,13 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     // one basic block for every tile; the last tile's split is surplus (stage nobody reads, keep = 0)
     split_tile_mfma(f, acc);
     split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+#ifndef WGRAD_NO_INTERLEAVE
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the two splits
     }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   for (int t = 0; t < T; t += 2) {
@@ -1047,7 +1058,7 @@ int launch_gemm(const GemmArgs& g, int grid, hipStream_t st) {
                     : launch_gemm_bk<A_KC, B_KC, 16>(g, grid, st);
 }
 
-constexpr size_t SPLIT_LDS = (size_t)2 * 2 * SIMG * 16, SPLIT_LDS_WGRAD = (size_t)2 * 2 * SIMGP * 16;
+constexpr size_t SPLIT_LDS = (size_t)(2 + SPLIT_ASTAGES) * SIMG * 16, SPLIT_LDS_WGRAD = (size_t)2 * 2 * SIMGP * 16;
 
 int64_t split_image_chunks(int M, int K) {
   return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * SIMG;
@@ -1055,6 +1066,15 @@ int64_t split_image_chunks(int M, int K) {
 
 int launch_split(const GemmArgs& d, hipStream_t st) {
   const int grid = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.nbatch;
+  static bool configured = SPLIT_LDS <= 64 * 1024;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS) != hipSuccess) {
+      paradis_set_error("pw_gemm(split): cannot reserve LDS");
+      return 2;
+    }
+    configured = true;
+  }
   hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, st, d);
   return 0;
 }
