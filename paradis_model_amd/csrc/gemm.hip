@@ -686,11 +686,21 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 struct SplitFrags { u32x4 a[3][2], b[3][2]; };
 template <int PA, int PB>
 __device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs, SplitFrags& f) {
+#ifdef SPLIT_READ_PLANE_ORDER   // diagnostic: plane by plane
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     f.a[s][0] = As[s * PA]; f.a[s][1] = As[s * PA + 32];
     f.b[s][0] = Bs[s * PB]; f.b[s][1] = Bs[s * PB + 32];
   }
+#else
+  // in the order of first use by split_tile_mfma (block (0,0): m.m, l.h, h.l first), so that the counted
+  // lgkmcnt waits let the first MFMAs start after two reads instead of seven
+  f.a[1][0] = As[PA];          f.b[1][0] = Bs[PB];
+  f.a[2][0] = As[2 * PA];      f.b[0][0] = Bs[0];
+  f.a[0][0] = As[0];           f.b[2][0] = Bs[2 * PB];
+  f.b[1][1] = Bs[PB + 32];     f.b[0][1] = Bs[32];          f.b[2][1] = Bs[2 * PB + 32];
+  f.a[1][1] = As[PA + 32];     f.a[2][1] = As[2 * PA + 32]; f.a[0][1] = As[32];
+#endif
 }
 // ... then the 24 MFMAs
 __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&acc)[2][2]) {
@@ -806,6 +816,20 @@ pw_gemm_split_kernel(GemmArgs g) {
   auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
     const u32x4* As = img + (2 + t % SA) * SIMG + lh * SCH + wm * 64 + li;
     const u32x4* Bs = img + cur * SIMG + lh * SCH + wn * 64 + li;
+    const bool dmaA = t + DA < T, ldB = t + 2 < T;
+#ifndef SPLIT_NO_DMA
+    if (dmaA) issueA(t + DA);
+#endif
+#ifndef SPLIT_NO_FETCH
+    if (ldB) fetchB(t + 2, xload);
+#endif
+    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's 3 DMA and 8 loads
+    if (dmaA && ldB) USE_X(xsplit, 11);
+    else if (ldB) USE_X(xsplit, 8);
+    else USE_X(xsplit, 0);
+    // The fragment reads sit in the block of the MFMAs (behind the branches above the compiler's lgkmcnt
+    // bookkeeping falls back to lgkmcnt(0) in front of the first MFMA; inside one block the waits are
+    // counted and the first MFMA starts after two of the twelve reads).
     SplitFrags f;
 #ifdef SPLIT_NO_LDSREAD
 #pragma unroll
@@ -819,21 +843,6 @@ pw_gemm_split_kernel(GemmArgs g) {
 #else
     split_tile_read<2 * SCH, 2 * SCH>(As, Bs, f);
 #endif
-    // The weight DMA goes after the fragment reads: the compiler waits for every pending LDS-DMA
-    // (vmcnt) in front of a ds_read that follows it.
-    __builtin_amdgcn_sched_barrier(0);
-    const bool dmaA = t + DA < T, ldB = t + 2 < T;
-#ifndef SPLIT_NO_DMA
-    if (dmaA) issueA(t + DA);
-#endif
-#ifndef SPLIT_NO_FETCH
-    if (ldB) fetchB(t + 2, xload);
-#endif
-    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's 3 DMA and 8 loads
-    if (dmaA && ldB) USE_X(xsplit, 11);
-    else if (ldB) USE_X(xsplit, 8);
-    else USE_X(xsplit, 0);
-    __builtin_amdgcn_sched_barrier(0);
     // One basic block for every tile, the last included (its split writes a stage that nobody reads any
     // more): a second copy of the MFMA block behind a branch costs 32 accumulator moves per tile.
     split_tile_mfma(f, acc);
@@ -843,6 +852,9 @@ pw_gemm_split_kernel(GemmArgs g) {
       split8(xsplit, h, m, l);
 #ifndef SPLIT_NO_INTERLEAVE   // one MFMA : three VALU of the split.  Isolated 1024^2 launches run 2.8 % faster
       // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
+#ifndef SPLIT_NO_LDSREAD
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // all fragment reads first, in first-use order
+#endif
 #pragma unroll
       for (int i = 0; i < 24; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
