@@ -34,7 +34,7 @@ extern "C" {
 #define PARADIS_INTERP_BILINEAR 1
 #define PARADIS_INTERP_BICUBIC 2
 
-int paradis_abi_version(void);
+int paradis_abi_version(void);   /* 2 since the bf16-split arguments of pw_gemm_*, bgemm, muon_step */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
