@@ -33,8 +33,17 @@ extern "C" {
 #define PARADIS_ACT_GELU 2
 #define PARADIS_INTERP_BILINEAR 1
 #define PARADIS_INTERP_BICUBIC 2
+/* `flags` of paradis_sl_advect_{fwd,bwd}: schedule (bits 0-1) and window halo of the tiled schedule
+ * (bits 8-15: 0 = built-in default, else halo + 1; bits 16-23: the same for the backward only).  0 = automatic: the whole padded plane in LDS when
+ * it fits 64 KiB, otherwise 128-column tiles with a halo and an L2 path for taps outside the window. */
+#define PARADIS_ADVECT_AUTO 0
+#define PARADIS_ADVECT_TILED 2
+#define PARADIS_ADVECT_SCHEDULE_MASK 3
+#define PARADIS_ADVECT_HALO_SHIFT 8
+#define PARADIS_ADVECT_HALO_BWD_SHIFT 16
+#define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 2 since the bf16-split arguments of pw_gemm_*, bgemm, muon_step */
+int paradis_abi_version(void);   /* 3: `flags` of sl_advect_*; the process-global debug setters are gone */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -50,7 +59,7 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
                           const float* sin_lat, const float* cos_lat, const float* lon,
                           int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs, int64_t o_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
-                          int mode, void* workspace, void* stream);
+                          int mode, int flags, void* workspace, void* stream);
 /* gfield [B,K,H,W] (batch stride gf_bs), gu/gv with batch stride guv_bs.
  * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes. */
 size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
@@ -60,7 +69,7 @@ int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
                           int B, int K, int H, int W, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                           int64_t gf_bs, int64_t guv_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
-                          int mode, void* workspace, void* stream);
+                          int mode, int flags, void* workspace, void* stream);
 
 /* ---- a7 (depthwise half of SepConv, reference model/blocks.py:101-113) and the static
  * encoder's GeoCyclicPadding(3)+Conv2d(groups=C) (reference model/paradis.py:189-190):
@@ -198,20 +207,6 @@ int paradis_adamw_chunk(void);
 int paradis_adamw_multi(const int64_t* ptrs, const int64_t* numel, const int* chunk_tensor,
                         const int64_t* chunk_off, int n_tensors, int n_chunks, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int step, void* stream);
-
-/* ---- diagnostics (process-global tunables used by tools/ and tests/; not needed in production)
- * advect: force the tiled schedule (1) / automatic choice (-1 or 0); halo of the tiled window (0..16)
- * gemm  : k-tile depth (16|32) and workgroups per CU (1..4) of the register-staged kernel; start-up
- *         stagger; LDS-DMA ring depth for fwd/dgrad (0 = off, 2..4) and for wgrad (0 = off, 2..3) */
-void paradis_debug_set_advect_gmem(int on);
-void paradis_debug_set_norm_bwd_reread(int on);          /* ChannelNorm backward: x re-read via L2 (1, default) or xhat in LDS (0) */
-void paradis_debug_set_norm_fwd_px(int px);              /* ChannelNorm forward: 32 (default) or 64 pixels per workgroup */
-void paradis_debug_set_advect_halo(int halo);            /* both directions */
-void paradis_debug_set_advect_halos(int fwd, int bwd);   /* -1 = default */
-void paradis_debug_set_gemm(int bk, int wg_per_cu);
-void paradis_debug_set_gemm_stagger(int units);
-void paradis_debug_set_gemm_dma(int stages);
-void paradis_debug_set_wgrad_dma(int stages);
 
 /* ---- f3 (second half): Muon / NorMuon step on T same-shaped weight matrices w_t[rows, cols] (conv
  * weights flattened to [out, in*kh*kw]), the reference's default optimiser for Conv/Linear weights

@@ -32,10 +32,10 @@ SIGNATURES = {
     "paradis_last_error": (c_char_p, []),
     "paradis_geocyclic_pad_fwd": (I, [P, P, L, I, I, I, P]),
     "paradis_geocyclic_pad_bwd": (I, [P, P, L, I, I, I, P]),
-    "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, P, P]),
+    "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, I, P, P]),
     "paradis_sl_advect_ws_bytes": (S, [I, I, I, I]),
     "paradis_sl_advect_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L,
-                                  F, F, F, F, F, I, P, P]),
+                                  F, F, F, F, F, I, I, P, P]),
     "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_wgrad_ws_bytes": (S, [I, I, I, I, I]),
@@ -81,15 +81,6 @@ SIGNATURES = {
     "paradis_bgemm": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P, P]),
     "paradis_adamw_chunk": (I, []),
     "paradis_adamw_multi": (I, [P, P, P, P, I, I, F, F, F, F, F, I, P]),
-    "paradis_debug_set_norm_fwd_px": (None, [I]),
-    "paradis_debug_set_norm_bwd_reread": (None, [I]),
-    "paradis_debug_set_advect_gmem": (None, [I]),
-    "paradis_debug_set_advect_halo": (None, [I]),
-    "paradis_debug_set_advect_halos": (None, [I, I]),
-    "paradis_debug_set_gemm": (None, [I, I]),
-    "paradis_debug_set_gemm_stagger": (None, [I]),
-    "paradis_debug_set_gemm_dma": (None, [I]),
-    "paradis_debug_set_wgrad_dma": (None, [I]),
 }
 
 _missing = []

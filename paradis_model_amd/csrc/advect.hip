@@ -829,13 +829,11 @@ AdvGeom make_geom(int H, int W, int p, float dt, float min_lat, float min_lon, f
 }
 
 constexpr size_t WHOLE_LDS_LIMIT = 64 * 1024;
-int g_force_tiled = -1;   // debug: -1 auto, 0/1 force
 // window halos (padded cells) of the tiled schedule.  Forward windows are cheap (4 B/cell); the
 // backward holds 12 B/cell (64-bit accumulators + field), so its halo is what LDS allows at 2
 // workgroups per CU.  Taps outside the window take the L2 / global-atomic path.
-int g_halo = 8;           // forward (in-model optimum 6-12 at 128x256 and 721x1440; 24 pays only for ~45 px
-                          // displacements)
-int g_halo_bwd = 10;      // backward (two workgroups of 512 threads per CU)
+constexpr int HALO_FWD = 8;    // in-model optimum 6-12 at 128x256 and 721x1440; 24 pays only for ~45 px displacements
+constexpr int HALO_BWD = 10;   // two workgroups of 512 threads per CU
 constexpr int MAX_HALO = 32;
 
 template <typename K>
@@ -848,22 +846,21 @@ int reserve_lds(K kernel, const char* what) {
   return 0;
 }
 
-bool use_tiled(size_t whole_bytes) {
-  if (g_force_tiled == 1) return true;
+// `flags` of the C ABI (include/paradis_hip.h, PARADIS_ADVECT_*): schedule choice and window halo are
+// per-call arguments, the library keeps no mutable state
+bool use_tiled(size_t whole_bytes, int flags) {
+  const int sched = flags & PARADIS_ADVECT_SCHEDULE_MASK;
+  if (sched == PARADIS_ADVECT_TILED) return true;
   return whole_bytes > WHOLE_LDS_LIMIT;
+}
+int halo_of(int flags, int dflt, bool backward) {
+  int h = (flags >> PARADIS_ADVECT_HALO_SHIFT) & 0xff;          // 0 = default, else halo + 1
+  const int hb = (flags >> PARADIS_ADVECT_HALO_BWD_SHIFT) & 0xff;
+  if (backward && hb) h = hb;
+  return h == 0 ? dflt : std::min(h - 1, MAX_HALO);
 }
 
 }  // namespace
-
-// test/diagnostic hooks: force the tiled schedule regardless of plane size; set its halo
-extern "C" void paradis_debug_set_advect_gmem(int on) { g_force_tiled = on; }
-extern "C" void paradis_debug_set_advect_halo(int halo) {   // both directions (tests force tiny halos)
-  g_halo = g_halo_bwd = halo < 0 ? 0 : (halo > MAX_HALO ? MAX_HALO : halo);
-}
-extern "C" void paradis_debug_set_advect_halos(int fwd, int bwd) {
-  g_halo = fwd < 0 ? 8 : (fwd > MAX_HALO ? MAX_HALO : fwd);
-  g_halo_bwd = bwd < 0 ? 10 : (bwd > MAX_HALO ? MAX_HALO : bwd);
-}
 
 extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W) {
   (void)H; (void)W;
@@ -884,7 +881,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
                                      const float* sin_lat, const float* cos_lat, const float* lon,
                                      int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs,
                                      int64_t o_bs, float dt, float min_lat, float min_lon,
-                                     float d_lat, float d_lon, int mode, void* workspace,
+                                     float d_lat, float d_lon, int mode, int flags, void* workspace,
                                      void* stream) {
   if (int e = check_adv("sl_advect_fwd", B, K, H, W, mode)) return e;
   if (B == 0) return 0;
@@ -896,7 +893,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // 16-byte staging path: aligned planes, p even (bicubic), padded width even
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && a16(field) && (p % 2 == 0);
-  if (!use_tiled(whole)) {
+  if (!use_tiled(whole, flags)) {
     ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
                (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_fwd");
@@ -908,15 +905,14 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, field, fmeans, planes, K, H, W, f_bs);
   const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_HF - 1) / TILE_HF, tiles = tx * ty;
   PD_REQUIRE((int64_t)planes * tiles < (1ll << 31), "sl_advect_fwd: too many tiles");
-  const int halo = g_halo;
+  const int halo = halo_of(flags, HALO_FWD, false);
   const size_t lds = (size_t)(TILE_HF + 2 * halo + NT) * (TILE_W + 2 * halo + NT) * sizeof(float);
   PD_REQUIRE(lds <= 160 * 1024, "sl_advect_fwd: window does not fit LDS");
-  static bool reserved = false;
-  if (!reserved) {
+  static PerDeviceOnce once;
+  if (once.first()) {
     if (reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS") ||
         reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
       return 2;
-    reserved = true;
   }
   ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
              cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
@@ -931,7 +927,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                                      int B, int K, int H, int W, int64_t go_bs, int64_t f_bs,
                                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, float dt,
                                      float min_lat, float min_lon, float d_lat, float d_lon, int mode,
-                                     void* workspace, void* stream) {
+                                     int flags, void* workspace, void* stream) {
   if (int e = check_adv("sl_advect_bwd", B, K, H, W, mode)) return e;
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
@@ -942,7 +938,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && (p % 2 == 0) &&
                    (reinterpret_cast<uintptr_t>(field) & 15) == 0;
   const size_t whole = lds_of((size_t)(H + 2 * p) * (W + 2 * p));
-  if (!use_tiled(whole)) {
+  if (!use_tiled(whole, flags)) {
     ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
                cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
                gf_bs, guv_bs, 0, 1, 1, vec4);
@@ -962,18 +958,18 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   }
   const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H, tiles = tx * ty;
   PD_REQUIRE((int64_t)planes * tiles < (1ll << 31), "sl_advect_bwd: too many tiles");
-  const size_t lds = lds_of((size_t)(TILE_H + 2 * g_halo_bwd + NT) * (TILE_W + 2 * g_halo_bwd + NT));
+  const int halo = halo_of(flags, HALO_BWD, true);
+  const size_t lds = lds_of((size_t)(TILE_H + 2 * halo + NT) * (TILE_W + 2 * halo + NT));
   PD_REQUIRE(lds <= 160 * 1024, "sl_advect_bwd: window does not fit LDS");
-  static bool reserved = false;
-  if (!reserved) {
+  static PerDeviceOnce once;
+  if (once.first()) {
     if (reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS") ||
         reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS"))
       return 2;
-    reserved = true;
   }
   ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
              gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-             f_bs, uv_bs, gf_bs, guv_bs, g_halo_bwd, tx, tiles, vec4);
+             f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4);
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");
   return 0;

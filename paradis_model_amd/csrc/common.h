@@ -28,6 +28,21 @@ void paradis_set_error(const char* fmt, ...);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property: a kernel family keeps one
+// of these and asks `first()` before its launches (true once per device of the calling process).
+struct PerDeviceOnce {
+  unsigned long long mask[2] = {0ull, 0ull};   // up to 128 devices
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 128) return true;
+    unsigned long long& m = mask[dev >> 6];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (m & bit) return false;
+    m |= bit;
+    return true;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Geocyclic index map (reference model/padding.py:11-39).
 // (ii, jj) are IMAGE coordinates of a padded cell: ii in [-p, H+p), jj in [-p, W+p).

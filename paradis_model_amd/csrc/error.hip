@@ -12,4 +12,4 @@ void paradis_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* paradis_last_error(void) { return g_err; }
-extern "C" int paradis_abi_version(void) { return 2; }   // 2: bf16-split GEMM arguments (pw_gemm_*, bgemm, muon_step)
+extern "C" int paradis_abi_version(void) { return 3; }   // 3: flags argument of sl_advect_*, no debug setters

@@ -1034,14 +1034,13 @@ int launch_gemm_bk(const GemmArgs& g, int grid, hipStream_t st) {
   // the dynamic-LDS request doubles as the occupancy control: 160 KiB / request = workgroups per CU
   size_t request = std::max(lds_bytes(BK), (size_t)(160 * 1024 / g_wg_per_cu) & ~(size_t)255);
   request = std::min(request, (size_t)160 * 1024);
-  static size_t configured = 0;
-  if (configured < request) {
+  static PerDeviceOnce once;
+  if (once.first()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<A_KC, B_KC, BK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess) {
       paradis_set_error("pw_gemm: cannot reserve LDS");
       return 2;
     }
-    configured = 160 * 1024;
   }
   hipLaunchKernelGGL((pw_gemm_kernel<A_KC, B_KC, BK>), dim3(grid), dim3(256), request, st, g);
   return 0;
@@ -1078,14 +1077,13 @@ int64_t split_image_chunks(int M, int K) {
 
 int launch_split(const GemmArgs& d, hipStream_t st) {
   const int grid = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.nbatch;
-  static bool configured = SPLIT_LDS <= 64 * 1024;
-  if (!configured) {
+  static PerDeviceOnce once;
+  if (SPLIT_LDS > 64 * 1024 && once.first()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS) != hipSuccess) {
       paradis_set_error("pw_gemm(split): cannot reserve LDS");
       return 2;
     }
-    configured = true;
   }
   hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, st, d);
   return 0;
@@ -1100,7 +1098,9 @@ int check_gemm(const char* name, int B, int M, int K, int N) {
 
 }  // namespace
 
-// diagnostic knobs (tools/gemm_bench.py); bk in {16,32}, wg_per_cu in 1..4
+#ifdef PARADIS_DEV_KNOBS
+// diagnostic knobs of the development build only (`make dev`, tools/gemm_bench.py); the shipped
+// library exports none of them.  bk in {16,32}, wg_per_cu in 1..4
 extern "C" void paradis_debug_set_gemm(int bk, int wg_per_cu) {
   if (bk == 16 || bk == 32) g_bk = bk;
   if (wg_per_cu >= 1 && wg_per_cu <= 4) g_wg_per_cu = wg_per_cu;
@@ -1108,6 +1108,7 @@ extern "C" void paradis_debug_set_gemm(int bk, int wg_per_cu) {
 extern "C" void paradis_debug_set_gemm_stagger(int units) { g_stagger = units < 0 ? 0 : units; }
 extern "C" void paradis_debug_set_gemm_dma(int stages) { g_dma_stages = stages < 2 ? 0 : (stages > 4 ? 4 : stages); }
 extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = stages < 2 ? 0 : (stages > 3 ? 3 : stages); }
+#endif
 
 extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K) {
   return M >= 1 && K >= 1 ? (size_t)split_image_chunks(M, K) * 16 : 0;

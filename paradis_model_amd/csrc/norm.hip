@@ -400,8 +400,10 @@ int check_norm(const char* name, int B, int C1, int C2, int P) {
 
 }  // namespace
 
+#ifdef PARADIS_DEV_KNOBS   // development build only (`make dev`, tools/stencil_bench.py)
 extern "C" void paradis_debug_set_norm_fwd_px(int px) { g_norm_fwd_px = px == 64 ? 64 : 32; }
 extern "C" void paradis_debug_set_norm_bwd_reread(int on) { g_norm_bwd_reread = on ? 1 : 0; }
+#endif
 
 extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
                                         const float* b, float* y, float* mean, float* rstd, int B,
@@ -470,8 +472,8 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     nblk = B * tiles32;
     float* partial = (float*)workspace;
     const size_t lds = (size_t)(2 * 32 * NPBr + C * NPBr) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce once;
+    if (once.first()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channel_norm_bwd_fused_kernel<36, 32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(&channel_norm_bwd_fused_kernel<4, 32>),
@@ -479,7 +481,6 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
         paradis_set_error("channel_norm_bwd: cannot reserve LDS");
         return 2;
       }
-      configured = true;
     }
     if (g_norm_bwd_reread == 1 && addend1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<true>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,

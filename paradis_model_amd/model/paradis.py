@@ -132,19 +132,18 @@ class Paradis(nn.Module):
         return checkpoint(self._layer_step, i, h, hs, use_reentrant=False)
 
     def _compile(self):
-        """The reference wraps sub-modules in ``torch.compile`` here (model/paradis.py:195-206).
-        The HIP path is already fused by hand and uses no tracing compiler: keep eager modules and
-        only re-bind the step function."""
+        """Per-module compilation, as the reference does for ``compute.compile == "modules"``
+        (reference model/paradis.py:195-206): the layer step, the static encoder and the two projections
+        become ``torch.compile`` regions in which every ``paradis::*`` custom op is one opaque node."""
+        self._layer_step = torch.compile(self._layer_step)
+        self.static_encoder = torch.compile(self.static_encoder)
+        self.input_proj = torch.compile(self.input_proj)
+        self.output_proj = torch.compile(self.output_proj)
         self.step_fn = self._checkpointed_step if self.gradient_checkpoint else self._layer_step
 
-    def compile(self, *args, **kwargs):
-        """The reference trainer calls ``model.compile(backend="inductor", fullgraph=True)`` when
-        ``compute.compile`` is set (trainer.py:261-267).  The HIP path is hand-fused and its ops are
-        opaque C-ABI calls, so tracing is neither needed nor possible: stay eager."""
-        import warnings
-        warnings.warn("paradis_model_amd: torch.compile is not used on the HIP path (already fused); "
-                      "running eager", stacklevel=2)
-        return self
+    # ``Paradis.compile(mode=..., fullgraph=True, dynamic=False, backend="inductor")`` (reference
+    # trainer.py:261-267) is ``nn.Module.compile``: the ops are registered with fake kernels and autograd
+    # formulas (paradis_model_amd/ops.py), so the whole forward traces into one graph.
 
     def upsample(self, x: torch.Tensor) -> torch.Tensor:
         """Longitude-periodic bilinear interpolation to (nlat, nlon), align_corners=True."""

@@ -1,15 +1,30 @@
-"""Autograd-aware Python entry points over the C-ABI HIP kernels.
+"""torch custom ops (namespace ``paradis``) over the C-ABI HIP kernels.
 
-Every function launches hand-written gfx950 kernels from ``libparadis_hip.so`` on
-the current HIP stream (no host sync).  Inputs must be fp32 HIP tensors; there is
-no CPU path (``_lib.require_hip`` raises).  Reference call sites are cited per op.
+Every entry point of the hot path is registered through ``torch.library``:
+
+* a ``CUDA`` (= HIP on ROCm) kernel that launches the hand-written gfx950 kernels of
+  ``libparadis_hip.so`` on the current HIP stream through the C ABI (no host sync);
+* a fake (Meta) kernel giving the output shapes, so ``torch.compile(fullgraph=True)`` and
+  AOTAutograd trace the model with these ops as opaque nodes (reference ``trainer.py:261-267``,
+  ``model/paradis.py:195-206``);
+* an autograd formula whose backward is again made of ``paradis::*_backward`` ops, so the traced
+  backward graph contains no Python-only calls;
+* an autocast rule: the kernels are fp32, under ``torch.autocast`` (the reference's
+  ``precision="bf16-mixed"``, ``train.py:56``) inputs are cast to fp32 - never a narrower
+  arithmetic than the reference's.
+
+There is no CPU kernel: a CPU tensor raises (``_lib.require_hip`` / the dispatcher), and so does any
+dtype but fp32.  The Python functions below (``pointwise``, ``sl_advect`` ...) are thin wrappers that
+check arguments and call ``torch.ops.paradis.*``.  Reference call sites are cited per op.
 """
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
+import weakref
+from typing import List, Optional, Sequence, Tuple
 
 import torch
+from torch import Tensor
 
 from . import _lib
 from ._lib import check, dptr, lib, require_hip, stream_ptr
@@ -17,50 +32,116 @@ from ._lib import check, dptr, lib, require_hip, stream_ptr
 ACT_CODES = {None: 0, "none": 0, "SiLU": 1, "GELU": 2}
 MODE_CODES = {"bilinear": 1, "bicubic": 2}
 
+_DEF = torch.library.Library("paradis", "DEF")
+OPS = {}            # op name -> OpOverload (torch.ops.paradis.<name>.default)
 
-def _ws(nbytes: int, device) -> Optional[torch.Tensor]:
+
+def _define(schema: str, autocast: bool = True):
+    """Register ``schema`` in the ``paradis`` namespace with the decorated function as its HIP kernel."""
+    name = schema[: schema.index("(")]
+    _DEF.define(schema)
+
+    def deco(fn):
+        _DEF.impl(name, fn, "CUDA")
+        if autocast:
+            torch.library.register_autocast(f"paradis::{name}", "cuda", torch.float32)
+        ov = getattr(torch.ops.paradis, name).default
+        OPS[name] = ov
+        return ov
+    return deco
+
+
+def _fake(name: str):
+    return torch.library.register_fake(f"paradis::{name}")
+
+
+def _autograd(name: str, setup, backward) -> None:
+    torch.library.register_autograd(f"paradis::{name}", backward, setup_context=setup)
+
+
+def _f32(*tensors) -> None:
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"paradis_model_amd ops are fp32; got {t.dtype}")
+
+
+def _ws(nbytes: int, device) -> Optional[Tensor]:
     if nbytes <= 0:
         return None
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def _planes_hw(x: torch.Tensor) -> Tuple[int, int, int]:
+def _planes_hw(x: Tensor) -> Tuple[int, int, int]:
     H, W = x.shape[-2:]
     return x.numel() // (H * W), H, W
+
+
+def _none_if_empty(t: Tensor) -> Optional[Tensor]:
+    return t if t.numel() else None
+
+
+def _plane_view(t: Tensor) -> Tuple[Tensor, int]:
+    """[B,C,H,W] whose (H,W) planes are contiguous and channels are P apart (e.g. a channel slice of a
+    larger contiguous tensor) is consumed in place: return (tensor, batch stride in elements);
+    anything else is made contiguous."""
+    B, C, H, W = t.shape
+    if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W:
+        return t, (t.stride(0) if B > 1 else C * H * W)
+    return t.contiguous(), C * H * W
 
 
 # ---------------------------------------------------------------------------
 # a1 geocyclic padding (reference model/padding.py:11-39)
 # ---------------------------------------------------------------------------
-class _GeoPad(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, p):
-        require_hip(x)
-        x = x.contiguous()
-        planes, H, W = _planes_hw(x)
-        y = torch.empty(*x.shape[:-2], H + 2 * p, W + 2 * p, dtype=x.dtype, device=x.device)
-        check(lib.paradis_geocyclic_pad_fwd(dptr(x), dptr(y), planes, H, W, p, stream_ptr()),
-              "geocyclic_pad_fwd")
-        ctx.p = p
-        ctx.shape = x.shape
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        gy = gy.contiguous()
-        gx = torch.empty(ctx.shape, dtype=gy.dtype, device=gy.device)
-        planes, H, W = _planes_hw(gx)
-        check(lib.paradis_geocyclic_pad_bwd(dptr(gy), dptr(gx), planes, H, W, ctx.p, stream_ptr()),
-              "geocyclic_pad_bwd")
-        return gx, None
+@_define("geocyclic_pad(Tensor x, int p) -> Tensor")
+def _geocyclic_pad(x, p):
+    _f32(x)
+    x = x.contiguous()
+    planes, H, W = _planes_hw(x)
+    y = torch.empty(*x.shape[:-2], H + 2 * p, W + 2 * p, dtype=x.dtype, device=x.device)
+    check(lib.paradis_geocyclic_pad_fwd(dptr(x), dptr(y), planes, H, W, p, stream_ptr()), "geocyclic_pad_fwd")
+    return y
 
 
-def geocyclic_pad(x: torch.Tensor, p: int) -> torch.Tensor:
+@_fake("geocyclic_pad")
+def _(x, p):
+    return x.new_empty(*x.shape[:-2], x.shape[-2] + 2 * p, x.shape[-1] + 2 * p)
+
+
+@_define("geocyclic_pad_backward(Tensor gy, int p) -> Tensor")
+def _geocyclic_pad_backward(gy, p):
+    _f32(gy)
+    gy = gy.contiguous()
+    H, W = gy.shape[-2] - 2 * p, gy.shape[-1] - 2 * p
+    gx = torch.empty(*gy.shape[:-2], H, W, dtype=gy.dtype, device=gy.device)
+    check(lib.paradis_geocyclic_pad_bwd(dptr(gy), dptr(gx), gx.numel() // (H * W), H, W, p, stream_ptr()),
+          "geocyclic_pad_bwd")
+    return gx
+
+
+@_fake("geocyclic_pad_backward")
+def _(gy, p):
+    return gy.new_empty(*gy.shape[:-2], gy.shape[-2] - 2 * p, gy.shape[-1] - 2 * p)
+
+
+def _pad_setup(ctx, inputs, output):
+    ctx.p = inputs[1]
+
+
+def _pad_backward(ctx, gy):
+    return _geocyclic_pad_backward(gy, ctx.p), None
+
+
+_autograd("geocyclic_pad", _pad_setup, _pad_backward)
+
+
+def geocyclic_pad(x: Tensor, p: int) -> Tensor:
     if p == 0:
         return x
     assert x.dim() == 4, "Input must be 4-dimensional [batch, channels, lat, lon]"
     assert x.shape[-1] % 2 == 0, "Number of longitude points must be even"
-    return _GeoPad.apply(x, p)
+    require_hip(x)
+    return _geocyclic_pad(x, int(p))
 
 
 # ---------------------------------------------------------------------------
@@ -70,7 +151,7 @@ class AdvectGeometry:
     """Device tables + scalars derived from the lat/lon grids once per module
     (the reference's non-persistent buffers, model/advection.py:58-72)."""
 
-    def __init__(self, lat_grid: torch.Tensor, lon_grid: torch.Tensor):
+    def __init__(self, lat_grid: Tensor, lon_grid: Tensor):
         lat = lat_grid.detach().to(torch.float32).cpu().contiguous()
         lon = lon_grid.detach().to(torch.float32).cpu().contiguous()
         self.H, self.W = lat.shape
@@ -91,193 +172,300 @@ class AdvectGeometry:
         return self._dev[key]
 
 
-def _bstride_view(t: torch.Tensor, K: int, H: int, W: int) -> Tuple[torch.Tensor, int]:
-    """Accept [B,K,H,W] views whose planes are contiguous (e.g. a channel slice); return
-    (tensor, batch stride in elements)."""
+_ADV_GEOM = "float dt, float min_lat, float min_lon, float d_lat, float d_lon, int mode, int flags"
+
+
+def _bstride_view(t: Tensor, K: int, H: int, W: int) -> Tuple[Tensor, int]:
     if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W:
         return t, t.stride(0) if t.shape[0] > 1 else K * H * W
-    t = t.contiguous()
-    return t, K * H * W
+    return t.contiguous(), K * H * W
 
 
-class _SLAdvect(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, field, u, v, geom: AdvectGeometry, dt: float, mode: str):
-        require_hip(field, u, v)
-        B, K, H, W = field.shape
-        assert (H, W) == (geom.H, geom.W) and u.shape == field.shape and v.shape == field.shape
-        field, f_bs = _bstride_view(field, K, H, W)
-        u, u_bs = _bstride_view(u, K, H, W)
-        v, v_bs = _bstride_view(v, K, H, W)
-        if u_bs != v_bs:
-            u, v = u.contiguous(), v.contiguous()
-            u_bs = v_bs = K * H * W
-        out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
-        sl, cl, lo = geom.tables(field.device)
-        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
-        _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
-                  dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
-                  f_bs, u_bs, K * H * W, dt, geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon,
-                  MODE_CODES[mode], dptr(ws), stream_ptr())
-        ctx.save_for_backward(field, u, v)
-        ctx.meta = (geom, dt, mode, f_bs, u_bs)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        field, u, v = ctx.saved_tensors
-        geom, dt, mode, f_bs, u_bs = ctx.meta
-        B, K, H, W = gout.shape
-        gout = gout.contiguous()
-        gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
-        guv = torch.empty(B, 2 * K, H, W, dtype=gout.dtype, device=gout.device)
-        gu, gv = guv[:, :K], guv[:, K:]
-        sl, cl, lo = geom.tables(gout.device)
-        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
-        P = K * H * W
-        _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
-                  dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
-                  dptr(cl), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, 2 * P, dt, geom.min_lat,
-                  geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode], dptr(ws), stream_ptr())
-        return gfield, gu, gv, None, None, None
+@_define(f"sl_advect(Tensor field, Tensor u, Tensor v, Tensor sin_lat, Tensor cos_lat, Tensor lon, {_ADV_GEOM}) -> Tensor")
+def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    _f32(field, u, v)
+    B, K, H, W = field.shape
+    field, f_bs = _bstride_view(field, K, H, W)
+    u, u_bs = _bstride_view(u, K, H, W)
+    v, v_bs = _bstride_view(v, K, H, W)
+    if u_bs != v_bs:
+        u, v = u.contiguous(), v.contiguous()
+        u_bs = K * H * W
+    out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+    _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
+              dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
+              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), stream_ptr())
+    return out
 
 
-class _SLAdvectVel(torch.autograd.Function):
+@_fake("sl_advect")
+def _(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    return field.new_empty(field.shape)
+
+
+@_define(f"sl_advect_backward(Tensor gout, Tensor field, Tensor u, Tensor v, Tensor sin_lat, Tensor cos_lat, "
+         f"Tensor lon, {_ADV_GEOM}) -> (Tensor, Tensor, Tensor)")
+def _sl_advect_backward(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    _f32(gout, field, u, v)
+    B, K, H, W = gout.shape
+    P = K * H * W
+    gout = gout.contiguous()
+    field, f_bs = _bstride_view(field, K, H, W)
+    u, u_bs = _bstride_view(u, K, H, W)
+    v, v_bs = _bstride_view(v, K, H, W)
+    if u_bs != v_bs:
+        u, v = u.contiguous(), v.contiguous()
+        u_bs = P
+    gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
+    gu, gv = torch.empty_like(gfield), torch.empty_like(gfield)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+    _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
+              dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
+              dptr(cl), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
+              flags, dptr(ws), stream_ptr())
+    return gfield, gu, gv
+
+
+@_fake("sl_advect_backward")
+def _(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    return gout.new_empty(gout.shape), gout.new_empty(gout.shape), gout.new_empty(gout.shape)
+
+
+def _adv_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:6])
+    ctx.geom = inputs[6:]
+
+
+def _adv_backward(ctx, gout):
+    gf, gu, gv = _sl_advect_backward(gout, *ctx.saved_tensors, *ctx.geom)
+    return (gf, gu, gv) + (None,) * 10
+
+
+_autograd("sl_advect", _adv_setup, _adv_backward)
+
+
+@_define(f"sl_advect_vel(Tensor field, Tensor vel, Tensor sin_lat, Tensor cos_lat, Tensor lon, {_ADV_GEOM}) -> Tensor")
+def _sl_advect_vel(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     """Same operator taking the velocity tensor [B,2K,H,W] whole (channels [0,K) = u, [K,2K) = v,
     reference model/paradis.py:236-237): no slice views, and the velocity gradient is written in
     place into one [B,2K,H,W] tensor."""
-
-    @staticmethod
-    def forward(ctx, field, vel, geom: AdvectGeometry, dt: float, mode: str):
-        require_hip(field, vel)
-        B, K, H, W = field.shape
-        assert vel.shape == (B, 2 * K, H, W) and (H, W) == (geom.H, geom.W)
-        field, f_bs = _bstride_view(field, K, H, W)
-        vel = vel.contiguous()
-        P = K * H * W
-        out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
-        sl, cl, lo = geom.tables(field.device)
-        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
-        u, v = vel[:, :K], vel[:, K:]
-        _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl),
-                  dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, geom.min_lat, geom.min_lon, geom.d_lat,
-                  geom.d_lon, MODE_CODES[mode], dptr(ws), stream_ptr())
-        ctx.save_for_backward(field, vel)
-        ctx.meta = (geom, dt, mode, f_bs)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        field, vel = ctx.saved_tensors
-        geom, dt, mode, f_bs = ctx.meta
-        B, K, H, W = gout.shape
-        gout = gout.contiguous()
-        P = K * H * W
-        gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
-        gvel = torch.empty_like(vel)
-        sl, cl, lo = geom.tables(gout.device)
-        ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
-        _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
-                  dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
-                  dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, geom.min_lat, geom.min_lon, geom.d_lat,
-                  geom.d_lon, MODE_CODES[mode], dptr(ws), stream_ptr())
-        return gfield, gvel, None, None, None
+    _f32(field, vel)
+    B, K, H, W = field.shape
+    field, f_bs = _bstride_view(field, K, H, W)
+    vel = vel.contiguous()
+    P = K * H * W
+    out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+    _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(vel[:, :K]), dptr(vel[:, K:]), dptr(out),
+              dptr(sl), dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
+              flags, dptr(ws), stream_ptr())
+    return out
 
 
-def sl_advect_vel(field, vel, geom: AdvectGeometry, dt: float, mode: str = "bicubic"):
+@_fake("sl_advect_vel")
+def _(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    return field.new_empty(field.shape)
+
+
+@_define(f"sl_advect_vel_backward(Tensor gout, Tensor field, Tensor vel, Tensor sin_lat, Tensor cos_lat, "
+         f"Tensor lon, {_ADV_GEOM}) -> (Tensor, Tensor)")
+def _sl_advect_vel_backward(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    _f32(gout, field, vel)
+    B, K, H, W = gout.shape
+    P = K * H * W
+    gout = gout.contiguous()
+    field, f_bs = _bstride_view(field, K, H, W)
+    vel = vel.contiguous()
+    gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
+    gvel = torch.empty_like(vel)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+    _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
+              dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
+              dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
+              flags, dptr(ws), stream_ptr())
+    return gfield, gvel
+
+
+@_fake("sl_advect_vel_backward")
+def _(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+    return gout.new_empty(gout.shape), vel.new_empty(vel.shape)
+
+
+def _advv_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:5])
+    ctx.geom = inputs[5:]
+
+
+def _advv_backward(ctx, gout):
+    gf, gvel = _sl_advect_vel_backward(gout, *ctx.saved_tensors, *ctx.geom)
+    return (gf, gvel) + (None,) * 10
+
+
+_autograd("sl_advect_vel", _advv_setup, _advv_backward)
+
+
+ADVECT_TILED = 2                    # include/paradis_hip.h PARADIS_ADVECT_TILED
+# schedule hints applied when a call passes none (diagnostics: tools/advect_halo_sweep.py)
+ADVECT_FLAGS = int(os.environ.get("PARADIS_ADVECT_FLAGS", "0"), 0)
+
+
+def advect_flags(tiled: bool = False, halo: Optional[int] = None, halo_bwd: Optional[int] = None) -> int:
+    """``flags`` of the advection ops: force the tiled schedule and/or its window halo (padded cells;
+    ``halo_bwd`` overrides it for the backward kernel)."""
+    return ((ADVECT_TILED if tiled else 0) | (((int(halo) + 1) << 8) if halo is not None else 0)
+            | (((int(halo_bwd) + 1) << 16) if halo_bwd is not None else 0))
+
+
+def _geom_args(geom: AdvectGeometry, device, dt: float, mode: str, flags: Optional[int]):
     if mode not in MODE_CODES:
         raise ValueError(f"interpolation must be one of {list(MODE_CODES)}")
-    return _SLAdvectVel.apply(field, vel, geom, float(dt), mode)
+    sl, cl, lo = geom.tables(device)
+    return (sl, cl, lo, float(dt), geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode],
+            ADVECT_FLAGS if flags is None else int(flags))
 
 
-def sl_advect(field, u, v, geom: AdvectGeometry, dt: float, mode: str = "bicubic"):
+def sl_advect_vel(field, vel, geom: AdvectGeometry, dt: float, mode: str = "bicubic", flags: Optional[int] = None):
+    require_hip(field, vel)
+    B, K, H, W = field.shape
+    assert vel.shape == (B, 2 * K, H, W) and (H, W) == (geom.H, geom.W)
+    return _sl_advect_vel(field, vel, *_geom_args(geom, field.device, dt, mode, flags))
+
+
+def sl_advect(field, u, v, geom: AdvectGeometry, dt: float, mode: str = "bicubic", flags: Optional[int] = None):
     """[B,K,H,W] x3 -> [B,K,H,W]; fused pole-mean / departure / gather / pole-mean."""
-    if mode not in MODE_CODES:
-        raise ValueError(f"interpolation must be one of {list(MODE_CODES)}")
-    return _SLAdvect.apply(field, u, v, geom, float(dt), mode)
-
-
-# ---------------------------------------------------------------------------
-# helpers for [B,C,H,W] tensors whose (H,W) planes are contiguous
-# ---------------------------------------------------------------------------
-def _plane_view(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
-    """Return (tensor, batch stride in elements); channel slices of a larger contiguous tensor are
-    accepted as they are, anything else is made contiguous."""
-    B, C, H, W = t.shape
-    if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W:
-        return t, (t.stride(0) if B > 1 else C * H * W)
-    return t.contiguous(), C * H * W
+    require_hip(field, u, v)
+    assert tuple(field.shape[-2:]) == (geom.H, geom.W) and u.shape == field.shape and v.shape == field.shape
+    return _sl_advect(field, u, v, *_geom_args(geom, field.device, dt, mode, flags))
 
 
 # ---------------------------------------------------------------------------
 # a7 depthwise stencil on the virtual geocyclic halo (reference model/blocks.py:101-113)
 # ---------------------------------------------------------------------------
-class _DwConvGeo(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        require_hip(x, weight, bias)
-        x = x.contiguous()
-        B, C, H, W = x.shape
-        k = weight.shape[-1]
-        assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
-        w = weight.contiguous()
-        y = torch.empty_like(x)
-        check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k,
-                                         stream_ptr()), "dwconv_geo_fwd")
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        return y
+@_define("dwconv_geo(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
+def _dwconv_geo(x, weight, bias):
+    _f32(x, weight, bias)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
+    w = weight.contiguous()
+    y = torch.empty_like(x)
+    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, stream_ptr()),
+          "dwconv_geo_fwd")
+    return y
 
-    @staticmethod
-    def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        B, C, H, W = x.shape
-        k = w.shape[-1]
-        gy = gy.contiguous()
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            check(lib.paradis_dwconv_geo_dgrad(dptr(gy), dptr(w), dptr(gx), B, C, H, W, k, stream_ptr()),
-                  "dwconv_geo_dgrad")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.empty_like(w)
-            gb = torch.empty(C, dtype=x.dtype, device=x.device) if ctx.has_bias else None
-            ws = _ws(lib.paradis_dwconv_geo_wgrad_ws_bytes(B, C, H, W, k), x.device)
-            check(lib.paradis_dwconv_geo_wgrad(dptr(gy), dptr(x), dptr(gw), dptr(gb), B, C, H, W, k,
-                                               dptr(ws), stream_ptr()), "dwconv_geo_wgrad")
-        return gx, gw, gb
+
+@_fake("dwconv_geo")
+def _(x, weight, bias):
+    return x.new_empty(x.shape)
+
+
+@_define("dwconv_geo_dgrad(Tensor gy, Tensor weight) -> Tensor")
+def _dwconv_geo_dgrad(gy, weight):
+    _f32(gy, weight)
+    gy, w = gy.contiguous(), weight.contiguous()
+    B, C, H, W = gy.shape
+    gx = torch.empty_like(gy)
+    check(lib.paradis_dwconv_geo_dgrad(dptr(gy), dptr(w), dptr(gx), B, C, H, W, w.shape[-1], stream_ptr()),
+          "dwconv_geo_dgrad")
+    return gx
+
+
+@_fake("dwconv_geo_dgrad")
+def _(gy, weight):
+    return gy.new_empty(gy.shape)
+
+
+@_define("dwconv_geo_wgrad(Tensor gy, Tensor x, int k, bool has_bias) -> (Tensor, Tensor)")
+def _dwconv_geo_wgrad(gy, x, k, has_bias):
+    _f32(gy, x)
+    gy, x = gy.contiguous(), x.contiguous()
+    B, C, H, W = x.shape
+    gw = torch.empty(C, 1, k, k, dtype=x.dtype, device=x.device)
+    gb = torch.empty(C if has_bias else 0, dtype=x.dtype, device=x.device)
+    ws = _ws(lib.paradis_dwconv_geo_wgrad_ws_bytes(B, C, H, W, k), x.device)
+    check(lib.paradis_dwconv_geo_wgrad(dptr(gy), dptr(x), dptr(gw), dptr(gb) if has_bias else None, B, C, H, W, k,
+                                       dptr(ws), stream_ptr()), "dwconv_geo_wgrad")
+    return gw, gb
+
+
+@_fake("dwconv_geo_wgrad")
+def _(gy, x, k, has_bias):
+    C = x.shape[1]
+    return x.new_empty(C, 1, k, k), x.new_empty(C if has_bias else 0)
+
+
+def _dw_setup(ctx, inputs, output):
+    x, w, bias = inputs
+    ctx.save_for_backward(x, w)
+    ctx.has_bias = bias is not None
+
+
+def _dw_backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    gx = gw = gb = None
+    if ctx.needs_input_grad[0]:
+        gx = _dwconv_geo_dgrad(gy, w)
+    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        gw, gb = _dwconv_geo_wgrad(gy, x, w.shape[-1], ctx.has_bias)
+        if not ctx.has_bias:
+            gb = None
+    return gx, gw, gb
+
+
+_autograd("dwconv_geo", _dw_setup, _dw_backward)
 
 
 def dwconv_geo(x, weight, bias=None):
-    return _DwConvGeo.apply(x, weight, bias)
+    require_hip(x, weight, bias)
+    return _dwconv_geo(x, weight, bias)
 
 
 # ---------------------------------------------------------------------------
 # a11 / a14 resampling
 # ---------------------------------------------------------------------------
-class _AvgPoolGeo(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, stride):
-        require_hip(x)
-        x = x.contiguous()
-        planes, H, W = _planes_hw(x)
-        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        y = torch.empty(*x.shape[:-2], Ho, Wo, dtype=x.dtype, device=x.device)
-        check(lib.paradis_avgpool_geo_fwd(dptr(x), dptr(y), planes, H, W, stride, stream_ptr()),
-              "avgpool_geo_fwd")
-        ctx.meta = (x.shape, stride)
-        return y
+@_define("avgpool_geo(Tensor x, int stride) -> Tensor")
+def _avgpool_geo(x, stride):
+    _f32(x)
+    x = x.contiguous()
+    planes, H, W = _planes_hw(x)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(*x.shape[:-2], Ho, Wo, dtype=x.dtype, device=x.device)
+    check(lib.paradis_avgpool_geo_fwd(dptr(x), dptr(y), planes, H, W, stride, stream_ptr()), "avgpool_geo_fwd")
+    return y
 
-    @staticmethod
-    def backward(ctx, gy):
-        shape, stride = ctx.meta
-        gy = gy.contiguous()
-        gx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
-        planes, H, W = _planes_hw(gx)
-        check(lib.paradis_avgpool_geo_bwd(dptr(gy), dptr(gx), planes, H, W, stride, stream_ptr()),
-              "avgpool_geo_bwd")
-        return gx, None
 
+@_fake("avgpool_geo")
+def _(x, stride):
+    H, W = x.shape[-2:]
+    return x.new_empty(*x.shape[:-2], (H - 1) // stride + 1, (W - 1) // stride + 1)
+
+
+@_define("avgpool_geo_backward(Tensor gy, int H, int W, int stride) -> Tensor")
+def _avgpool_geo_backward(gy, H, W, stride):
+    _f32(gy)
+    gy = gy.contiguous()
+    gx = torch.empty(*gy.shape[:-2], H, W, dtype=gy.dtype, device=gy.device)
+    check(lib.paradis_avgpool_geo_bwd(dptr(gy), dptr(gx), gx.numel() // (H * W), H, W, stride, stream_ptr()),
+          "avgpool_geo_bwd")
+    return gx
+
+
+@_fake("avgpool_geo_backward")
+def _(gy, H, W, stride):
+    return gy.new_empty(*gy.shape[:-2], H, W)
+
+
+def _pool_setup(ctx, inputs, output):
+    ctx.meta = (inputs[0].shape[-2], inputs[0].shape[-1], inputs[1])
+
+
+def _pool_backward(ctx, gy):
+    return _avgpool_geo_backward(gy, *ctx.meta), None
+
+
+_autograd("avgpool_geo", _pool_setup, _pool_backward)
 
 _BOX_WEIGHTS = {}
 
@@ -285,193 +473,322 @@ _BOX_WEIGHTS = {}
 def avgpool_geo(x, stride: int):
     if stride < 1:
         raise ValueError("Coarsening factor must be >=1")
-    if stride == 1 and x.is_cuda:
+    require_hip(x)
+    if stride == 1:
         # stride 1 = depthwise 5x5 stencil with uniform taps 1/25: reuse the LDS-tiled kernels
         # (forward 2.8x, backward 5x faster than the generic strided kernels)
-        key = (x.shape[1], x.device)
+        key = (x.shape[1], str(x.device))
         if key not in _BOX_WEIGHTS:
             _BOX_WEIGHTS[key] = torch.full((x.shape[1], 1, 5, 5), 1.0 / 25.0, dtype=torch.float32,
                                            device=x.device)
-        return _DwConvGeo.apply(x, _BOX_WEIGHTS[key], None)
-    return _AvgPoolGeo.apply(x, int(stride))
+        return _dwconv_geo(x, _BOX_WEIGHTS[key], None)
+    return _avgpool_geo(x, int(stride))
 
 
-class _UpsampleLonP(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, nlat, nlon):
-        require_hip(x)
-        x = x.contiguous()
-        planes, Hc, Wc = _planes_hw(x)
-        y = torch.empty(*x.shape[:-2], nlat, nlon, dtype=x.dtype, device=x.device)
-        check(lib.paradis_upsample_lonp_fwd(dptr(x), dptr(y), planes, Hc, Wc, nlat, nlon, stream_ptr()),
-              "upsample_lonp_fwd")
-        ctx.meta = (x.shape, nlat, nlon)
-        return y
+@_define("upsample_lonp(Tensor x, int nlat, int nlon) -> Tensor")
+def _upsample_lonp(x, nlat, nlon):
+    _f32(x)
+    x = x.contiguous()
+    planes, Hc, Wc = _planes_hw(x)
+    y = torch.empty(*x.shape[:-2], nlat, nlon, dtype=x.dtype, device=x.device)
+    check(lib.paradis_upsample_lonp_fwd(dptr(x), dptr(y), planes, Hc, Wc, nlat, nlon, stream_ptr()),
+          "upsample_lonp_fwd")
+    return y
 
-    @staticmethod
-    def backward(ctx, gy):
-        shape, nlat, nlon = ctx.meta
-        gy = gy.contiguous()
-        gx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
-        planes, Hc, Wc = _planes_hw(gx)
-        check(lib.paradis_upsample_lonp_bwd(dptr(gy), dptr(gx), planes, Hc, Wc, nlat, nlon, stream_ptr()),
-              "upsample_lonp_bwd")
-        return gx, None, None
+
+@_fake("upsample_lonp")
+def _(x, nlat, nlon):
+    return x.new_empty(*x.shape[:-2], nlat, nlon)
+
+
+@_define("upsample_lonp_backward(Tensor gy, int Hc, int Wc) -> Tensor")
+def _upsample_lonp_backward(gy, Hc, Wc):
+    _f32(gy)
+    gy = gy.contiguous()
+    nlat, nlon = gy.shape[-2:]
+    gx = torch.empty(*gy.shape[:-2], Hc, Wc, dtype=gy.dtype, device=gy.device)
+    check(lib.paradis_upsample_lonp_bwd(dptr(gy), dptr(gx), gx.numel() // (Hc * Wc), Hc, Wc, nlat, nlon,
+                                        stream_ptr()), "upsample_lonp_bwd")
+    return gx
+
+
+@_fake("upsample_lonp_backward")
+def _(gy, Hc, Wc):
+    return gy.new_empty(*gy.shape[:-2], Hc, Wc)
+
+
+def _up_setup(ctx, inputs, output):
+    ctx.meta = tuple(inputs[0].shape[-2:])
+
+
+def _up_backward(ctx, gy):
+    return _upsample_lonp_backward(gy, *ctx.meta), None, None
+
+
+_autograd("upsample_lonp", _up_setup, _up_backward)
 
 
 def upsample_lonp(x, nlat: int, nlon: int):
     if tuple(x.shape[-2:]) == (int(nlat), int(nlon)):
         return x   # equal sizes: ATen's align_corners interpolation is the exact identity
-    return _UpsampleLonP.apply(x, int(nlat), int(nlon))
+    require_hip(x)
+    return _upsample_lonp(x, int(nlat), int(nlon))
 
 
 # ---------------------------------------------------------------------------
 # a8 ChannelNorm (reference model/blocks.py:118-134), optionally over a virtual concat
 # ---------------------------------------------------------------------------
-class _ChannelNorm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x1, x2, weight, bias, eps, with_skip):
-        require_hip(x1, x2, weight, bias)
-        x1_in = x1
-        x1, bs1 = _plane_view(x1)
-        B, C1, H, W = x1.shape
-        C2, bs2 = 0, 0
-        if x2 is not None:
-            x2, bs2 = _plane_view(x2)
-            C2 = x2.shape[1]
-        P = H * W
-        C = C1 + C2
-        y = torch.empty(B, C, H, W, dtype=x1.dtype, device=x1.device)
-        mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
-        rstd = torch.empty_like(mean)
-        check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y),
-                                           dptr(mean), dptr(rstd), B, C1, C2, P, bs1, bs2, eps,
-                                           stream_ptr()), "channel_norm_fwd")
-        ctx.save_for_backward(x1, x2 if x2 is not None else x1.new_empty(0), weight, mean, rstd)
-        ctx.meta = (C1, C2, bs1, bs2, H, W)
-        if with_skip:
-            # second output = x1 itself: consumers of the residual path take it from here, so both
-            # gradients of x1 arrive at this node and are summed inside the backward kernel
-            ctx.set_materialize_grads(False)
-            return y, x1_in
-        return y
+@_define("channel_norm(Tensor x1, Tensor? x2, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor, Tensor)")
+def _channel_norm(x1, x2, weight, bias, eps):
+    _f32(x1, x2, weight, bias)
+    x1, bs1 = _plane_view(x1)
+    B, C1, H, W = x1.shape
+    C2, bs2 = 0, 0
+    if x2 is not None:
+        x2, bs2 = _plane_view(x2)
+        C2 = x2.shape[1]
+    P = H * W
+    y = torch.empty(B, C1 + C2, H, W, dtype=x1.dtype, device=x1.device)
+    mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
+    rstd = torch.empty_like(mean)
+    check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y), dptr(mean),
+                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, stream_ptr()), "channel_norm_fwd")
+    return y, mean, rstd
+
+
+@_fake("channel_norm")
+def _(x1, x2, weight, bias, eps):
+    B, C1, H, W = x1.shape
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
+    return x1.new_empty(B, C, H, W), x1.new_empty(B, H * W), x1.new_empty(B, H * W)
+
+
+@_define("channel_norm_backward(Tensor gy, Tensor x1, Tensor? x2, Tensor weight, Tensor mean, Tensor rstd, "
+         "Tensor? add) -> (Tensor, Tensor, Tensor, Tensor)")
+def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
+    """``add``: a gradient that reaches x1 along another path (the residual branch around the block);
+    it is added inside the kernel instead of by a separate accumulation pass."""
+    _f32(gy, x1, x2, add)
+    x1, bs1 = _plane_view(x1)
+    B, C1, H, W = x1.shape
+    C2, bs2 = 0, 0
+    if x2 is not None:
+        x2, bs2 = _plane_view(x2)
+        C2 = x2.shape[1]
+    P, C = H * W, C1 + C2
+    gy = gy.contiguous()
+    add_bs = 0
+    if add is not None:
+        add, add_bs = _plane_view(add)
+    gx1 = torch.empty(B, C1, H, W, dtype=gy.dtype, device=gy.device)
+    gx2 = torch.empty(B, C2, H, W, dtype=gy.dtype, device=gy.device)
+    gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
+    gb = torch.empty_like(gw)
+    ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
+    check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight), dptr(mean),
+                                       dptr(rstd), dptr(gx1), dptr(gx2) if C2 else None, dptr(gw), dptr(gb), B,
+                                       C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add), add_bs, dptr(ws),
+                                       stream_ptr()), "channel_norm_bwd")
+    return gx1, gx2, gw, gb
+
+
+@_fake("channel_norm_backward")
+def _(gy, x1, x2, weight, mean, rstd, add):
+    B, C1, H, W = x1.shape
+    C2 = x2.shape[1] if x2 is not None else 0
+    return (gy.new_empty(B, C1, H, W), gy.new_empty(B, C2, H, W), gy.new_empty(C1 + C2), gy.new_empty(C1 + C2))
+
+
+def _norm_setup(ctx, inputs, output):
+    x1, x2, weight, bias, eps = inputs
+    y, mean, rstd = output
+    ctx.save_for_backward(x1, x2, weight, mean, rstd)
+    ctx.mark_non_differentiable(mean, rstd)
+    ctx.set_materialize_grads(False)
+
+
+def _norm_backward(ctx, gy, gmean=None, grstd=None):
+    x1, x2, weight, mean, rstd = ctx.saved_tensors
+    if gy is None:
+        return None, None, None, None, None
+    gx1, gx2, gw, gb = _channel_norm_backward(gy, x1, x2, weight, mean, rstd, None)
+    return gx1, (gx2 if x2 is not None else None), gw, gb, None
+
+
+_autograd("channel_norm", _norm_setup, _norm_backward)
+
+
+class _ChannelNormSkip(torch.autograd.Function):
+    """``(channel_norm(x), x)``: the second output is ``x`` itself for the residual branch around the
+    block, so every gradient of ``x`` arrives at this node and is added inside the backward kernel
+    (``channel_norm_backward(..., add=...)``) instead of by autograd's accumulation pass.  Eager only:
+    under ``torch.compile`` the plain op is used and the traced graph holds the addition."""
 
     @staticmethod
-    def backward(ctx, gy, gskip=None):
+    def forward(ctx, x1, x2, weight, bias, eps):
+        y, mean, rstd = _channel_norm(x1, x2, weight, bias, eps)
+        ctx.save_for_backward(x1, x2, weight, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return y, x1
+
+    @staticmethod
+    def backward(ctx, gy, gskip):
         x1, x2, weight, mean, rstd = ctx.saved_tensors
-        C1, C2, bs1, bs2, H, W = ctx.meta
-        B, P, C = x1.shape[0], H * W, C1 + C2
         if gy is None:          # only the skip path was used
-            return gskip, None, None, None, None, None
-        gy = gy.contiguous()
-        add, add_bs = None, 0
-        if gskip is not None:
-            add, add_bs = _plane_view(gskip)
-        gx1 = torch.empty(B, C1, H, W, dtype=gy.dtype, device=gy.device)
-        gx2 = torch.empty(B, C2, H, W, dtype=gy.dtype, device=gy.device) if C2 else None
-        gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
-        gb = torch.empty_like(gw)
-        ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
-        check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight),
-                                           dptr(mean), dptr(rstd), dptr(gx1), dptr(gx2), dptr(gw),
-                                           dptr(gb), B, C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add),
-                                           add_bs, dptr(ws), stream_ptr()), "channel_norm_bwd")
-        return gx1, gx2, gw, gb, None, None
+            return gskip, None, None, None, None
+        gx1, gx2, gw, gb = _channel_norm_backward(gy, x1, x2, weight, mean, rstd, gskip)
+        return gx1, (gx2 if x2 is not None else None), gw, gb, None
 
 
 def channel_norm(x, weight, bias, eps: float = 1e-5, x_extra=None):
     """ChannelNorm over channels of ``x`` (and, virtually concatenated after them, ``x_extra``)."""
-    return _ChannelNorm.apply(x, x_extra, weight, bias, float(eps), False)
+    require_hip(x, x_extra, weight, bias)
+    return _channel_norm(x, x_extra, weight, bias, float(eps))[0]
 
 
 def channel_norm_skip(x, weight, bias, eps: float = 1e-5, x_extra=None):
-    """``(channel_norm(x), x)``: the second output is ``x`` for the residual branch around the block.
-    Its gradient is added to the normalisation's input gradient inside the backward kernel instead of
-    by a separate autograd accumulation pass."""
-    return _ChannelNorm.apply(x, x_extra, weight, bias, float(eps), True)
+    """``(channel_norm(x), x)`` for a block with a residual branch around it (see ``_ChannelNormSkip``)."""
+    require_hip(x, x_extra, weight, bias)
+    if torch.compiler.is_compiling():
+        return _channel_norm(x, x_extra, weight, bias, float(eps))[0], x
+    return _ChannelNormSkip.apply(x, x_extra, weight, bias, float(eps))
 
 
 # ---------------------------------------------------------------------------
 # a9 GlobalBias map (reference model/blocks.py:188-196)
 # ---------------------------------------------------------------------------
-class _GlobalBiasMap(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, A, U, V, Pw):
-        require_hip(A, U, V, Pw)
-        A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
-        Cin, R = A.shape
-        H, W = U.shape[1], V.shape[1]
-        if Pw is not None:
-            Pw = Pw.contiguous()
-            Co = Pw.shape[0]
-            m8 = torch.empty(Cin, H, W, dtype=A.dtype, device=A.device)
-        else:
-            Co, m8 = Cin, None
-        out = torch.empty(Co, H, W, dtype=A.dtype, device=A.device)
-        check(lib.paradis_global_bias_map_fwd(dptr(A), dptr(U), dptr(V), dptr(Pw), dptr(m8), dptr(out),
-                                              Cin, Co, R, H, W, stream_ptr()), "global_bias_map_fwd")
-        ctx.save_for_backward(A, U, V, Pw if Pw is not None else A.new_empty(0),
-                              m8 if m8 is not None else A.new_empty(0))
-        ctx.has_proj = Pw is not None
-        return out
+@_define("global_bias_map(Tensor A, Tensor U, Tensor V, Tensor? Pw) -> (Tensor, Tensor)")
+def _global_bias_map(A, U, V, Pw):
+    _f32(A, U, V, Pw)
+    A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
+    Cin, R = A.shape
+    H, W = U.shape[1], V.shape[1]
+    if Pw is not None:
+        Pw = Pw.contiguous()
+        Co = Pw.shape[0]
+        m8 = torch.empty(Cin, H, W, dtype=A.dtype, device=A.device)
+    else:
+        Co, m8 = Cin, A.new_empty(0)
+    out = torch.empty(Co, H, W, dtype=A.dtype, device=A.device)
+    check(lib.paradis_global_bias_map_fwd(dptr(A), dptr(U), dptr(V), dptr(Pw), dptr(m8) if Pw is not None else None,
+                                          dptr(out), Cin, Co, R, H, W, stream_ptr()), "global_bias_map_fwd")
+    return out, m8
 
-    @staticmethod
-    def backward(ctx, gmap):
-        A, U, V, Pw, m8 = ctx.saved_tensors
-        Cin, R = A.shape
-        H, W = U.shape[1], V.shape[1]
-        gmap = gmap.contiguous()
-        Co = gmap.shape[0]
-        gA, gU, gV = torch.empty_like(A), torch.empty_like(U), torch.empty_like(V)
-        gPw = torch.empty_like(Pw) if ctx.has_proj else None
-        ws = _ws(lib.paradis_global_bias_map_bwd_ws_bytes(Cin, Co, R, H, W), A.device)
-        check(lib.paradis_global_bias_map_bwd(dptr(gmap), dptr(A), dptr(U), dptr(V),
-                                              dptr(Pw) if ctx.has_proj else None,
-                                              dptr(m8) if ctx.has_proj else None, dptr(gA), dptr(gU),
-                                              dptr(gV), dptr(gPw), Cin, Co, R, H, W, dptr(ws),
-                                              stream_ptr()), "global_bias_map_bwd")
-        return gA, gU, gV, gPw
+
+@_fake("global_bias_map")
+def _(A, U, V, Pw):
+    Cin, H, W = A.shape[0], U.shape[1], V.shape[1]
+    if Pw is not None:
+        return A.new_empty(Pw.shape[0], H, W), A.new_empty(Cin, H, W)
+    return A.new_empty(Cin, H, W), A.new_empty(0)
+
+
+@_define("global_bias_map_backward(Tensor gmap, Tensor A, Tensor U, Tensor V, Tensor? Pw, Tensor m8) "
+         "-> (Tensor, Tensor, Tensor, Tensor)")
+def _global_bias_map_backward(gmap, A, U, V, Pw, m8):
+    _f32(gmap)
+    A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
+    Cin, R = A.shape
+    H, W = U.shape[1], V.shape[1]
+    gmap = gmap.contiguous()
+    Co = gmap.shape[0]
+    has_proj = Pw is not None
+    gA, gU, gV = torch.empty_like(A), torch.empty_like(U), torch.empty_like(V)
+    gPw = torch.empty_like(Pw) if has_proj else A.new_empty(0)
+    ws = _ws(lib.paradis_global_bias_map_bwd_ws_bytes(Cin, Co, R, H, W), A.device)
+    check(lib.paradis_global_bias_map_bwd(dptr(gmap), dptr(A), dptr(U), dptr(V),
+                                          dptr(Pw.contiguous()) if has_proj else None,
+                                          dptr(m8) if has_proj else None, dptr(gA), dptr(gU), dptr(gV),
+                                          dptr(gPw) if has_proj else None, Cin, Co, R, H, W, dptr(ws),
+                                          stream_ptr()), "global_bias_map_bwd")
+    return gA, gU, gV, gPw
+
+
+@_fake("global_bias_map_backward")
+def _(gmap, A, U, V, Pw, m8):
+    return (A.new_empty(A.shape), U.new_empty(U.shape), V.new_empty(V.shape),
+            A.new_empty(Pw.shape) if Pw is not None else A.new_empty(0))
+
+
+def _gbm_setup(ctx, inputs, output):
+    A, U, V, Pw = inputs
+    ctx.save_for_backward(A, U, V, Pw, output[1])
+    ctx.mark_non_differentiable(output[1])
+    ctx.set_materialize_grads(False)
+
+
+def _gbm_backward(ctx, gmap, gm8=None):
+    A, U, V, Pw, m8 = ctx.saved_tensors
+    if gmap is None:
+        return None, None, None, None
+    gA, gU, gV, gPw = _global_bias_map_backward(gmap, A, U, V, Pw, m8)
+    return gA, gU, gV, (gPw if Pw is not None else None)
+
+
+_autograd("global_bias_map", _gbm_setup, _gbm_backward)
 
 
 def global_bias_map(A, U, V, Pw=None):
-    return _GlobalBiasMap.apply(A, U, V, Pw)
+    require_hip(A, U, V, Pw)
+    return _global_bias_map(A, U, V, Pw)[0]
 
 
-class _GlobalBiasM8(torch.autograd.Function):
+@_define("global_bias_m8(Tensor A, Tensor U, Tensor V) -> Tensor")
+def _global_bias_m8(A, U, V):
     """Un-projected rank-R map m8[Cin,H,W]; the projection to the layer width is applied inside
     the GEMM epilogue (``pointwise(..., bias_proj=(m8, Pw))``) so the [Co,H,W] map is never stored."""
+    _f32(A, U, V)
+    A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
+    Cin, R = A.shape
+    H, W = U.shape[1], V.shape[1]
+    m8 = torch.empty(Cin, H, W, dtype=A.dtype, device=A.device)
+    check(lib.paradis_global_bias_m8_fwd(dptr(A), dptr(U), dptr(V), dptr(m8), Cin, R, H, W, stream_ptr()),
+          "global_bias_m8_fwd")
+    return m8
 
-    @staticmethod
-    def forward(ctx, A, U, V):
-        require_hip(A, U, V)
-        A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
-        Cin, R = A.shape
-        H, W = U.shape[1], V.shape[1]
-        m8 = torch.empty(Cin, H, W, dtype=A.dtype, device=A.device)
-        check(lib.paradis_global_bias_m8_fwd(dptr(A), dptr(U), dptr(V), dptr(m8), Cin, R, H, W, stream_ptr()),
-              "global_bias_m8_fwd")
-        ctx.save_for_backward(A, U, V)
-        return m8
 
-    @staticmethod
-    def backward(ctx, gm8):
-        A, U, V = ctx.saved_tensors
-        Cin, R = A.shape
-        H, W = U.shape[1], V.shape[1]
-        gm8 = gm8.contiguous()
-        gA, gU, gV = torch.empty_like(A), torch.empty_like(U), torch.empty_like(V)
-        ws = _ws(lib.paradis_global_bias_map_bwd_ws_bytes(Cin, Cin, R, H, W), A.device)
-        check(lib.paradis_global_bias_m8_bwd(dptr(gm8), dptr(A), dptr(U), dptr(V), dptr(gA), dptr(gU), dptr(gV),
-                                             Cin, R, H, W, dptr(ws), stream_ptr()), "global_bias_m8_bwd")
-        return gA, gU, gV
+@_fake("global_bias_m8")
+def _(A, U, V):
+    return A.new_empty(A.shape[0], U.shape[1], V.shape[1])
+
+
+@_define("global_bias_m8_backward(Tensor gm8, Tensor A, Tensor U, Tensor V) -> (Tensor, Tensor, Tensor)")
+def _global_bias_m8_backward(gm8, A, U, V):
+    _f32(gm8)
+    A, U, V = A.contiguous(), U.contiguous(), V.contiguous()
+    Cin, R = A.shape
+    H, W = U.shape[1], V.shape[1]
+    gm8 = gm8.contiguous()
+    gA, gU, gV = torch.empty_like(A), torch.empty_like(U), torch.empty_like(V)
+    ws = _ws(lib.paradis_global_bias_map_bwd_ws_bytes(Cin, Cin, R, H, W), A.device)
+    check(lib.paradis_global_bias_m8_bwd(dptr(gm8), dptr(A), dptr(U), dptr(V), dptr(gA), dptr(gU), dptr(gV),
+                                         Cin, R, H, W, dptr(ws), stream_ptr()), "global_bias_m8_bwd")
+    return gA, gU, gV
+
+
+@_fake("global_bias_m8_backward")
+def _(gm8, A, U, V):
+    return A.new_empty(A.shape), U.new_empty(U.shape), V.new_empty(V.shape)
+
+
+def _gb8_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _gb8_backward(ctx, gm8):
+    return _global_bias_m8_backward(gm8, *ctx.saved_tensors)
+
+
+_autograd("global_bias_m8", _gb8_setup, _gb8_backward)
 
 
 def global_bias_m8(A, U, V):
-    return _GlobalBiasM8.apply(A, U, V)
+    require_hip(A, U, V)
+    return _global_bias_m8(A, U, V)
 
 
 # ---------------------------------------------------------------------------
-# a6 pointwise channel mixing on FP32 MFMA with fused epilogue
+# a6 pointwise channel mixing on the matrix cores with fused epilogue
 #     y = residual + act(W x + bias + bias_map)
 # (reference model/blocks.py:86,110 + :196 + activation + the residual adds of paradis.py:246,253)
 # ---------------------------------------------------------------------------
@@ -480,126 +797,252 @@ def global_bias_m8(A, U, V):
 # tests/test_hip_gemm_split.py), False = exact f32 MFMA chain.  PARADIS_GEMM=exact selects the latter.
 GEMM_SPLIT = os.environ.get("PARADIS_GEMM", "split") != "exact"
 
+# bf16 h/m/l tile images of the weights (split GEMMs) are rebuilt only when the weights change:
+# keyed on the parameter object, its data pointer, its autograd version (every torch in-place update
+# bumps it) and WEIGHT_EPOCH, which the HIP optimisers bump (their kernels write through raw pointers).
+WEIGHT_EPOCH = 0
+_IMAGES = {}     # (id(weight), transpose) -> (weakref, data_ptr, version, epoch, image)
 
-def _split_weights(w2: torch.Tensor, Co: int, Ci: int, transpose: bool) -> torch.Tensor:
+
+def weights_updated() -> None:
+    """Called by optimisers that update parameters through the C ABI (no version-counter bump)."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def _drop_images(wid: int) -> None:
+    _IMAGES.pop((wid, False), None)
+    _IMAGES.pop((wid, True), None)
+
+
+def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool) -> Tensor:
+    key = (id(weight), transpose)
+    ent = _IMAGES.get(key)
+    ver = weight._version
+    if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == ver and \
+            ent[3] == WEIGHT_EPOCH:
+        return ent[4]
+    w2 = weight.reshape(Co, Ci).contiguous()
     nbytes = lib.paradis_pw_gemm_split_bytes(Ci, Co) if transpose else lib.paradis_pw_gemm_split_bytes(Co, Ci)
-    out = torch.empty(nbytes, dtype=torch.uint8, device=w2.device)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, dptr(out), stream_ptr()),
           "pw_gemm_split_weights")
+    if isinstance(weight, torch.nn.Parameter) or weight.is_leaf:
+        wid = id(weight)
+        try:
+            ref = weakref.ref(weight, lambda _r, wid=wid: _drop_images(wid))
+            _IMAGES[key] = (ref, weight.data_ptr(), ver, WEIGHT_EPOCH, out)
+        except TypeError:
+            pass
     return out
 
 
-class _Pointwise(torch.autograd.Function):
-    """y = residual + act(W x + bias + bias_map).
+@_define("pointwise(Tensor x, Tensor weight, Tensor? bias, Tensor? bmap, Tensor? residual, int act, "
+         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z) -> (Tensor, Tensor)")
+def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z):
+    """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z).
 
     Activation-gradient hand-off between two chained ops (GMBlock drives it):
       * ``defer_act_grad`` (producer): the op's backward receives d(pre-activation) directly and
-        skips its own act' pass; it also returns its pre-activation ``z`` as a second output.
+        skips its own act' pass; the consumer reads the returned ``z``.
       * ``x_pre`` / ``x_act`` (consumer): x = act(x_pre) was produced by such an op; the consumer's
         dgrad multiplies by act'(x_pre) in the GEMM epilogue, so what it returns as the gradient of
         ``x`` already is the producer's d(pre-activation).
     """
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw):
-        require_hip(x, weight, bias, bmap, residual, x_pre, m8, pw)
-        x, x_bs = _plane_view(x)
-        B, Ci, H, W = x.shape
-        Co = weight.shape[0]
-        P = H * W
-        w2 = weight.reshape(Co, -1)
-        assert w2.shape[1] == Ci, "weight/in-channel mismatch"
-        w2 = w2.contiguous()
-        res_bs = 0
-        if residual is not None:
-            residual, res_bs = _plane_view(residual)
-        if bmap is not None:
-            bmap = bmap.contiguous()
-        y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
-        need_z = act != 0 and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[9:11])
-                               or defer_act_grad)
-        cin = 0
-        if pw is not None:
-            m8, pw = m8.contiguous(), pw.contiguous()
-            cin = pw.shape[1]
-            assert pw.shape[0] == Co and m8.shape == (cin, H, W) and bmap is None
-            assert Co % 4 == 0 and cin <= 16, "fused GlobalBias projection needs Co % 4 == 0 and <= 16 bias channels"
-            pwt = pw.t().contiguous()   # [cin, Co]: four consecutive output rows per 16-byte load
-        z = torch.empty_like(y) if need_z else None
-        w2t = wsp = None
-        split = GEMM_SPLIT
-        if split:
-            # bf16-split image of the weights (h/m/l planes in tile order) for the split-MFMA kernel
-            wsp = _split_weights(w2, Co, Ci, transpose=False)
-        elif Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
+    _f32(x, weight, bias, bmap, residual, m8, pw)
+    x, x_bs = _plane_view(x)
+    B, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    P = H * W
+    assert weight.numel() == Co * Ci, "weight/in-channel mismatch"
+    res_bs = 0
+    if residual is not None:
+        residual, res_bs = _plane_view(residual)
+    if bmap is not None:
+        bmap = bmap.contiguous()
+    y = torch.empty(B, Co, H, W, dtype=x.dtype, device=x.device)
+    cin, pwt = 0, None
+    if pw is not None:
+        m8, pw = m8.contiguous(), pw.contiguous()
+        cin = pw.shape[1]
+        assert pw.shape[0] == Co and m8.shape == (cin, H, W) and bmap is None
+        assert Co % 4 == 0 and cin <= 16, "fused GlobalBias projection needs Co % 4 == 0 and <= 16 bias channels"
+        pwt = pw.t().contiguous()   # [cin, Co]: four consecutive output rows per 16-byte load
+    z = torch.empty_like(y) if (save_z and act != 0) else y.new_empty(0)
+    w2 = w2t = wsp = None
+    if GEMM_SPLIT:
+        wsp = _split_image(weight, Co, Ci, False)   # bf16 h/m/l planes in tile order
+    else:
+        w2 = weight.reshape(Co, Ci).contiguous()
+        if Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
             # [Ci,Co] copy of the weights: makes the A operand row-contiguous for the LDS-DMA kernel
             w2t = torch.empty(Ci, Co, dtype=x.dtype, device=x.device)
             check(lib.paradis_transpose(dptr(w2), dptr(w2t), Co, Ci, stream_ptr()), "transpose")
-        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), dptr(x), dptr(bias),
-                  dptr(bmap), dptr(m8), dptr(pwt) if cin else None, cin, dptr(residual), dptr(y), dptr(z), B, Co, Ci, P, x_bs,
-                  res_bs, Co * P, act, stream_ptr())
-        if x_pre is not None:
-            x_pre = x_pre.contiguous()
-        ctx.save_for_backward(x, w2, z if z is not None else x.new_empty(0),
-                              x_pre if x_pre is not None else x.new_empty(0),
-                              m8 if pw is not None else x.new_empty(0),
-                              pw if pw is not None else x.new_empty(0))
-        ctx.meta = (x_bs, act, bias is not None, bmap is not None, residual is not None, weight.shape,
-                    x_act if x_pre is not None else 0, bool(defer_act_grad), split)
-        if defer_act_grad:
-            # z carries no gradient; without this autograd would materialise a full-size zero tensor
-            # for it on every backward (24 fills of [B,896,H,W] per training step)
-            ctx.mark_non_differentiable(z)
-            ctx.set_materialize_grads(False)
-            return y, z
-        return y
+    if w2 is None:
+        w2 = weight.reshape(Co, Ci)
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+    _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), dptr(x), dptr(bias),
+              dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
+              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
+    return y, z
 
-    @staticmethod
-    def backward(ctx, gy, *unused):
-        x, w2, z, x_pre, m8, pw = ctx.saved_tensors
-        x_bs, act, has_bias, has_map, has_res, wshape, x_act, deferred, split = ctx.meta
-        has_proj = pw.numel() > 0
-        B, Ci, H, W = x.shape
-        Co, P = w2.shape[0], H * W
-        gy = gy.contiguous()
-        st = stream_ptr()
-        gres = gy if has_res else None
-        if act != 0 and not deferred:
-            dz = torch.empty_like(gy)
-            check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, st), "act_bwd")
-        else:
-            dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
-        gx = gw = gb = gmap = gm8 = gpw = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty(B, Ci, H, W, dtype=gy.dtype, device=gy.device)
-            zmul = x_pre if x_act != 0 else None
-            wtsp = _split_weights(w2, Co, Ci, transpose=True) if split else None
-            _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), dptr(dz), dptr(zmul), None, dptr(gx),
-                      B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P, x_act, st)
-        want_b = has_bias and ctx.needs_input_grad[2]
-        want_p = has_proj and (ctx.needs_input_grad[9] or ctx.needs_input_grad[10])
-        want_m = (has_map and ctx.needs_input_grad[3]) or want_p
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty(Co, Ci, dtype=gy.dtype, device=gy.device)
-            ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), gy.device)
-            if want_b and not want_m:   # bias gradient = row sums of dz: fused into the wgrad GEMM
-                gb = torch.empty(Co, dtype=gy.dtype, device=gy.device)
-                want_b = False
-            _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), dptr(gb), B, Co,
-                      Ci, P, Co * P, x_bs, 1 if split else 0, dptr(ws), st)
-            gw = gw.reshape(wshape)
-        if want_b or want_m:
-            gb = torch.empty(Co, dtype=gy.dtype, device=gy.device) if want_b else None
-            gmap = torch.empty(Co, H, W, dtype=gy.dtype, device=gy.device) if want_m else None
-            check(lib.paradis_bias_grads(dptr(dz), dptr(gmap), dptr(gb), B, Co, P, Co * P, st), "bias_grads")
-        if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
-            cin = pw.shape[1]
-            gpw = torch.empty_like(pw)
-            gm8 = torch.empty_like(m8)
-            check(lib.paradis_global_bias_proj_bwd(dptr(gmap), dptr(m8), dptr(pw), dptr(gpw), dptr(gm8), cin,
-                                                   Co, P, st), "global_bias_proj_bwd")
+
+@_fake("pointwise")
+def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z):
+    B, _, H, W = x.shape
+    y = x.new_empty(B, weight.shape[0], H, W)
+    return y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0))
+
+
+@_define("act_backward(Tensor gy, Tensor z, int act) -> Tensor")
+def _act_backward(gy, z, act):
+    _f32(gy, z)
+    gy, z = gy.contiguous(), z.contiguous()
+    dz = torch.empty_like(gy)
+    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, stream_ptr()), "act_bwd")
+    return dz
+
+
+@_fake("act_backward")
+def _(gy, z, act):
+    return gy.new_empty(gy.shape)
+
+
+@_define("pw_gemm_dgrad(Tensor dz, Tensor weight, Tensor? zmul, int x_act) -> Tensor")
+def _pw_gemm_dgrad(dz, weight, zmul, x_act):
+    """gx = W^T dz (* act'(zmul) when the producing layer deferred its activation gradient)."""
+    _f32(dz, weight, zmul)
+    dz = dz.contiguous()
+    B, Co, H, W = dz.shape
+    Ci = weight.numel() // Co
+    P = H * W
+    gx = torch.empty(B, Ci, H, W, dtype=dz.dtype, device=dz.device)
+    w2 = weight.reshape(Co, Ci)
+    if not w2.is_contiguous():
+        w2 = w2.contiguous()
+    wtsp = _split_image(weight, Co, Ci, True) if GEMM_SPLIT else None
+    if zmul is not None:
+        zmul = zmul.contiguous()
+    _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), dptr(dz),
+              dptr(zmul) if x_act != 0 else None, None, dptr(gx), B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P,
+              x_act, stream_ptr())
+    return gx
+
+
+@_fake("pw_gemm_dgrad")
+def _(dz, weight, zmul, x_act):
+    B, Co, H, W = dz.shape
+    return dz.new_empty(B, weight.numel() // Co, H, W)
+
+
+@_define("pw_gemm_wgrad(Tensor dz, Tensor x, bool want_bias) -> (Tensor, Tensor)")
+def _pw_gemm_wgrad(dz, x, want_bias):
+    """gW[Co,Ci] = sum over samples and points of dz x^T; the bias gradient (row sums of dz) falls out
+    of the same pass."""
+    _f32(dz, x)
+    dz = dz.contiguous()
+    x, x_bs = _plane_view(x)
+    B, Co, H, W = dz.shape
+    Ci, P = x.shape[1], H * W
+    gw = torch.empty(Co, Ci, dtype=dz.dtype, device=dz.device)
+    gb = torch.empty(Co if want_bias else 0, dtype=dz.dtype, device=dz.device)
+    ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), dz.device)
+    _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), dptr(gb) if want_bias else None,
+              B, Co, Ci, P, Co * P, x_bs, 1 if GEMM_SPLIT else 0, dptr(ws), stream_ptr())
+    return gw, gb
+
+
+@_fake("pw_gemm_wgrad")
+def _(dz, x, want_bias):
+    Co, Ci = dz.shape[1], x.shape[1]
+    return dz.new_empty(Co, Ci), dz.new_empty(Co if want_bias else 0)
+
+
+@_define("bias_grads(Tensor dz, bool want_bias, bool want_map) -> (Tensor, Tensor)")
+def _bias_grads(dz, want_bias, want_map):
+    """gb[Co] = sum over (B,H,W), gmap[Co,H,W] = sum over B of dz."""
+    _f32(dz)
+    dz = dz.contiguous()
+    B, Co, H, W = dz.shape
+    gb = torch.empty(Co if want_bias else 0, dtype=dz.dtype, device=dz.device)
+    gmap = torch.empty((Co, H, W) if want_map else (0,), dtype=dz.dtype, device=dz.device)
+    check(lib.paradis_bias_grads(dptr(dz), dptr(gmap) if want_map else None, dptr(gb) if want_bias else None, B,
+                                 Co, H * W, Co * H * W, stream_ptr()), "bias_grads")
+    return gb, gmap
+
+
+@_fake("bias_grads")
+def _(dz, want_bias, want_map):
+    B, Co, H, W = dz.shape
+    return dz.new_empty(Co if want_bias else 0), dz.new_empty((Co, H, W) if want_map else (0,))
+
+
+@_define("global_bias_proj_backward(Tensor gmap, Tensor m8, Tensor pw) -> (Tensor, Tensor)")
+def _global_bias_proj_backward(gmap, m8, pw):
+    """adjoint of the projection fused into the GEMM epilogue: gmap[Co,H,W] -> (gPw[Co,cin], gm8[cin,H,W])"""
+    _f32(gmap, m8, pw)
+    gmap, m8, pw = gmap.contiguous(), m8.contiguous(), pw.contiguous()
+    Co, cin = pw.shape
+    gpw, gm8 = torch.empty_like(pw), torch.empty_like(m8)
+    check(lib.paradis_global_bias_proj_bwd(dptr(gmap), dptr(m8), dptr(pw), dptr(gpw), dptr(gm8), cin, Co,
+                                           m8.shape[1] * m8.shape[2], stream_ptr()), "global_bias_proj_bwd")
+    return gpw, gm8
+
+
+@_fake("global_bias_proj_backward")
+def _(gmap, m8, pw):
+    return pw.new_empty(pw.shape), m8.new_empty(m8.shape)
+
+
+def _pw_setup(ctx, inputs, output):
+    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z = inputs
+    y, z = output
+    ctx.save_for_backward(x, weight, z, x_pre, m8, pw)
+    ctx.meta = (act, bias is not None, bmap is not None, residual is not None,
+                x_act if x_pre is not None else 0, bool(defer))
+    # z carries no gradient; without this autograd would materialise a full-size zero tensor for it
+    ctx.mark_non_differentiable(z)
+    ctx.set_materialize_grads(False)
+
+
+def _pw_backward(ctx, gy, gz=None):
+    x, weight, z, x_pre, m8, pw = ctx.saved_tensors
+    act, has_bias, has_map, has_res, x_act, deferred = ctx.meta
+    need = ctx.needs_input_grad
+    if gy is None:
+        return (None,) * 12
+    has_proj = pw is not None
+    gres = gy if has_res else None
+    if act != 0 and not deferred:
+        dz = _act_backward(gy, z, act)
+    else:
+        dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
+    gx = gw = gb = gmap = gm8 = gpw = None
+    if need[0]:
+        gx = _pw_gemm_dgrad(dz, weight, x_pre if x_act != 0 else None, x_act)
+    want_b = has_bias and need[2]
+    want_p = has_proj and (need[9] or need[10])
+    want_m = (has_map and need[3]) or want_p
+    if need[1]:
+        fused_b = want_b and not want_m     # bias gradient = row sums of dz: fused into the wgrad GEMM
+        gw, gbf = _pw_gemm_wgrad(dz, x, fused_b)
+        gw = gw.reshape(weight.shape)
+        if fused_b:
+            gb, want_b = gbf, False
+    if want_b or want_m:
+        gb2, gmap = _bias_grads(dz, want_b, want_m)
+        if want_b:
+            gb = gb2
+        if not want_m:
             gmap = None
-        return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw
+    if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
+        gpw, gm8 = _global_bias_proj_backward(gmap, m8, pw)
+        gmap = None
+    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None
+
+
+_autograd("pointwise", _pw_setup, _pw_backward)
 
 
 def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
@@ -609,191 +1052,284 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     ``bias_proj=(m8[Cin,H,W], Pw[Co,Cin])`` adds the projected low-rank GlobalBias map inside the GEMM
     epilogue instead of a materialised ``bias_map``.
     ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
-    called with ``x_pre=z, x_act=act`` (see ``_Pointwise``); only valid when ``y`` has no other use."""
+    called with ``x_pre=z, x_act=act`` (see the op docstring); only valid when ``y`` has no other use."""
     if defer_act_grad and (act is None or residual is not None):
         raise ValueError("defer_act_grad needs an activation and no residual")
     m8, pw = bias_proj if bias_proj is not None else (None, None)
-    return _Pointwise.apply(x, weight, bias, bias_map, residual, ACT_CODES[act], x_pre,
-                            ACT_CODES[x_act], bool(defer_act_grad), m8, pw)
+    require_hip(x, weight, bias, bias_map, residual, x_pre, m8, pw)
+    code = ACT_CODES[act]
+    save_z = bool(defer_act_grad)
+    if code != 0 and not save_z and torch.is_grad_enabled():
+        save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
+    y, z = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad),
+                      m8, pw, save_z)
+    return (y, z) if defer_act_grad else y
 
 
 # ---------------------------------------------------------------------------
 # elementwise glue
 # ---------------------------------------------------------------------------
-class _Activation(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, act):
-        require_hip(x)
-        x = x.contiguous()
-        y = torch.empty_like(x)
-        check(lib.paradis_act_fwd(dptr(x), dptr(y), x.numel(), act, stream_ptr()), "act_fwd")
-        ctx.save_for_backward(x)
-        ctx.act = act
-        return y
+@_define("activation(Tensor x, int act) -> Tensor")
+def _activation(x, act):
+    _f32(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.paradis_act_fwd(dptr(x), dptr(y), x.numel(), act, stream_ptr()), "act_fwd")
+    return y
 
-    @staticmethod
-    def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
-        gy = gy.contiguous()
-        gx = torch.empty_like(x)
-        check(lib.paradis_act_bwd(dptr(gy), dptr(x), dptr(gx), x.numel(), ctx.act, stream_ptr()), "act_bwd")
-        return gx, None
+
+@_fake("activation")
+def _(x, act):
+    return x.new_empty(x.shape)
+
+
+def _act_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+    ctx.act = inputs[1]
+
+
+def _act_bwd(ctx, gy):
+    return _act_backward(gy, ctx.saved_tensors[0], ctx.act), None
+
+
+_autograd("activation", _act_setup, _act_bwd)
 
 
 def activation(x, name: str):
     if name not in ("SiLU", "GELU"):
         raise ValueError(f"Unknown activation_fn '{name}'. Allowed: ['SiLU', 'GELU']")
-    return _Activation.apply(x, ACT_CODES[name])
+    require_hip(x)
+    return _activation(x, ACT_CODES[name])
 
 
-class _GatedBlend(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, h, adv, alpha):
-        require_hip(h, adv, alpha)
-        h, adv, alpha = h.contiguous(), adv.contiguous(), alpha.contiguous()
-        B, C, H, W = h.shape
-        out = torch.empty_like(h)
-        check(lib.paradis_gated_blend_fwd(dptr(h), dptr(adv), dptr(alpha), dptr(out), B, C, H * W,
-                                          stream_ptr()), "gated_blend_fwd")
-        ctx.save_for_backward(h, adv, alpha)
-        return out
+@_define("gated_blend(Tensor h, Tensor adv, Tensor alpha) -> Tensor")
+def _gated_blend(h, adv, alpha):
+    _f32(h, adv, alpha)
+    h, adv, alpha = h.contiguous(), adv.contiguous(), alpha.contiguous()
+    B, C, H, W = h.shape
+    out = torch.empty_like(h)
+    check(lib.paradis_gated_blend_fwd(dptr(h), dptr(adv), dptr(alpha), dptr(out), B, C, H * W, stream_ptr()),
+          "gated_blend_fwd")
+    return out
 
-    @staticmethod
-    def backward(ctx, gout):
-        h, adv, alpha = ctx.saved_tensors
-        B, C, H, W = h.shape
-        gout = gout.contiguous()
-        gh, gadv, galpha = torch.empty_like(h), torch.empty_like(h), torch.empty_like(alpha)
-        ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
-        check(lib.paradis_gated_blend_bwd(dptr(gout), dptr(h), dptr(adv), dptr(alpha), dptr(gh),
-                                          dptr(gadv), dptr(galpha), B, C, H * W, dptr(ws), stream_ptr()),
-              "gated_blend_bwd")
-        return gh, gadv, galpha
+
+@_fake("gated_blend")
+def _(h, adv, alpha):
+    return h.new_empty(h.shape)
+
+
+@_define("gated_blend_backward(Tensor gout, Tensor h, Tensor adv, Tensor alpha) -> (Tensor, Tensor, Tensor)")
+def _gated_blend_backward(gout, h, adv, alpha):
+    _f32(gout)
+    h, adv, alpha, gout = h.contiguous(), adv.contiguous(), alpha.contiguous(), gout.contiguous()
+    B, C, H, W = h.shape
+    gh, gadv, galpha = torch.empty_like(h), torch.empty_like(h), torch.empty_like(alpha)
+    ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
+    check(lib.paradis_gated_blend_bwd(dptr(gout), dptr(h), dptr(adv), dptr(alpha), dptr(gh), dptr(gadv),
+                                      dptr(galpha), B, C, H * W, dptr(ws), stream_ptr()), "gated_blend_bwd")
+    return gh, gadv, galpha
+
+
+@_fake("gated_blend_backward")
+def _(gout, h, adv, alpha):
+    return h.new_empty(h.shape), h.new_empty(h.shape), alpha.new_empty(alpha.shape)
+
+
+def _blend_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _blend_backward(ctx, gout):
+    return _gated_blend_backward(gout, *ctx.saved_tensors)
+
+
+_autograd("gated_blend", _blend_setup, _blend_backward)
 
 
 def gated_blend(h, adv, alpha):
     """h + sigmoid(alpha)[None,:,None,None] * (adv - h)   (reference model/paradis.py:239-243)"""
-    return _GatedBlend.apply(h, adv, alpha)
+    require_hip(h, adv, alpha)
+    return _gated_blend(h, adv, alpha)
 
 
-class _Add(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a, b):
-        require_hip(a, b)
-        assert a.shape == b.shape
-        a, b = a.contiguous(), b.contiguous()
-        y = torch.empty_like(a)
-        check(lib.paradis_add(dptr(a), dptr(b), dptr(y), a.numel(), stream_ptr()), "add")
-        return y
+@_define("add(Tensor a, Tensor b) -> Tensor")
+def _add(a, b):
+    _f32(a, b)
+    assert a.shape == b.shape
+    a, b = a.contiguous(), b.contiguous()
+    y = torch.empty_like(a)
+    check(lib.paradis_add(dptr(a), dptr(b), dptr(y), a.numel(), stream_ptr()), "add")
+    return y
 
-    @staticmethod
-    def backward(ctx, gy):
-        return gy, gy
+
+@_fake("add")
+def _(a, b):
+    return a.new_empty(a.shape)
+
+
+_autograd("add", lambda ctx, inputs, output: None, lambda ctx, gy: (gy, gy))
 
 
 def add(a, b):
-    return _Add.apply(a, b)
+    require_hip(a, b)
+    return _add(a, b)
 
 
-class _AddBiasMap(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, bmap):
-        require_hip(x, bmap)
-        x, bmap = x.contiguous(), bmap.contiguous()
-        B = x.shape[0]
-        assert x.shape[1:] == bmap.shape
-        y = torch.empty_like(x)
-        check(lib.paradis_add_bcast(dptr(x), dptr(bmap), dptr(y), bmap.numel(), B, stream_ptr()), "add_bcast")
-        return y
+@_define("add_bias_map(Tensor x, Tensor bmap) -> Tensor")
+def _add_bias_map(x, bmap):
+    _f32(x, bmap)
+    x, bmap = x.contiguous(), bmap.contiguous()
+    assert x.shape[1:] == bmap.shape
+    y = torch.empty_like(x)
+    check(lib.paradis_add_bcast(dptr(x), dptr(bmap), dptr(y), bmap.numel(), x.shape[0], stream_ptr()), "add_bcast")
+    return y
 
-    @staticmethod
-    def backward(ctx, gy):
-        gy = gy.contiguous()
-        B, C, H, W = gy.shape
-        gmap = None
-        if ctx.needs_input_grad[1]:
-            gmap = torch.empty(C, H, W, dtype=gy.dtype, device=gy.device)
-            check(lib.paradis_bias_grads(dptr(gy), dptr(gmap), None, B, C, H * W, C * H * W, stream_ptr()),
-                  "bias_grads")
-        return gy, gmap
+
+@_fake("add_bias_map")
+def _(x, bmap):
+    return x.new_empty(x.shape)
+
+
+def _abm_backward(ctx, gy):
+    gmap = None
+    if ctx.needs_input_grad[1]:
+        gmap = _bias_grads(gy, False, True)[1]
+    return gy, gmap
+
+
+_autograd("add_bias_map", lambda ctx, inputs, output: None, _abm_backward)
 
 
 def add_bias_map(x, bmap):
     """x[B,C,H,W] + bmap[C,H,W] (standalone GlobalBias, reference model/blocks.py:196)"""
-    return _AddBiasMap.apply(x, bmap)
+    require_hip(x, bmap)
+    return _add_bias_map(x, bmap)
 
 
 # ---------------------------------------------------------------------------
-# rows f1-f3: loss, rollout glue, optimiser step (SURVEY.md section 8f)
+# rows f1-f2: loss and rollout glue (SURVEY.md section 8f)
 # ---------------------------------------------------------------------------
-class _ParadisLoss(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, pred, target, wf, wl, kind, delta):
-        require_hip(pred, target, wf, wl)
-        pred, target = pred.contiguous(), target.contiguous()
-        B, C, H, W = pred.shape
-        assert target.shape == pred.shape and wf.numel() == C and (wl is None or wl.numel() == H)
-        loss = torch.empty((), dtype=pred.dtype, device=pred.device)
-        want_grad = ctx.needs_input_grad[0]
-        grad = torch.empty_like(pred) if want_grad else None
-        partial = torch.empty(lib.paradis_loss_blocks(pred.numel()), dtype=pred.dtype, device=pred.device)
-        check(lib.paradis_loss_fwd_bwd(dptr(pred), dptr(target), dptr(wf), dptr(wl), dptr(loss), dptr(grad),
-                                       dptr(partial), B, C, H, W, kind, delta, stream_ptr()), "loss_fwd_bwd")
-        if want_grad:
-            ctx.save_for_backward(grad)
-        return loss
+@_define("paradis_loss(Tensor pred, Tensor target, Tensor wf, Tensor? wl, int kind, float delta, bool want_grad) "
+         "-> (Tensor, Tensor)")
+def _paradis_loss(pred, target, wf, wl, kind, delta, want_grad):
+    """mean(wf[c] * wl[h] * l(pred - target)) and, in the same pass, its derivative w.r.t. pred."""
+    _f32(pred, target, wf, wl)
+    pred, target = pred.contiguous(), target.contiguous()
+    B, C, H, W = pred.shape
+    assert target.shape == pred.shape and wf.numel() == C and (wl is None or wl.numel() == H)
+    loss = torch.empty((), dtype=pred.dtype, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else pred.new_empty(0)
+    partial = torch.empty(lib.paradis_loss_blocks(pred.numel()), dtype=pred.dtype, device=pred.device)
+    check(lib.paradis_loss_fwd_bwd(dptr(pred), dptr(target), dptr(wf), dptr(wl), dptr(loss),
+                                   dptr(grad) if want_grad else None, dptr(partial), B, C, H, W, kind, delta,
+                                   stream_ptr()), "loss_fwd_bwd")
+    return loss, grad
 
-    @staticmethod
-    def backward(ctx, gout):
-        (grad,) = ctx.saved_tensors
-        out = torch.empty_like(grad)
-        check(lib.paradis_scale(dptr(grad), dptr(gout.contiguous()), dptr(out), grad.numel(), stream_ptr()),
-              "scale")
-        return out, None, None, None, None, None
+
+@_fake("paradis_loss")
+def _(pred, target, wf, wl, kind, delta, want_grad):
+    return pred.new_empty(()), (pred.new_empty(pred.shape) if want_grad else pred.new_empty(0))
+
+
+@_define("scale(Tensor x, Tensor s) -> Tensor")
+def _scale(x, s):
+    """x * s for a one-element device tensor s (no host sync)"""
+    _f32(x, s)
+    x, s = x.contiguous(), s.contiguous()
+    out = torch.empty_like(x)
+    check(lib.paradis_scale(dptr(x), dptr(s), dptr(out), x.numel(), stream_ptr()), "scale")
+    return out
+
+
+@_fake("scale")
+def _(x, s):
+    return x.new_empty(x.shape)
+
+
+def _loss_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.mark_non_differentiable(output[1])
+    ctx.set_materialize_grads(False)
+
+
+def _loss_backward(ctx, gout, ggrad=None):
+    (grad,) = ctx.saved_tensors
+    if gout is None:
+        return (None,) * 7
+    if grad.numel() == 0:
+        raise RuntimeError("paradis_loss was called with want_grad=False but its gradient is requested")
+    return (_scale(grad, gout),) + (None,) * 6
+
+
+_autograd("paradis_loss", _loss_setup, _loss_backward)
 
 
 def paradis_loss(pred, target, feature_weights, lat_weights=None, kind="reversed_huber", delta=1.0):
     """mean(feature_weights[c] * lat_weights[h] * l(pred - target)); forward and d/dpred in one pass."""
     code = {"mse": 0, "reversed_huber": 1}[kind]
-    return _ParadisLoss.apply(pred, target, feature_weights, lat_weights, code, float(delta))
+    require_hip(pred, target, feature_weights, lat_weights)
+    want_grad = torch.is_grad_enabled() and pred.requires_grad
+    return _paradis_loss(pred, target, feature_weights, lat_weights, code, float(delta), want_grad)[0]
 
 
-class _ConcatChannels(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, *parts):
-        require_hip(*parts)
-        B = parts[0].shape[0]
-        H, W = parts[0].shape[-2:]
-        chans = [p.shape[1] for p in parts]
-        P = H * W
-        out = torch.empty(B, sum(chans), H, W, dtype=parts[0].dtype, device=parts[0].device)
-        off = 0
-        for p, c in zip(parts, chans):
-            p, bs = _plane_view(p)
-            check(lib.paradis_copy_channels(dptr(p), bs, dptr(out[:, off:]), sum(chans) * P, B, c * P,
-                                            stream_ptr()), "copy_channels")
-            off += c
-        ctx.chans = chans
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        gout = gout.contiguous()
-        B, Ct, H, W = gout.shape
-        P = H * W
-        grads, off = [], 0
-        for i, c in enumerate(ctx.chans):
-            if ctx.needs_input_grad[i]:
-                g = torch.empty(B, c, H, W, dtype=gout.dtype, device=gout.device)
-                check(lib.paradis_copy_channels(dptr(gout[:, off:]), Ct * P, dptr(g), c * P, B, c * P,
-                                                stream_ptr()), "copy_channels")
-                grads.append(g)
-            else:
-                grads.append(None)
-            off += c
-        return tuple(grads)
-
-
-def concat_channels(parts):
+@_define("concat_channels(Tensor[] parts) -> Tensor", autocast=False)
+def _concat_channels(parts):
     """cat(parts, dim=1) for [B,C_i,H,W] tensors (channel slices accepted) by strided block copies."""
-    return _ConcatChannels.apply(*parts)
+    _f32(*parts)
+    B = parts[0].shape[0]
+    H, W = parts[0].shape[-2:]
+    chans = [p.shape[1] for p in parts]
+    P, Ct = H * W, sum(chans)
+    out = torch.empty(B, Ct, H, W, dtype=parts[0].dtype, device=parts[0].device)
+    off = 0
+    for p, c in zip(parts, chans):
+        p, bs = _plane_view(p)
+        check(lib.paradis_copy_channels(dptr(p), bs, dptr(out[:, off:]), Ct * P, B, c * P, stream_ptr()),
+              "copy_channels")
+        off += c
+    return out
+
+
+@_fake("concat_channels")
+def _(parts):
+    B, _, H, W = parts[0].shape
+    return parts[0].new_empty(B, sum(p.shape[1] for p in parts), H, W)
+
+
+@_define("slice_channels(Tensor x, int off, int c) -> Tensor")
+def _slice_channels(x, off, c):
+    """contiguous copy of x[:, off:off+c]"""
+    _f32(x)
+    x = x.contiguous()
+    B, Ct, H, W = x.shape
+    P = H * W
+    g = torch.empty(B, c, H, W, dtype=x.dtype, device=x.device)
+    check(lib.paradis_copy_channels(dptr(x[:, off:]), Ct * P, dptr(g), c * P, B, c * P, stream_ptr()),
+          "copy_channels")
+    return g
+
+
+@_fake("slice_channels")
+def _(x, off, c):
+    return x.new_empty(x.shape[0], c, x.shape[2], x.shape[3])
+
+
+def _cat_setup(ctx, inputs, output):
+    ctx.chans = [p.shape[1] for p in inputs[0]]
+
+
+def _cat_backward(ctx, gout):
+    grads, off = [], 0
+    need = ctx.needs_input_grad[0]
+    for i, c in enumerate(ctx.chans):
+        grads.append(_slice_channels(gout, off, c) if need[i] else None)
+        off += c
+    return (grads,)
+
+
+_autograd("concat_channels", _cat_setup, _cat_backward)
+
+
+def concat_channels(parts: Sequence[Tensor]):
+    require_hip(*parts)
+    return _concat_channels(list(parts))

@@ -49,15 +49,17 @@ class AdamW(torch.optim.Optimizer):
                                              dptr(state["exp_avg_sq"]), p.numel(), group["lr"], b1, b2,
                                              group["eps"], group["weight_decay"], int(state["step"]), st),
                       "adamw_step")
+        ops.weights_updated()     # the kernels write through raw pointers: no version-counter bump
         return loss
 
     def _step_group_fused(self, gi, group, params, step, st):
-        """One launch for the group (``paradis_adamw_multi``).  The chunk list and the parameter /
-        moment addresses are built once per parameter set; the gradient addresses are refreshed every
-        step (autograd re-allocates ``.grad`` unless DDP keeps bucket views) through a pinned staging
-        buffer, without a host synchronisation."""
+        """One launch for the group (``paradis_adamw_multi``).  Only the chunk list (a function of the
+        parameter sizes) is cached; the four address rows (parameter, gradient, both moments) are
+        rewritten every step - ``load_state_dict``, ``p.data = ...`` or ``model.to()`` replace tensors
+        behind the same parameter ids - and reach the device through a pinned staging buffer without a
+        host synchronisation."""
         dev = params[0].device
-        key = tuple(id(p) for p in params)
+        key = tuple((id(p), p.numel()) for p in params) + (str(dev),)
         cache = self.__dict__.setdefault("_fused_cache", {})
         c = cache.get(gi)
         if c is None or c["key"] != key:
@@ -69,10 +71,6 @@ class AdamW(torch.optim.Optimizer):
                     ct.append(t)
                     co.append(off)
             host = torch.empty(4 * T, dtype=torch.int64).pin_memory()
-            for t, p in enumerate(params):
-                host[t] = p.data_ptr()
-                host[2 * T + t] = self.state[p]["exp_avg"].data_ptr()
-                host[3 * T + t] = self.state[p]["exp_avg_sq"].data_ptr()
             c = cache[gi] = dict(
                 key=key, T=T, host=host, ptrs=torch.empty(4 * T, dtype=torch.int64, device=dev),
                 numel=torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev),
@@ -81,7 +79,14 @@ class AdamW(torch.optim.Optimizer):
         T, host = c["T"], c["host"]
         if c.get("pending") is not None:     # the previous step's async copy out of `host` (long done)
             c["pending"].synchronize()
-        host[T:2 * T] = torch.tensor([p.grad.data_ptr() for p in params], dtype=torch.int64)
+        moments = [(self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in params]
+        for m, v in moments:
+            require_hip(m, v)
+            if not (m.is_contiguous() and v.is_contiguous()):
+                raise RuntimeError("AdamW: non-contiguous optimizer state")
+        host.copy_(torch.tensor([p.data_ptr() for p in params] + [p.grad.data_ptr() for p in params]
+                                + [m.data_ptr() for m, _ in moments] + [v.data_ptr() for _, v in moments],
+                                dtype=torch.int64))
         c["ptrs"].copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -96,25 +101,28 @@ class AdamW(torch.optim.Optimizer):
 # Muon / NorMuon (the reference's default optimiser family, trainer.py:337-364, from `dion`)
 # ---------------------------------------------------------------------------------------------
 def build_param_groups(model, lr, weight_decay, optimizer_name):
-    """Parameter grouping of reference trainer.py:24-64: weights of Linear/Conv modules go to the
-    Muon-family algorithm (flattened to 2-D), their biases and every other parameter to AdamW."""
+    """The reference's split of the parameters between the two algorithms (rule of reference
+    ``trainer.py:24-64``): a ``weight`` owned directly by a Linear / ConvNd module is a matrix for the
+    Muon family (conv kernels flattened to 2-D); every other trainable parameter - the biases of those
+    modules first, then norm scales, GlobalBias factors, gates - is updated by AdamW.  Group order and
+    the order inside each group follow module traversal, so optimiser state dicts index parameters
+    the way the reference's do."""
     from torch import nn
-    muon_params, adamw_params, seen = [], [], set()
-    for _, module in model.named_modules():
-        if isinstance(module, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d)):
-            if getattr(module, "weight", None) is not None and module.weight.requires_grad:
-                muon_params.append(module.weight)
-                seen.add(id(module.weight))
-            if getattr(module, "bias", None) is not None and module.bias.requires_grad:
-                adamw_params.append(module.bias)
-                seen.add(id(module.bias))
-    for _, p in model.named_parameters():
-        if not p.requires_grad or id(p) in seen:
-            continue
-        adamw_params.append(p)
-        seen.add(id(p))
-    return [dict(params=muon_params, algorithm=optimizer_name, lr=lr, weight_decay=weight_decay, flatten=True),
-            dict(params=adamw_params, algorithm="adamw", lr=lr, weight_decay=weight_decay)]
+    matrix_owner = (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d)
+    role = {}                                  # id(parameter) -> "matrix" | "bias": first owner wins
+    for module in model.modules():
+        if isinstance(module, matrix_owner):
+            for name, kind in (("weight", "matrix"), ("bias", "bias")):
+                p = module._parameters.get(name)
+                if p is not None:
+                    role.setdefault(id(p), kind)
+    buckets = {"matrix": [], "bias": [], None: []}
+    for p in model.parameters():               # de-duplicated, module traversal order
+        if p.requires_grad:
+            buckets[role.get(id(p))].append(p)
+    return [dict(params=buckets["matrix"], algorithm=optimizer_name, lr=lr, weight_decay=weight_decay,
+                 flatten=True),
+            dict(params=buckets["bias"] + buckets[None], algorithm="adamw", lr=lr, weight_decay=weight_decay)]
 
 
 def _adjusted_lr(lr, shape, adjust):
@@ -204,7 +212,7 @@ class Muon(AdamW):
                     state["variance_neuron"] = torch.zeros(p.shape[0], 1, dtype=p.dtype, device=p.device)
             state["step"] += 1
         dev = params[0].device
-        key = tuple(id(p) for p in params)
+        key = tuple((id(p), tuple(p.shape)) for p in params) + (str(dev), normuon)
         cache = self.__dict__.setdefault("_muon_cache", {})
         c = cache.get(gi)
         if c is None or c["key"] != key:
@@ -217,11 +225,6 @@ class Muon(AdamW):
                 order.extend(ps)
             T = len(order)
             host = torch.zeros(4 * T, dtype=torch.int64).pin_memory()
-            for t, p in enumerate(order):
-                host[t] = p.data_ptr()
-                host[2 * T + t] = self.state[p]["momentum"].data_ptr()
-                if normuon:
-                    host[3 * T + t] = self.state[p]["variance_neuron"].data_ptr()
             ws_bytes = max(lib.paradis_muon_ws_bytes(n, rows, cols) for rows, cols, _, _, n in shapes)
             c = cache[gi] = dict(key=key, order=order, shapes=shapes, T=T, host=host,
                                  table=torch.empty(4 * T, dtype=torch.int64, device=dev),
@@ -233,7 +236,14 @@ class Muon(AdamW):
         for p in c["order"]:
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             grads.append(g)          # keep alive until the kernels are queued
-        host[T:2 * T] = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64)
+        # all four address rows are rewritten every step (state tensors can be replaced by
+        # load_state_dict behind the same parameter ids)
+        mom = [self.state[p]["momentum"] for p in c["order"]]
+        var = [self.state[p]["variance_neuron"] for p in c["order"]] if normuon else []
+        require_hip(*mom, *var)
+        host.copy_(torch.tensor([p.data_ptr() for p in c["order"]] + [g.data_ptr() for g in grads]
+                                + [m.data_ptr() for m in mom]
+                                + ([v.data_ptr() for v in var] if normuon else [0] * T), dtype=torch.int64))
         c["table"].copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -248,6 +258,7 @@ class Muon(AdamW):
                                         int(bool(group["nesterov"])), int(normuon),
                                         1 if ops.GEMM_SPLIT else 0, dptr(c["ws"]), st),
                   "muon_step")
+        ops.weights_updated()
 
 
 class NorMuon(Muon):

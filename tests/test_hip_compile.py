@@ -1,0 +1,144 @@
+"""The custom-op boundary on the GPU: ``torch.compile(fullgraph=True)`` of the drop-in model (what the
+reference trainer does with ``compute.compile``, ``trainer.py:261-269``), per-module ``_compile()``
+(``model/paradis.py:195-206``), autocast, ``torch.library.opcheck`` of the op registrations."""
+import copy
+
+import pytest
+import torch
+
+from paradis_model_amd.config import reduced_config, stub_datamodule
+from tests._util import make_grid, max_rel, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cfg, H=16, W=32):
+    from paradis_model_amd.model import Paradis
+    _, lg, og = make_grid(H, W, False)
+    torch.manual_seed(42)
+    m = Paradis(stub_datamodule(cfg), cfg, lg, og)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        for n, p in m.named_parameters():
+            if n.endswith((".A", ".U", ".V")):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    return m.cuda()
+
+
+def _fwd_bwd(model, x):
+    model.zero_grad(set_to_none=True)
+    xd = x.clone().requires_grad_(True)
+    y = model(xd)
+    y.square().mean().backward()
+    grads = torch.cat([p.grad.flatten() for p in model.parameters()])
+    return y.detach(), xd.grad.detach(), grads
+
+
+@pytest.mark.parametrize("backend", ["aot_eager", "inductor"])
+def test_compile_fullgraph_matches_eager(backend):
+    """reference trainer.py:262-267: model.compile(mode="default", fullgraph=True, dynamic=False, backend=...)"""
+    cfg = reduced_config()
+    eager = _build(cfg)
+    comp = copy.deepcopy(eager)
+    comp.compile(mode="default", fullgraph=True, dynamic=False, backend=backend)
+    x = seeded(1, 2, 186, 16, 32).cuda()
+    y0, gx0, g0 = _fwd_bwd(eager, x)
+    y1, gx1, g1 = _fwd_bwd(comp, x)
+    assert max_rel(y1, y0) <= 1e-6
+    assert max_rel(gx1, gx0) <= 1e-5     # float atomics in a few reductions: not bit-reproducible
+    assert max_rel(g1, g0) <= 1e-5
+    # second call reuses the compiled graph
+    y2, _, _ = _fwd_bwd(comp, x)
+    assert max_rel(y2, y0) <= 1e-6
+
+
+def test_per_module_compile_matches_eager():
+    """reference model/paradis.py:195-206 (compute.compile == "modules")"""
+    cfg = reduced_config()
+    eager = _build(cfg)
+    comp = copy.deepcopy(eager)
+    comp._compile()
+    x = seeded(2, 2, 186, 16, 32).cuda()
+    y0, gx0, g0 = _fwd_bwd(eager, x)
+    y1, gx1, g1 = _fwd_bwd(comp, x)
+    assert max_rel(y1, y0) <= 1e-6 and max_rel(gx1, gx0) <= 1e-5 and max_rel(g1, g0) <= 1e-5
+    # the trainer strips "._orig_mod." when it loads such a checkpoint (reference trainer.py:222-258)
+    keys = {k.replace("._orig_mod", "") for k in comp.state_dict()}
+    assert keys == set(eager.state_dict())
+
+
+def test_autocast_runs_the_fp32_kernels():
+    """precision="bf16-mixed" (reference train.py:56): the ops cast their inputs to fp32 - never a
+    narrower arithmetic than the reference's - so the result equals the fp32 run."""
+    cfg = reduced_config()
+    model = _build(cfg)
+    x = seeded(3, 1, 186, 16, 32).cuda()
+    with torch.no_grad():
+        y0 = model(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y1 = model(x)
+            y2 = model(x.to(torch.bfloat16))      # a bf16 input is widened, not rejected
+    assert y1.dtype == torch.float32 and torch.equal(y1, y0)
+    assert y2.dtype == torch.float32 and max_rel(y2, y0) < 0.05
+
+
+def test_non_fp32_and_cpu_tensors_raise():
+    from paradis_model_amd import ops
+    x = torch.randn(1, 2, 8, 16)
+    with pytest.raises(RuntimeError):
+        ops.geocyclic_pad(x, 1)
+    with pytest.raises(RuntimeError):
+        ops.geocyclic_pad(x.cuda().double(), 1)
+    with pytest.raises(RuntimeError):
+        torch.ops.paradis.add(x.cuda().double(), x.cuda().double())
+
+
+def test_opcheck_registrations():
+    """torch.library.opcheck: schema, fake kernel vs real kernel (shapes/strides/dtypes), autograd
+    registration and AOT dispatch of representative ops."""
+    from paradis_model_amd import ops
+    from torch.library import opcheck
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration", "test_aot_dispatch_dynamic")
+    H, W = 8, 16
+    _, lg, og = make_grid(H, W, False)
+    geom = ops.AdvectGeometry(lg, og)
+    sl, cl, lo = geom.tables(torch.device("cuda"))
+    g = lambda *s: torch.randn(*s, device="cuda", requires_grad=True)
+    opcheck(torch.ops.paradis.geocyclic_pad.default, (g(1, 2, H, W), 2), test_utils=tests)
+    opcheck(torch.ops.paradis.sl_advect.default,
+            (g(1, 2, H, W), g(1, 2, H, W), g(1, 2, H, W), sl, cl, lo, 0.2, geom.min_lat, geom.min_lon,
+             geom.d_lat, geom.d_lon, 2, 0), test_utils=tests)
+    opcheck(torch.ops.paradis.dwconv_geo.default, (g(1, 3, H, W), g(3, 1, 5, 5), None), test_utils=tests)
+    opcheck(torch.ops.paradis.channel_norm.default, (g(1, 4, H, W), g(1, 2, H, W), g(6), g(6), 1e-5),
+            test_utils=tests)
+    opcheck(torch.ops.paradis.pointwise.default,
+            (g(1, 4, H, W), g(5, 4, 1, 1), g(5), None, g(1, 5, H, W), 1, None, 0, False, None, None, True),
+            test_utils=tests)
+    opcheck(torch.ops.paradis.gated_blend.default, (g(1, 3, H, W), g(1, 3, H, W), g(3)), test_utils=tests)
+    opcheck(torch.ops.paradis.concat_channels.default, ([g(1, 3, H, W), g(1, 2, H, W)],), test_utils=tests)
+
+
+def test_weight_image_cache_follows_weight_updates():
+    """The bf16-split weight images are cached across calls; an in-place torch update (version counter),
+    an optimiser step through the C ABI (WEIGHT_EPOCH) and a new tensor at the same address must all be
+    seen."""
+    from paradis_model_amd import ops
+    if not ops.GEMM_SPLIT:
+        pytest.skip("exact f32 GEMMs keep no weight images")
+    x = torch.randn(2, 32, 8, 16, device="cuda")
+    w = torch.nn.Parameter(torch.randn(48, 32, 1, 1, device="cuda"))
+    ref = lambda: torch.einsum("oc,bchw->bohw", w.detach().reshape(48, 32).double(), x.double()).float()
+    with torch.no_grad():
+        y = ops.pointwise(x, w)
+        assert max_rel(y, ref()) < 1e-5
+        n_img = len(ops._IMAGES)
+        ops.pointwise(x, w)
+        assert len(ops._IMAGES) == n_img                    # cached
+        w.mul_(2.0)                                         # torch in-place update
+        assert max_rel(ops.pointwise(x, w), ref()) < 1e-5
+    from paradis_model_amd.optim import AdamW
+    opt = AdamW([w], lr=0.1)
+    ops.pointwise(x, w).square().mean().backward()
+    opt.step()                                              # HIP kernel writes through raw pointers
+    with torch.no_grad():
+        assert max_rel(ops.pointwise(x, w), ref()) < 1e-5

@@ -46,19 +46,13 @@ def test_pad_rejects_bad_input(ops):
 def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6):
     """force_gmem: use the tiled schedule (window + global fallback) regardless of plane size;
     a small halo forces most taps through the fallback path."""
-    from paradis_model_amd._lib import lib
-    lib.paradis_debug_set_advect_gmem(1 if force_gmem else 0)
-    lib.paradis_debug_set_advect_halo(halo)
-    try:
-        geom = ops.AdvectGeometry(lg, og)
-        fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
-        y = ops.sl_advect(fd, ud, vd, geom, dt, mode)
-        y.backward(ct.cuda())
-        torch.cuda.synchronize()
-        return y.detach().cpu(), fd.grad.cpu(), ud.grad.cpu(), vd.grad.cpu()
-    finally:
-        lib.paradis_debug_set_advect_gmem(-1)
-        lib.paradis_debug_set_advect_halos(-1, -1)
+    flags = ops.advect_flags(tiled=True, halo=halo) if force_gmem else 0
+    geom = ops.AdvectGeometry(lg, og)
+    fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
+    y = ops.sl_advect(fd, ud, vd, geom, dt, mode, flags=flags)
+    y.backward(ct.cuda())
+    torch.cuda.synchronize()
+    return y.detach().cpu(), fd.grad.cpu(), ud.grad.cpu(), vd.grad.cpu()
 
 
 @pytest.mark.parametrize("force_gmem,halo", [(False, 6), (True, 6), (True, 0)])

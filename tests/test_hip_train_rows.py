@@ -61,3 +61,40 @@ def test_adamw_kernel_matches_torch():
         assert max_rel(m.detach().cpu(), r.detach()) <= 1e-6
     sd = o_mine.state_dict()["state"][0]
     assert set(sd) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_adamw_state_dict_round_trip_between_steps():
+    """load_state_dict after a fused step replaces the moment tensors behind the same parameter ids:
+    the next step must update the LOADED moments (the address table is rebuilt every step)."""
+    import copy
+    from paradis_model_amd.optim import AdamW
+    torch.manual_seed(1)
+    ps = [torch.randn(300), torch.randn(17, 9), torch.randn(5000)]
+    gs = [[torch.randn_like(p) for p in ps] for _ in range(3)]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    mine = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    kw = dict(lr=1e-2, weight_decay=1e-2, betas=(0.9, 0.95))
+    o_ref, o_mine = torch.optim.AdamW(ref, **kw), AdamW(mine, **kw)
+
+    def step(k):
+        for r, m, g in zip(ref, mine, gs[k]):
+            r.grad, m.grad = g.clone(), g.clone().cuda()
+        o_ref.step(); o_mine.step()
+
+    step(0)
+    sd_ref, sd_mine = copy.deepcopy(o_ref.state_dict()), copy.deepcopy(o_mine.state_dict())
+    step(1)                                   # moves the moments away from the snapshot
+    o_ref.load_state_dict(sd_ref)             # back to the snapshot: new state tensors, same parameter ids
+    o_mine.load_state_dict(sd_mine)
+    old_ptrs = {id(p): o_mine.state[p]["exp_avg"].data_ptr() for p in mine}
+    step(2)
+    for r, m in zip(ref, mine):
+        assert max_rel(m.detach().cpu(), r.detach()) <= 1e-6
+        assert max_rel(o_mine.state[m]["exp_avg"].cpu(), o_ref.state[r]["exp_avg"]) <= 1e-6
+        assert o_mine.state[m]["exp_avg"].data_ptr() == old_ptrs[id(m)]
+    # a parameter re-homed with .data = (model.to(), manual re-allocation) is followed as well
+    with torch.no_grad():
+        mine[0].data = mine[0].data.clone()
+    step(0)
+    for r, m in zip(ref, mine):
+        assert max_rel(m.detach().cpu(), r.detach()) <= 1e-6

@@ -33,12 +33,12 @@ def main():
         go = torch.randn(B, K, H, W, device="cuda")
         pts = B * K * H * W
         for hf, hb in ((4, 4), (6, 6), (8, 10), (12, 10), (16, 12), (24, 14)):
-            lib.paradis_debug_set_advect_halos(hf, hb)
+            flags = ops.advect_flags(halo=hf, halo_bwd=hb)
             y = None
 
             def fwd():
                 nonlocal y
-                y = ops.sl_advect(f, vel[:, :K], vel[:, K:], geom, 0.196887, "bicubic")
+                y = ops.sl_advect(f, vel[:, :K], vel[:, K:], geom, 0.196887, "bicubic", flags=flags)
 
             def bwd():
                 f.grad = None; vel.grad = None
@@ -47,7 +47,6 @@ def main():
             tb = timeit(bwd)
             print(f"{H}x{W} B={B} vel_scale={scale}: halo fwd {hf:2d} -> {tf:7.3f} ms ({16 * pts / tf / 1e6:6.0f} GB/s)   "
                   f"halo bwd {hb:2d} -> {tb:7.3f} ms ({28 * pts / tb / 1e6:6.0f} GB/s)")
-        lib.paradis_debug_set_advect_halos(-1, -1)
 
 
 if __name__ == "__main__":

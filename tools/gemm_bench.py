@@ -1,3 +1,9 @@
+import os
+# needs the development build of the library (make -C paradis_model_amd/csrc dev): the shipped one exports
+# no paradis_debug_set_* tunables
+os.environ.setdefault("PARADIS_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                                      "paradis_model_amd", "libparadis_hip_dev.so"))
+
 #!/usr/bin/env python3
 """Diagnostic: A/B the FP32-MFMA pointwise GEMM tunables (k-tile depth, resident workgroups per CU)
 over the GEMM shapes of the default PARADIS layer, interleaved in one process (HIP events)."""

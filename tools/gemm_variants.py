@@ -1,3 +1,9 @@
+import os
+# needs the development build of the library (make -C paradis_model_amd/csrc dev): the shipped one exports
+# no paradis_debug_set_* tunables
+os.environ.setdefault("PARADIS_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                                      "paradis_model_amd", "libparadis_hip_dev.so"))
+
 #!/usr/bin/env python3
 """Diagnostic: time ablated builds of the pointwise GEMM (results are WRONG by construction; only
 the timing matters) to attribute the matrix-pipe idle time."""
