@@ -33,12 +33,19 @@ extern "C" {
 #define PARADIS_ACT_GELU 2
 #define PARADIS_INTERP_BILINEAR 1
 #define PARADIS_INTERP_BICUBIC 2
-/* `flags` of paradis_sl_advect_{fwd,bwd}: schedule (bits 0-1) and window halo of the tiled schedule
- * (bits 8-15: 0 = built-in default, else halo + 1; bits 16-23: the same for the backward only).  0 = automatic: the whole padded plane in LDS when
- * it fits 64 KiB, otherwise 128-column tiles with a halo and an L2 path for taps outside the window. */
+/* `flags` of paradis_sl_advect_{fwd,bwd}.  0 = automatic schedule: the whole padded plane in LDS when it
+ * fits 64 KiB (one wave per latitude row when W == 64 and PARADIS_ADVECT_SEPARABLE is set), otherwise
+ * 128-column tiles with a halo and an L2 path for taps outside the window.
+ *   bit 0  PARADIS_ADVECT_GENERIC   whole-plane schedule with per-point table loads even when W == 64
+ *   bit 1  PARADIS_ADVECT_TILED     tiled schedule regardless of the plane size
+ *   bit 2  PARADIS_ADVECT_SEPARABLE the caller vouches that sin_lat/cos_lat are constant along a row and
+ *                                   lon along a column (every regular lat-lon grid)
+ *   bits 8-15  window halo of the tiled schedule (0 = built-in default, else halo + 1)
+ *   bits 16-23 the same for the backward kernel only */
 #define PARADIS_ADVECT_AUTO 0
+#define PARADIS_ADVECT_GENERIC 1
 #define PARADIS_ADVECT_TILED 2
-#define PARADIS_ADVECT_SCHEDULE_MASK 3
+#define PARADIS_ADVECT_SEPARABLE 4
 #define PARADIS_ADVECT_HALO_SHIFT 8
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)

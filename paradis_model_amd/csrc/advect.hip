@@ -9,92 +9,74 @@
 // Saved-for-backward state is (F, u, v) only; everything else is recomputed.
 // Algorithmic HBM traffic: 16 B/point forward, 28 B/point backward.
 //
-// Design (round 1, second version).  The kernels are VALU-bound, not HBM-bound, so the per-point
-// instruction count is what matters.  A workgroup stages a WINDOW of the geocyclic-PADDED plane in
-// LDS through the a1 index map (pole rows already replaced by their means); the 4x4 / 2x2 taps of a
-// point are then plain 2-D indexing from one base address - no per-tap wrap / mirror / validity
-// logic.  Two instantiations of the same kernel:
-//   WHOLE : window = the whole padded plane (planes up to 32x64..64x64), one workgroup per plane,
-//           pole means computed in LDS, no fallback path;
-//   tiled : 16x128 arrival tiles with a halo of D padded cells; taps outside the window (large
-//           displacement, over-the-pole flow) fall back to global loads through the index map /
-//           global float atomics; pole rows by two tiny pre/post kernels.
+// The kernels are VALU-issue bound, not HBM bound (round 1: 264 issue units per point; on gfx950
+// only fp32 add/mul/fma, v_mov, v_and and v_add_u32 issue at 2 cycles per wave, every compare, select,
+// min/max/med3, conversion, shift, integer multiply-add and DPP move costs 4, transcendentals 8:
+// tools/valu_rate_bench.hip).  Round 2 therefore restates the coordinate arithmetic:
+//
+//   * Sample coordinates.  The reference forms  lon_d = remainder(lon_a + atan2(n,d) + 2pi, 2pi),
+//     pix = (lon_d - min)/d_lon (W-1), normalises to [-1,1] and ATen un-normalises again: ten fp32
+//     roundings per axis.  Here  ix = wrap(lon_a cx + atan2(n,d) cx, period) + c0x  and
+//     iy = asin(s) cy + c0y  with cx = (W-1)/d_lon, cy = (H-1)/d_lat, period = 2 pi cx and the offsets
+//     evaluated in double on the host (two FMAs and a floor per axis).  Same mathematical function;
+//     its distance to the fp64 evaluation is HALF the CPU-fp32 reference's own (x: 1.4e-6 vs 3.4e-6
+//     cells rms at 32x64), and its distance to the CPU-fp32 result is that reference's own rounding
+//     noise (6.5e-6 rms at 32x64, tests/test_hip_pad_advect.py).
+//   * asin / atan2 / sincos: polynomial kernels with wave-uniform range specialisation (a wave is one
+//     latitude row: all its lanes sit in the same asin branch; displacements below 45 degrees need
+//     neither range reduction nor octant fix-ups).  <= 2.3 ulp like the host libm.
+//   * Cubic weights from A t (1-t)^2 and A t^2 (1-t) (5 instead of 8 operations for the outer taps).
+//   * Tap origin: v_fract / v_med3 in float, one conversion for the LDS index.
+//
+// A workgroup stages a WINDOW of the geocyclic-PADDED plane in LDS through the a1 index map (pole rows
+// already replaced by their means); the 4x4 / 2x2 taps of a point are plain 2-D indexing from one
+// base address.  Three schedules of the same arithmetic:
+//   row64 : W == 64, separable grid (the 5.625 degree configuration): window = the whole padded plane,
+//           one workgroup per plane, one wave per latitude row: sin/cos(lat) are scalar loads, the
+//           longitude column is a per-thread constant, pole-row means are wave reductions;
+//   whole : any plane that fits LDS, per-point table loads;
+//   tiled : 64x128 (forward) / 16x128 (backward) arrival tiles with a halo of D padded cells; taps
+//           outside the window fall back to global loads through the index map / global float atomics.
 // Backward scatters into 64-bit fixed-point window accumulators with integer LDS atomics
 // (ds_add_f32 is ~30x slower than ds_add_u64 on gfx950, tools/lds_atomic_bench.hip), scaled by an
-// exact power of two from the tile's max |cotangent| (resolution max|g| 2^-41), then folds the halo
-// back (WHOLE) or flushes the window once with global atomics (tiled).
-//
-// The coordinate chain keeps the reference's fp32 operation order; this file is compiled with
-// -ffp-contract=off (see Makefile) so that no extra FMAs are formed (explicit fmaf is used only
-// inside the sincos range reduction).
+// exact power of two from the tile's max |cotangent| (resolution max|g| 2^-41; integer adds are
+// associative: bitwise reproducible), then folds the halo back (whole) or flushes the window once
+// with global atomics (tiled).
 #include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
-#pragma clang fp contract(off)
+#pragma clang fp contract(off)   // every FMA below is explicit
 
-// Diagnostic ablation switches (tools/advect_variants.py builds side libraries with them; the
-// shipped library defines none):  ADV_NO_ATOMIC, ADV_NO_TRIG, ADV_OCML_SINCOS, ADV_NO_SMALL_ANGLE, ADV_IEEE_DIV, ADV_OCML_ATAN2, ...
 namespace {
 
-constexpr float TWO_PI_F = 6.283185307179586f;
 constexpr float CLAMP_HI = 0.9999999f;  // float(1 - 1e-7), as torch.clamp converts its python bound
 constexpr float KA = -0.75f;
-#ifndef ADV_TILE_HB
-#define ADV_TILE_HB 16
-#endif
-#ifndef ADV_THREADS_B
-#define ADV_THREADS_B 512
-#endif
-constexpr int TILE_H = ADV_TILE_HB, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
-#ifndef ADV_TILE_HF
-#define ADV_TILE_HF 64
-#endif
+constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
 // forward tile height: a taller tile amortises the halo (window cells per arrival point 2.6 at 16
 // rows, 1.9 at 32, 1.5 at 64 with a halo of 8); the forward window is 4 B/cell, so LDS is not the
 // limit.  Measured at 128x256: 1.64 / 1.42 / 1.23 ms per launch for 16 / 32 / 64 rows
-constexpr int TILE_HF = ADV_TILE_HF;
+constexpr int TILE_HF = 64;
 // threads per tile in the tiled schedule: the window fixes the LDS per workgroup, so waves per SIMD
 // come from the workgroup size.  Backward (12 B/cell, 2 workgroups per CU): at 256 threads it ran 1.7
-// waves per SIMD at 29 % VALU issue, 512 threads measured 6.9 -> 5.6 ms at 128x256; the forward
-// (4 B/cell) has the occupancy already and is 5-10 % faster with 256.
-constexpr int TILED_THREADS_FWD = TILE_HF >= 32 ? 512 : 256, TILED_THREADS_BWD = ADV_THREADS_B;
-#ifndef ADV_UNROLL
-#define ADV_UNROLL 4
-#endif
-#ifndef ADV_UNROLL_BWD
-#define ADV_UNROLL_BWD 2
-#endif
-#ifndef ADV_PF
-#define ADV_PF 2   // prefetch distance (points) of the operand loads in the whole-plane forward kernel
-#endif
+// waves per SIMD at 29 % VALU issue, 512 threads measured 6.9 -> 5.6 ms at 128x256
+constexpr int TILED_THREADS_FWD = 512, TILED_THREADS_BWD = 512;
+constexpr int ADV_PF = 2;   // prefetch distance (points) of the operand loads
 
 struct AdvGeom {
   int H, W, p;
-  float dt, min_lat, min_lon, d_lat, d_lon;
-  // correctly rounded reciprocals of the four loop-invariant divisors (host, via double)
-  float r_lat, r_lon, r_wpm1, r_hpm1;
+  float ndt;              // -dt
+  float cx, cy;           // cells per radian: (W-1)/d_lon, (H-1)/d_lat
+  float per, inv_per;     // longitude period in cells (2 pi cx) and its reciprocal
+  float c0x, c0y;         // p - min_lon cx,  p - min_lat cy
+  double cxd;             // cx in double: lon -> cells conversion of the longitude table
 };
-
-// x / d for a loop-invariant d with rd = RN(1/d): q = RN(x rd), r = x - q d (exact in the FMA),
-// q' = RN(q + r rd) is the correctly rounded quotient (Markstein), i.e. bit-identical to the IEEE
-// division of the reference's fp32 chain at 3 instructions instead of ~10.  Verified bit-exact
-// against '/' for the divisors of every grid (tests/test_hip_pad_advect.py, oracle/check_div.c).
-__device__ __forceinline__ float div_by(float x, float d, float rd) {
-#ifdef ADV_IEEE_DIV
-  (void)rd;
-  return x / d;
-#else
-  const float q = x * rd;
-  const float r = fmaf(-q, d, x);
-  return fmaf(r, rd, q);
-#endif
-}
 
 struct DepState {  // intermediates needed by the backward chain
   float sp, cp, sl, cl, s, n, d;
 };
 
+// ---- elementary functions ------------------------------------------------------------------
 // sin and cos: cephes minimax polynomials on [-pi/4, pi/4] (<= ~1 ulp) behind a Cody-Waite reduction
 // (fdlibm's float split of pi/2); huge arguments take the ocml path.
 __device__ __forceinline__ void sincos_kernel(float r, float& ps, float& pc) {
@@ -104,7 +86,7 @@ __device__ __forceinline__ void sincos_kernel(float r, float& ps, float& pc) {
             fmaf(-0.5f, z, 1.0f));
 }
 
-__device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
+__device__ __forceinline__ void sincos_reduced(float x, float& s, float& c) {
   if (fabsf(x) > 8192.0f) {
     sincosf(x, &s, &c);
     return;
@@ -124,48 +106,52 @@ __device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
 
 // sin/cos of the two rotation angles of a point.  |angle| < 0.78 (< pi/4: the reduction's k is 0 and
 // r = x exactly) for every lane of the wave is the normal case - displacements of less than 45 degrees
-// per step - and needs no reduction and no quadrant selects: same bits, 9 instead of ~35
-// instructions per angle.
+// per step - and needs no reduction and no quadrant selects: same bits, 10 instead of ~35 operations.
 __device__ __forceinline__ void sincos_pair(float phi, float lam, float& sp, float& cp, float& sl, float& cl) {
-#if defined(ADV_OCML_SINCOS)
-  sincosf(phi, &sp, &cp);
-  sincosf(lam, &sl, &cl);
-#else
-#ifndef ADV_NO_SMALL_ANGLE
-  if (__all(fabsf(phi) < 0.78f && fabsf(lam) < 0.78f)) {
+  if (__all(fmaxf(fabsf(phi), fabsf(lam)) < 0.78f)) {
     sincos_kernel(phi, sp, cp);
     sincos_kernel(lam, sl, cl);
     return;
   }
-#endif
-  sincos_fast(phi, sp, cp);
-  sincos_fast(lam, sl, cl);
-#endif
+  sincos_reduced(phi, sp, cp);
+  sincos_reduced(lam, sl, cl);
 }
 
-// exact fmod(t, 2*pi_f) for the range the path produces (Sterbenz: the subtractions are exact);
-// anything else takes fmodf + the sign fix of torch.remainder
-__device__ __forceinline__ float wrap_two_pi(float t) {
-  if (t >= 0.f && t < 3.0f * TWO_PI_F) {
-    if (t >= 2.0f * TWO_PI_F) return t - 2.0f * TWO_PI_F;
-    if (t >= TWO_PI_F) return t - TWO_PI_F;
-    return t;
+// (asin(x) - x) / x^3 as a polynomial in y = x^2 on [0, 1/4]; with the half-angle identity
+// asin(x) = pi/2 - 2 asin(sqrt((1-x)/2)) for |x| >= 1/2 the result is within 2.3 ulp (mean 0.45),
+// the host libm's float asin within 3.1 (mean 0.44)
+__device__ __forceinline__ float asin_poly(float y) {
+  float p = fmaf(0x1.15e14ep-5f, y, 0x1.169fe6p-6f);
+  p = fmaf(p, y, 0x1.fe10a0p-6f);
+  p = fmaf(p, y, 0x1.6d55e8p-5f);
+  p = fmaf(p, y, 0x1.333448p-4f);
+  return fmaf(p, y, 0x1.555554p-3f);
+}
+
+// asin for |x| < 1.  The lanes of a wave share a latitude row in every schedule, so the branch is
+// wave-uniform almost always; the mixed case evaluates one polynomial behind selects.
+__device__ __forceinline__ float asin_wave(float x) {
+  const float ax = fabsf(x);
+  const bool big = ax >= 0.5f;
+  if (!__any(big)) {
+    const float y = x * x;
+    return fmaf(x, y * asin_poly(y), x);
   }
-  float m = fmodf(t, TWO_PI_F);
-  if (m != 0.f && m < 0.f) m += TWO_PI_F;
-  return m;
+  const float t = fmaf(ax, -0.5f, 0.5f);
+  const float r = __builtin_amdgcn_sqrtf(t);   // 1 ulp; contributes <= 0.5 ulp of the result
+  float y = t, a = r;
+  const bool mixed = !__all(big);
+  if (mixed) {
+    y = big ? t : ax * ax;
+    a = big ? r : ax;
+  }
+  const float yy = fmaf(a, y * asin_poly(y), a);
+  float res = fmaf(-2.0f, yy, 0x1.921fb6p+0f);
+  if (mixed) res = big ? res : yy;
+  return copysignf(res, x);
 }
 
-// atan2f for finite arguments of ordinary magnitude (here n^2 + d^2 = cos^2(lat_d) > 1e-7): the
-// ocml algorithm (min/max quotient by v_rcp, degree-8 minimax in t^2, octant fix-ups) without its
-// frexp/ldexp overflow scaling and inf/NaN classification - same bits in this range.
-__device__ __forceinline__ float atan2_finite(float y, float x) {
-#ifdef ADV_OCML_ATAN2
-  return atan2f(y, x);
-#else
-  const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  const float t = mn * __builtin_amdgcn_rcpf(mx);
+__device__ __forceinline__ float atan_poly(float t) {   // ocml's degree-8 minimax in t^2, |t| <= 1
   const float z = t * t;
   float pp = fmaf(z, 0x1.5a54bp-9f, -0x1.f4b218p-7f);
   pp = fmaf(z, pp, 0x1.53f67ep-5f);
@@ -174,67 +160,87 @@ __device__ __forceinline__ float atan2_finite(float y, float x) {
   pp = fmaf(z, pp, -0x1.22c1ccp-3f);
   pp = fmaf(z, pp, 0x1.99717ep-3f);
   pp = fmaf(z, pp, -0x1.5554c4p-2f);
-  float a = fmaf(t, z * pp, t);
+  return fmaf(t, z * pp, t);
+}
+
+// atan2 for finite arguments of ordinary magnitude (here y^2 + x^2 = cos^2(lat_d) > 1e-7).  When every
+// lane of the wave has |y| < x (the departure point is less than 45 degrees of longitude away: the
+// normal case) the quotient needs no octant bookkeeping.
+__device__ __forceinline__ float atan2_wave(float y, float x) {
+  if (__all(fabsf(y) < x)) return atan_poly(y * __builtin_amdgcn_rcpf(x));
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = atan_poly(mn * __builtin_amdgcn_rcpf(mx));
   a = (ay > ax) ? 0x1.921fb6p+0f - a : a;
   a = (x < 0.f) ? 0x1.921fb6p+1f - a : a;
   a = (y == 0.f) ? ((__float_as_int(x) < 0) ? 0x1.921fb6p+1f : 0.f) : a;   // also covers 0/0
   return copysignf(a, y);
-#endif
 }
 
-__device__ __forceinline__ void departure(float u, float v, float sa, float ca, float lon_a,
+// lonc = lon_a cx (cells), sa/ca = sin/cos(lat_a).  Returns the sample coordinates on the padded plane.
+__device__ __forceinline__ void departure(float u, float v, float sa, float ca, float lonc,
                                           const AdvGeom& g, float& ix, float& iy, DepState* st) {
-#ifdef ADV_NO_TRIG
-  ix = lon_a * 3.0f + u + (float)g.p; iy = sa * 5.0f + 7.0f + v + (float)g.p;
-  if (st) { st->sp = u; st->cp = v; st->sl = sa; st->cl = ca; st->s = 0.5f; st->n = u; st->d = 1.0f + v * v; }
-  return;
-#endif
-  const float lam = -u * g.dt;
-  const float phi = -v * g.dt;
+  const float lam = u * g.ndt;
+  const float phi = v * g.ndt;
   float sp, cp, sl, cl;
   sincos_pair(phi, lam, sp, cp, sl, cl);
   const float cc = cp * cl;
-  const float s = sp * ca + cc * sa;
-  const float sc = fminf(fmaxf(s, -CLAMP_HI), CLAMP_HI);
-  const float lat_d = asinf(sc);
+  const float s = fmaf(sp, ca, cc * sa);
+  const float sc = __builtin_amdgcn_fmed3f(s, -CLAMP_HI, CLAMP_HI);
+  const float lat_d = asin_wave(sc);
   const float n = cp * sl;
-  const float d = cc * ca - sp * sa;
-  float lon_d = lon_a + atan2_finite(n, d);
-  lon_d = lon_d + TWO_PI_F;
-  const float m = wrap_two_pi(lon_d);
-  const float pix_x = div_by(m - g.min_lon, g.d_lon, g.r_lon) * ((float)g.W - 1.0f);
-  const float pix_y = div_by(lat_d - g.min_lat, g.d_lat, g.r_lat) * ((float)g.H - 1.0f);
-  const float wpm1 = (float)(g.W + 2 * g.p - 1), hpm1 = (float)(g.H + 2 * g.p - 1);
-  const float gx = 2.0f * div_by(pix_x + (float)g.p, wpm1, g.r_wpm1) - 1.0f;
-  const float gy = 2.0f * div_by(pix_y + (float)g.p, hpm1, g.r_hpm1) - 1.0f;
-  ix = ((gx + 1.0f) / 2.0f) * wpm1;
-  iy = ((gy + 1.0f) / 2.0f) * hpm1;
+  const float d = fmaf(cc, ca, -(sp * sa));
+  const float a = atan2_wave(n, d);
+  const float t = fmaf(a, g.cx, lonc);                 // unwrapped departure longitude in cells
+  const float q = floorf(t * g.inv_per);
+  const float m = fmaf(-q, g.per, t);                  // in [0, period) up to one rounding
+  ix = m + g.c0x;
+  iy = fmaf(lat_d, g.cy, g.c0y);
   if (st) {
     st->sp = sp; st->cp = cp; st->sl = sl; st->cl = cl; st->s = s; st->n = n; st->d = d;
   }
 }
 
-// (explicit FMAs: the weights and tap sums are not coordinate-critical - an ulp of a weight is
-//  1e-7 relative in the result, whereas an ulp of a sample coordinate is multiplied by the field slope)
+// A wave-uniform pointer pinned to scalar registers: `srow(p)[lane]` with an unsigned 32-bit lane then
+// becomes a global access with a scalar base and a 32-bit vector offset (no 64-bit vector address
+// arithmetic per load: 7 half-rate VALU operations per access in the first version of these loops).
+template <typename T>
+__device__ __forceinline__ T* srow(T* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float lon_cells(float lon, const AdvGeom& g) { return (float)((double)lon * g.cxd); }
+
+// ---- interpolation weights -------------------------------------------------------------------
+// (the weights and tap sums are not coordinate-critical - an ulp of a weight is 1e-7 relative in the
+//  result, whereas an ulp of a sample coordinate is multiplied by the field slope)
 __device__ __forceinline__ float cub1(float x) { return fmaf(fmaf(KA + 2.f, x, -(KA + 3.f)) * x, x, 1.f); }
-__device__ __forceinline__ float cub2(float x) { return fmaf(fmaf(fmaf(KA, x, -5.f * KA), x, 8.f * KA), x, -4.f * KA); }
 __device__ __forceinline__ float dcub1(float x) { return fmaf(3.f * (KA + 2.f), x, -2.f * (KA + 3.f)) * x; }
-__device__ __forceinline__ float dcub2(float x) { return fmaf(fmaf(3.f * KA, x, -10.f * KA), x, 8.f * KA); }
 
 template <int MODE>
 struct Interp {
   static constexpr int NT = (MODE == PARADIS_INTERP_BICUBIC) ? 4 : 2;
   static constexpr int OFF0 = (MODE == PARADIS_INTERP_BICUBIC) ? -1 : 0;
+  // Keys cubic convolution, A = -0.75: taps at -1, 0, 1, 2 carry  A t (1-t)^2,  c1(t),  c1(1-t),  A t^2 (1-t)
   static __device__ __forceinline__ void weights(float t, float* w) {
     if (MODE == PARADIS_INTERP_BICUBIC) {
-      w[0] = cub2(t + 1.f); w[1] = cub1(t); w[2] = cub1(1.f - t); w[3] = cub2(2.f - t);
+      // the four weights sum to 1 and w0 + w3 = A t (1-t) (t + (1-t)): the fourth costs two subtractions
+      const float um = 1.f - t, atu = (KA * t) * um;
+      w[0] = atu * um; w[1] = cub1(t); w[3] = atu * t; w[2] = (1.f - w[1]) - atu;
     } else {
       w[0] = 1.f - t; w[1] = t;
     }
   }
   static __device__ __forceinline__ void dweights(float t, float* dw) {
     if (MODE == PARADIS_INTERP_BICUBIC) {
-      dw[0] = dcub2(t + 1.f); dw[1] = dcub1(t); dw[2] = -dcub1(1.f - t); dw[3] = -dcub2(2.f - t);
+      const float um = 1.f - t;
+      dw[0] = fmaf(fmaf(3.f * KA, t, -4.f * KA), t, KA);     // A (3t^2 - 4t + 1)
+      dw[1] = dcub1(t);
+      dw[2] = -dcub1(um);
+      dw[3] = fmaf(-3.f * KA, t, 2.f * KA) * t;              // A (2t - 3t^2)
     } else {
       dw[0] = -1.f; dw[1] = 1.f;
     }
@@ -277,6 +283,23 @@ __device__ __forceinline__ void tap_origin(float ix, float iy, int Hp, int Wp, i
   sy = by - y0;
 }
 
+// Tap block of a point when the window is the WHOLE padded plane: fraction, clamped origin and the
+// LDS index in float arithmetic (exact: every value is an integer below 2^24), one conversion.
+// Returns true when the clamp moved the origin (a coordinate on the plane edge, or not finite): the
+// caller takes the general path.  `cell` indexes tap (0,0) BEFORE the OFF0 shift.
+template <int MODE>
+__device__ __forceinline__ bool tap_block_whole(float ix, float iy, float Hpf, float Wpf, float& tx, float& ty,
+                                                int& cell) {
+  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
+  tx = __builtin_amdgcn_fractf(ix);
+  ty = __builtin_amdgcn_fractf(iy);
+  const float x0f = ix - tx, y0f = iy - ty;
+  const float xc = __builtin_amdgcn_fmed3f(x0f, (float)(-OFF0), Wpf - (float)(NT + OFF0));
+  const float yc = __builtin_amdgcn_fmed3f(y0f, (float)(-OFF0), Hpf - (float)(NT + OFF0));
+  cell = (int)fmaf(yc, Wpf, xc);
+  return !(xc == x0f && yc == y0f);
+}
+
 __device__ __forceinline__ float wave_row_mean(const float* row, int W) {
   float s = 0.f;
   for (int x = threadIdx.x & 63; x < W; x += 64) s += row[x];
@@ -288,7 +311,7 @@ struct Window {
   int wy0, wx0, WH, WW;
 };
 
-// iterate i = tid, tid+256, ... < th*tw as (yl, xl) without a division per point
+// iterate i = tid, tid+nth, ... < th*tw as (yl, xl) without a division per point
 struct TileIter {
   int yl, xl, dy, dx, tw;
   __device__ __forceinline__ TileIter(int tid, int tw_, int nth = 256) : tw(tw_) {
@@ -301,18 +324,15 @@ struct TileIter {
 };
 
 // stage src plane (image H x W) into the window through the geocyclic map; subst: replace source
-// rows 0 / H-1 by the given means (tiled schedule; WHOLE computes the means in LDS afterwards).
+// rows 0 / H-1 by the given means (tiled schedule; whole-plane schedules compute the means in LDS).
 // Flat over the window in batches: all loads of a batch are issued before the first LDS write, so a
-// workgroup pays ~one memory round trip for its window.  (A row-per-wave loop serialised one round
-// trip per row - 9 per wave at 32x64 - and cost 23 % of the forward kernel.)
+// workgroup pays ~one memory round trip for its window.
 constexpr int STAGE_BATCH = 6;
 __device__ __forceinline__ void stage_window(float* win, const float* __restrict__ F, const Window& w,
                                              int H, int W, int p, bool subst, float m0, float m1,
                                              int nth = 256) {
   // A thread keeps one window column (its longitude wrap - plain and mirrored - is computed once) and
-  // walks down the rows; only the cheap row map (mirror beyond a pole) is per element.  A flat
-  // element-per-thread assignment paid the full index map (~50 VALU) for each of the 2.6x more window
-  // cells than arrival points: 1 of the 2.1 ms of the tiled forward at 128x256.
+  // walks down the rows; only the cheap row map (mirror beyond a pole) is per element.
   const int Hp = H + 2 * p;
   const int tid = threadIdx.x;
   const int cols = w.WW < nth ? w.WW : nth;          // window columns per pass
@@ -351,9 +371,112 @@ __device__ __forceinline__ void stage_window(float* win, const float* __restrict
   }
 }
 
+// pole rows of a whole padded plane in LDS <- their mean over the W interior columns (lon halo included)
+__device__ __forceinline__ void pole_rows_to_mean_lds(float* win, int H, int W, int p, int Wp) {
+  const int wave = threadIdx.x >> 6;
+  if (wave < 2) {
+    float* row = win + (wave == 0 ? p : H - 1 + p) * Wp;
+    const float m = wave_row_mean(row + p, W);
+    for (int x = threadIdx.x & 63; x < Wp; x += 64) row[x] = m;
+  }
+}
+
 // ======================================================================================
 // forward
 // ======================================================================================
+// value of one arrival point from a WHOLE-plane window
+template <int MODE>
+__device__ __forceinline__ float sample_whole(const float* win, float ix, float iy, int Hp, int Wp, float Hpf,
+                                              float Wpf) {
+  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
+  float tx, ty, wx[NT], wy[NT];
+  int cell;
+  const bool edge = tap_block_whole<MODE>(ix, iy, Hpf, Wpf, tx, ty, cell);
+  const float* base = win + OFF0 * (Wp + 1) + cell;
+  if (__any(edge)) {   // a coordinate rounded onto the plane edge, or is not finite: general origin + shifted weights
+    int bx, by, sx, sy;
+    tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
+    Interp<MODE>::weights(tx, wx);
+    Interp<MODE>::weights(ty, wy);
+    shift_weights<NT>(wx, sx);
+    shift_weights<NT>(wy, sy);
+    base = win + by * Wp + bx;
+  } else {
+    Interp<MODE>::weights(tx, wx);
+    Interp<MODE>::weights(ty, wy);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    float rowacc = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[a * Wp + bb], wx[bb], rowacc);
+    acc = fmaf(rowacc, wy[a], acc);
+  }
+  return acc;
+}
+
+// W == 64, separable grid: one workgroup (4 waves) per plane, wave w owns rows w, w+4, ...
+template <int MODE>
+__global__ void __launch_bounds__(256)
+sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u,
+                    const float* __restrict__ v, float* __restrict__ out,
+                    const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                    const float* __restrict__ lon, int K, AdvGeom g, int64_t f_bs, int64_t uv_bs,
+                    int64_t o_bs, int vec4) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int W = 64;
+  const int H = g.H, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;   // unsigned: row pointer (scalar) + 32-bit lane offset addressing
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
+  float* win = smem;
+
+  // operands of the first rows are in flight while the window is staged
+  float qu[ADV_PF], qv[ADV_PF];
+#pragma unroll
+  for (int d = 0; d < ADV_PF; ++d) {
+    const int j = min(wave + 4 * d, H - 1) * W;
+    qu[d] = srow(U + j)[lane]; qv[d] = srow(V + j)[lane];
+  }
+  const float lonc = lon_cells(lon[lane], g);
+  if (vec4) stage_plane_vec4(win, F, H, W, p);
+  else {
+    Window w{0, 0, Hp, Wp};
+    stage_window(win, F, w, H, W, p, false, 0.f, 0.f, 256);
+  }
+  __syncthreads();
+  pole_rows_to_mean_lds(win, H, W, p, Wp);
+  __syncthreads();
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp;
+  for (int y0 = wave; y0 < H; y0 += 4 * ADV_PF) {
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) {
+      const int y = y0 + 4 * d;                 // wave-uniform
+      const float cu = qu[d], cv = qv[d];
+      {
+        const int j = min(y + 4 * ADV_PF, H - 1) * W;
+        qu[d] = srow(U + j)[lane]; qv[d] = srow(V + j)[lane];
+      }
+      if (y < H) {
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];   // uniform address: scalar loads
+        float ix, iy;
+        departure(cu, cv, sa, ca, lonc, g, ix, iy, nullptr);
+        float acc = sample_whole<MODE>(win, ix, iy, Hp, Wp, Hpf, Wpf);
+        if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
+        srow(O + y * W)[lane] = acc;
+      }
+    }
+  }
+}
+
 template <int MODE, bool WHOLE, int NTH>
 __global__ void __launch_bounds__(NTH)
 sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ u,
@@ -379,38 +502,25 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
   Window w;
   if (WHOLE) { w.wy0 = 0; w.wx0 = 0; w.WH = Hp; w.WW = Wp; }
   else { w.wy0 = ty0 + p - halo; w.wx0 = tx0 + p - halo; w.WH = TILE_HF + 2 * halo + NT; w.WW = TILE_W + 2 * halo + NT; }
-  float* win = smem;                       // [WH*WW]
-  float* pole_out = smem + w.WH * w.WW;    // [2*W]  (WHOLE only)
+  float* win = smem;                           // [WH*WW]
+  float* pole_out = win + w.WH * w.WW;         // [2*W]  (WHOLE only)
 
   float m0 = 0.f, m1 = 0.f;
   if (!WHOLE) { m0 = fmeans[2 * plane]; m1 = fmeans[2 * plane + 1]; }
-#ifndef ADV_NO_STAGE
   if (WHOLE && vec4) stage_plane_vec4(win, F, H, W, p);
   else stage_window(win, F, w, H, W, p, !WHOLE, m0, m1, NTH);
-#endif
   __syncthreads();
   if (WHOLE) {
-    // pole rows <- their mean, over the whole padded row (lon halo included).  (Reducing the two rows
-    // from global before staging would save this barrier but puts a dependent load in front of the
-    // staging loads: measured 2-7 % slower.)
-    if (wave < 2) {
-      float* row = win + (wave == 0 ? p : H - 1 + p) * Wp;
-      const float m = wave_row_mean(row + p, W);
-      for (int x = tid & 63; x < Wp; x += 64) row[x] = m;
-    }
+    pole_rows_to_mean_lds(win, H, W, p, Wp);
     __syncthreads();
   }
-  // W == 64: an output row is one wave's lanes in one iteration -> its mean is a wave reduction
-  const bool rowwave = WHOLE && W == 64;
-
+  const float Hpf = (float)Hp, Wpf = (float)Wp;
   const int npts = th * tw;
-  // (a 4-points-per-thread variant with 16-B loads/stores measured SLOWER: 124 VGPRs halve the
-  //  occupancy and the kernel is latency/issue-bound, not bandwidth-bound)
-  // one arrival point: departure -> tap block -> window gather (or L2 fallback in the tiled schedule)
-  auto point = [&](float uu, float vv, float sa, float ca, float lo) -> float {
+  // one arrival point of the tiled schedule: departure -> tap block -> window gather or L2 fallback
+  auto point_tiled = [&](float uu, float vv, float sa, float ca, float lo) -> float {
     float ix, iy, tx, ty, wx[NT], wy[NT];
     int bx, by, sx, sy;
-    departure(uu, vv, sa, ca, lo, g, ix, iy, nullptr);
+    departure(uu, vv, sa, ca, lon_cells(lo, g), g, ix, iy, nullptr);
     tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
     Interp<MODE>::weights(tx, wx);
     Interp<MODE>::weights(ty, wy);
@@ -419,18 +529,11 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
       shift_weights<NT>(wy, sy);
     }
     int ry = by - w.wy0, rx = bx - w.wx0;
-    bool inwin = true;
-    if (!WHOLE) {
-      if (rx < 0) rx += W; else if (rx > w.WW - NT) rx -= W;
-      inwin = ry >= 0 && ry <= w.WH - NT && rx >= 0 && rx <= w.WW - NT;
-    }
+    if (rx < 0) rx += W; else if (rx > w.WW - NT) rx -= W;
+    const bool inwin = ry >= 0 && ry <= w.WH - NT && rx >= 0 && rx <= w.WW - NT;
     float acc = 0.f;
     if (inwin) {
       const float* base = win + ry * w.WW + rx;
-#ifdef ADV_NO_GATHER
-      acc = (float)(ry * w.WW + rx) * (wx[0] + wx[1] + wy[0] + wy[1] + wx[NT - 1] + wy[NT - 1]);
-      (void)base;
-#else
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         float rowacc = 0.f;
@@ -438,8 +541,7 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
         for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[a * w.WW + bb], wx[bb], rowacc);
         acc = fmaf(rowacc, wy[a], acc);
       }
-#endif
-    } else {  // tiled schedule only: taps served by L2 through the index map
+    } else {  // taps served by L2 through the index map
       const int lastrow = H - 1;
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
@@ -450,9 +552,9 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
           geo_src(by + a - p, bx + bb - p, H, W, r, c);
           float val = F[(int64_t)r * W + c];
           if (r == 0) val = m0; else if (r == lastrow) val = m1;
-          rowacc += val * wx[bb];
+          rowacc = fmaf(val, wx[bb], rowacc);
         }
-        acc += rowacc * wy[a];
+        acc = fmaf(rowacc, wy[a], acc);
       }
     }
     return acc;
@@ -460,9 +562,7 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
   if constexpr (WHOLE) {
     // Whole plane: the arrival index is the flat index.  Operands are prefetched ADV_PF points ahead
     // into a queue whose slots are fixed registers (the loop is unrolled ADV_PF times) with
-    // unconditional, clamped loads: straight-line code lets the compiler count vmcnt exactly -
-    // with per-lane conditionals around the loads it emitted s_waitcnt vmcnt(0) every iteration,
-    // i.e. every point waited for the previous point's store to be acknowledged.
+    // unconditional, clamped loads: straight-line code lets the compiler count vmcnt exactly.
     const int last = npts - 1;
     float qu[ADV_PF], qv[ADV_PF], qs[ADV_PF], qc[ADV_PF], ql[ADV_PF];
 #pragma unroll
@@ -478,21 +578,23 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
         const float cu = qu[d], cv = qv[d], csa = qs[d], cca = qc[d], clo = ql[d];
         {
           const int j = min(i + NTH * ADV_PF, last);
-          qu[d] = U[j]; qv[d] = V[j];
-#ifndef ADV_NO_TABLES
-          qs[d] = sin_lat[j]; qc[d] = cos_lat[j]; ql[d] = lon[j];
-#endif
+          qu[d] = U[j]; qv[d] = V[j]; qs[d] = sin_lat[j]; qc[d] = cos_lat[j]; ql[d] = lon[j];
         }
-        const float acc = point(cu, cv, csa, cca, clo);
+        float ix, iy;
+        departure(cu, cv, csa, cca, lon_cells(clo, g), g, ix, iy, nullptr);
+        const float acc = sample_whole<MODE>(win, ix, iy, Hp, Wp, Hpf, Wpf);
         if (i < npts) {
-          if (i < W || i >= lastrow0) {
-            if (rowwave) O[i] = wave_sum(acc) / (float)W;
-            else pole_out[i < W ? i : W + i - lastrow0] = acc;
-          } else {
-            O[i] = acc;
-          }
+          if (i < W || i >= lastrow0) pole_out[i < W ? i : W + i - lastrow0] = acc;
+          else O[i] = acc;
         }
       }
+    }
+    __syncthreads();
+    if (wave < 2) {
+      const float* row = pole_out + (wave == 0 ? 0 : W);
+      const float m = wave_row_mean(row, W);
+      float* orow = O + (wave == 0 ? 0 : (int64_t)(H - 1) * W);
+      for (int x = tid & 63; x < W; x += 64) orow[x] = m;
     }
   } else {
     // tiled schedule: operands of point i+1 are loaded before point i is computed
@@ -510,16 +612,7 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
         const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
         nu = U[nidx]; nv = V[nidx]; nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx];
       }
-      O[idx] = point(cu, cv, csa, cca, clo);
-    }
-  }
-  if (WHOLE && !rowwave) {
-    __syncthreads();
-    if (wave < 2) {
-      const float* row = pole_out + (wave == 0 ? 0 : W);
-      const float m = wave_row_mean(row, W);
-      float* orow = O + (wave == 0 ? 0 : (int64_t)(H - 1) * W);
-      for (int x = tid & 63; x < W; x += 64) orow[x] = m;
+      O[idx] = point_tiled(cu, cv, csa, cca, clo);
     }
   }
 }
@@ -532,14 +625,12 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
 // pattern from the high word.  (A float -> int64 conversion proper is ~12 VALU instructions and the
 // scatter does 16 of them per point.)
 __device__ __forceinline__ unsigned long long fixed_from_float(float x) {
-#ifdef ADV_CVT_I64
-  return (unsigned long long)__float2ll_rn(x);
-#else
   const double d = (double)x + 6755399441055744.0;
   return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
-#endif
 }
 
+// mx = max |cotangent| of the tile, NaN if any cotangent is NaN (the reduction runs on the bit
+// patterns of |g|: as unsigned integers they order like the floats, and every NaN sorts above +inf)
 __device__ __forceinline__ void fixed_point_scale(float mx, float& scale, float& inv) {
   scale = 0.f; inv = 0.f;
   if (mx > 0.f && mx < INFINITY) {
@@ -549,34 +640,207 @@ __device__ __forceinline__ void fixed_point_scale(float mx, float& scale, float&
     scale = ldexpf(1.0f, 40 - e);
     inv = ldexpf(1.0f, e - 40);
   } else if (!(mx < INFINITY)) {
-    inv = NAN;                            // non-finite cotangent: propagate NaN like float adds would
+    inv = NAN;                            // Inf or NaN cotangent: the field gradient is NaN, like float adds would give
   }
 }
 
+__device__ __forceinline__ unsigned abs_bits(float g) { return __float_as_uint(g) & 0x7fffffffu; }
+
 __device__ __forceinline__ void departure_backward(const DepState& st, float sa, float ca, float gix,
-                                                   float giy, float kx, float ky, float dt, float& gu,
-                                                   float& gv) {
-  const float glam_c = gix * kx, gphi_c = giy * ky;
-  const float sc = fminf(fmaxf(st.s, -CLAMP_HI), CLAMP_HI);
-#ifdef ADV_IEEE_DIV
-  const float gs = (st.s >= -CLAMP_HI && st.s <= CLAMP_HI) ? gphi_c / sqrtf(1.0f - sc * sc) : 0.f;
-  const float den = st.n * st.n + st.d * st.d;
-  const float gn = glam_c * st.d / den;
-  const float gd = -glam_c * st.n / den;
-#else
+                                                   float giy, const AdvGeom& g, float& gu, float& gv) {
+  const float glam_c = gix * g.cx, gphi_c = giy * g.cy;
+  const float sc = __builtin_amdgcn_fmed3f(st.s, -CLAMP_HI, CLAMP_HI);
   // v_rsq / v_rcp (1 ulp) with one Newton step on the reciprocal: gradient error ~1e-7 relative
-  const float gs = (st.s >= -CLAMP_HI && st.s <= CLAMP_HI) ? gphi_c * __builtin_amdgcn_rsqf(1.0f - sc * sc) : 0.f;
-  const float den = st.n * st.n + st.d * st.d;
+  const float gs = (sc == st.s) ? gphi_c * __builtin_amdgcn_rsqf(fmaf(-sc, sc, 1.0f)) : 0.f;
+  const float den = fmaf(st.n, st.n, st.d * st.d);
   float rden = __builtin_amdgcn_rcpf(den);
   rden = fmaf(fmaf(-den, rden, 1.0f), rden, rden);
-  const float gn = glam_c * st.d * rden;
-  const float gd = -glam_c * st.n * rden;
-#endif
-  const float gphi = gs * (st.cp * ca - st.sp * st.cl * sa) + gn * (-st.sp * st.sl) +
-                     gd * (-st.sp * st.cl * ca - st.cp * sa);
-  const float glam = gs * (-st.cp * st.sl * sa) + gn * (st.cp * st.cl) + gd * (-st.cp * st.sl * ca);
-  gu = -dt * glam;
-  gv = -dt * gphi;
+  const float gl = glam_c * rden;
+  const float gn = gl * st.d;
+  const float gd = -gl * st.n;
+  // d s / d phi' = cp ca - sp cl sa,   d n / d phi' = -sp sl,   d d / d phi' = -sp cl ca - cp sa
+  const float spcl = st.sp * st.cl, cpsl = st.cp * st.sl;
+  const float gphi = fmaf(gs, fmaf(st.cp, ca, -(spcl * sa)),
+                          fmaf(gn, -(st.sp * st.sl), gd * -fmaf(spcl, ca, st.cp * sa)));
+  // d s / d lam' = -cp sl sa,           d n / d lam' = cp cl,    d d / d lam' = -cp sl ca
+  const float glam = fmaf(gs, -(cpsl * sa), fmaf(gn, st.cp * st.cl, gd * -(cpsl * ca)));
+  gu = g.ndt * glam;
+  gv = g.ndt * gphi;
+}
+
+// round-to-nearest-even integer of the product a*b in one double FMA (a, b widened once per row /
+// column of the tap block instead of a conversion per tap): a*b is exact in double, the sum with
+// 1.5*2^52 rounds it to an integer in the low mantissa bits
+__device__ __forceinline__ unsigned long long fixed_from_product(double a, double b) {
+  const double d = fma(a, b, 6755399441055744.0);
+  return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
+}
+
+// taps of one arrival point against a window: scatter g w_y w_x into the fixed-point accumulators,
+// gather the field for the coordinate gradients.  base = index of tap (0,0) in the window.
+template <int MODE>
+__device__ __forceinline__ void scatter_gather(unsigned long long* acc, const float* win, int base, int WW,
+                                               const float* wx, const float* wy, const float* dwx,
+                                               const float* dwy, float gs_, float& gix, float& giy) {
+  constexpr int NT = Interp<MODE>::NT;
+  gix = 0.f; giy = 0.f;
+  double wxd[NT];
+#pragma unroll
+  for (int bb = 0; bb < NT; ++bb) wxd[bb] = (double)wx[bb];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    float sxv = 0.f, sdx = 0.f;
+    const double gwy = (double)(gs_ * wy[a]);
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) {
+      const int cell = base + a * WW + bb;
+      const float val = win[cell];
+      atomicAdd(&acc[cell], fixed_from_product(gwy, wxd[bb]));
+      sxv = fmaf(val, wx[bb], sxv);
+      sdx = fmaf(val, dwx[bb], sdx);
+    }
+    gix = fmaf(wy[a], sdx, gix);
+    giy = fmaf(dwy[a], sxv, giy);
+  }
+}
+
+// workgroup maximum of the |cotangent| bit patterns; contains a barrier
+__device__ __forceinline__ float reduce_gmax(unsigned gmaxb, float* misc, int nwaves) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gmaxb = max(gmaxb, (unsigned)__shfl_xor((int)gmaxb, o, 64));
+  if ((threadIdx.x & 63) == 0) misc[2 + (threadIdx.x >> 6)] = __uint_as_float(gmaxb);
+  __syncthreads();
+  unsigned m = 0;
+  for (int q = 0; q < nwaves; ++q) m = max(m, __float_as_uint(misc[2 + q]));
+  return __uint_as_float(m);
+}
+
+// W == 64, separable grid: one workgroup per plane, wave w owns rows w, w+4, ...
+template <int MODE>
+__global__ void __launch_bounds__(256)
+sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ field,
+                    const float* __restrict__ u, const float* __restrict__ v,
+                    float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
+                    const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                    const float* __restrict__ lon, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
+                    int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int vec4) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0, W = 64;
+  const int H = g.H, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* GO = gout + (int64_t)b * go_bs + (int64_t)k * P;
+  float* GF = gfield + (int64_t)b * gf_bs + (int64_t)k * P;
+  float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
+  float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
+
+  const int wn = Hp * Wp, wn2 = (wn + 1) & ~1;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);  // [wn] fixed-point sums
+  float* win = smem + 2 * wn2;                                             // [wn]  F~ window
+  float* misc = win + wn2;   // [0..1] pole means of gout, [2..6) per-wave max |cotangent|
+
+  // first rows' operands while the window is staged
+  float qu[ADV_PF], qv[ADV_PF], qg[ADV_PF];
+#pragma unroll
+  for (int d = 0; d < ADV_PF; ++d) {
+    const int j = min(wave + 4 * d, H - 1) * W;
+    qu[d] = srow(U + j)[lane]; qv[d] = srow(V + j)[lane]; qg[d] = srow(GO + j)[lane];
+  }
+  const float lonc = lon_cells(lon[lane], g);
+  if (vec4) stage_plane_vec4(win, F, H, W, p);
+  else {
+    Window w{0, 0, Hp, Wp};
+    stage_window(win, F, w, H, W, p, false, 0.f, 0.f, 256);
+  }
+  for (int i = tid; i < wn; i += 256) acc[i] = 0ull;
+  unsigned gmaxb = 0;
+  for (int y = wave; y < H; y += 4) {
+    const float gval = srow(GO + y * W)[lane];
+    gmaxb = max(gmaxb, abs_bits(gval));
+    if (y == 0 || y == H - 1) {   // adjoint of the final pole mean: the cotangent of a pole row is its row mean
+      const float m = wave_sum(gval) * (1.0f / 64.0f);
+      if (lane == 0) misc[y == 0 ? 0 : 1] = m;
+    }
+  }
+  const float mxall = reduce_gmax(gmaxb, misc, 4);    // its barrier also closes the staging
+  pole_rows_to_mean_lds(win, H, W, p, Wp);
+  __syncthreads();
+  const float gm0 = misc[0], gm1 = misc[1];
+  float scale, inv_scale;   // every thread derives the same power-of-two scale
+  fixed_point_scale(mxall, scale, inv_scale);
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp;
+  for (int y0 = wave; y0 < H; y0 += 4 * ADV_PF) {
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) {
+      const int y = y0 + 4 * d;                 // wave-uniform
+      const float cu = qu[d], cv = qv[d], cgo = qg[d];
+      {
+        const int j = min(y + 4 * ADV_PF, H - 1) * W;
+        qu[d] = srow(U + j)[lane]; qv[d] = srow(V + j)[lane]; qg[d] = srow(GO + j)[lane];
+      }
+      if (y < H) {
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+        float ix, iy, tx, ty, wx[NT], wy[NT], dwx[NT], dwy[NT];
+        DepState st;
+        departure(cu, cv, sa, ca, lonc, g, ix, iy, &st);
+        int cell;
+        const bool edge = tap_block_whole<MODE>(ix, iy, Hpf, Wpf, tx, ty, cell);
+        int base = cell + OFF0 * (Wp + 1);
+        if (__any(edge)) {
+          int bx, by, sx, sy;
+          tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
+          Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+          Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+          shift_weights<NT>(wx, sx); shift_weights<NT>(dwx, sx);
+          shift_weights<NT>(wy, sy); shift_weights<NT>(dwy, sy);
+          base = by * Wp + bx;
+        } else {
+          Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+          Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+        }
+        const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
+        float gix, giy;
+        scatter_gather<MODE>(acc, win, base, Wp, wx, wy, dwx, dwy, gval * scale, gix, giy);
+        float guv, gvv;
+        departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
+        srow(GU + y * W)[lane] = guv;
+        srow(GV + y * W)[lane] = gvv;
+      }
+    }
+  }
+  __syncthreads();
+  // fold the halo back: every source cell sums its aliases (adjoint of the a1 map: its own cell, the
+  // lon-wrap copies of the p edge columns, and for rows next to a pole the mirrored row shifted by
+  // W/2), then the adjoint of the first pole mean (rows 0, H-1 <- their mean)
+  const double inv = (double)inv_scale;
+  const bool lo_edge = lane < p, hi_edge = lane >= W - p;
+  const unsigned xm = lane ^ 32u;                     // (x + W/2) mod W
+  const bool mlo = xm < p, mhi = xm >= W - p;
+  for (int y = wave; y < H; y += 4) {
+    const unsigned long long* row = acc + (y + p) * Wp + p;
+    long long s = (long long)row[lane];
+    if (lo_edge) s += (long long)row[lane + W];
+    if (hi_edge) s += (long long)row[lane - W];
+    int mr = -1;                                 // padded row of the over-the-pole alias (wave-uniform)
+    if (y >= 1 && y <= p) mr = p - y;
+    else if (y >= H - 1 - p && y <= H - 2) mr = 2 * (H - 1) - y + p;
+    if (mr >= 0) {
+      const unsigned long long* mrow = acc + mr * Wp + p;
+      s += (long long)mrow[xm];
+      if (mlo) s += (long long)mrow[xm + W];
+      if (mhi) s += (long long)mrow[xm - W];
+    }
+    float val = (float)((double)s * inv);
+    if (y == 0 || y == H - 1) val = wave_sum(val) * (1.0f / 64.0f);
+    srow(GF + y * W)[lane] = val;
+  }
 }
 
 template <int MODE, bool WHOLE, int NTH>
@@ -624,22 +888,19 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
   for (int i = tid; i < wn; i += NTH) acc[i] = 0ull;
   // max |cotangent| over this workgroup's arrival points -> fixed-point scale
   const int npts = th * tw;
-  float gmax = WHOLE ? 0.f : fmaxf(fabsf(gm0), fabsf(gm1));
+  unsigned gmaxb = WHOLE ? 0u : max(abs_bits(gm0), abs_bits(gm1));
   {
     TileIter itg(tid, tw, NTH);
     for (int i = tid; i < npts; i += NTH, itg.next())
-      gmax = fmaxf(gmax, fabsf(GO[(ty0 + itg.yl) * W + tx0 + itg.xl]));
+      gmaxb = max(gmaxb, abs_bits(GO[(ty0 + itg.yl) * W + tx0 + itg.xl]));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
-  if ((tid & 63) == 0) misc[2 + wave] = gmax;
-  __syncthreads();
+  const float mxall = reduce_gmax(gmaxb, misc, NTH / 64);
   if (WHOLE) {
     if (wave < 2) {
       float* row = win + (wave == 0 ? p : H - 1 + p) * Wp;
       const float m = wave_row_mean(row + p, W);
       for (int x = tid & 63; x < Wp; x += 64) row[x] = m;
-    } else {
+    } else if (wave < 4) {
       // adjoint of the final pole mean: the cotangent of a pole row is its own row mean
       const float* row = GO + (wave == 2 ? 0 : (int64_t)(H - 1) * W);
       const float m = wave_row_mean(row, W);
@@ -649,13 +910,8 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     gm0 = misc[0]; gm1 = misc[1];
   }
   float scale, inv_scale;   // every thread derives the same power-of-two scale
-  float mxall = misc[2];
-#pragma unroll
-  for (int q = 1; q < NTH / 64; ++q) mxall = fmaxf(mxall, misc[2 + q]);
   fixed_point_scale(mxall, scale, inv_scale);
-  const bool rowwave = WHOLE && W == 64;
 
-  const float kx = ((float)W - 1.0f) / g.d_lon, ky = ((float)H - 1.0f) / g.d_lat;
   TileIter it(tid, tw, NTH);
   // operands of point i+1 are in flight while point i is computed (see the forward kernel)
   float nu = 0.f, nv = 0.f, nsa = 0.f, nca = 0.f, nlo = 0.f, ngo = 0.f;
@@ -674,7 +930,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     float ix, iy, tx, ty, wx[NT], wy[NT], dwx[NT], dwy[NT];
     int bx, by, sx, sy;
     DepState st;
-    departure(cu, cv, sa, ca, clo, g, ix, iy, &st);
+    departure(cu, cv, sa, ca, lon_cells(clo, g), g, ix, iy, &st);
     tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
     Interp<MODE>::weights(tx, wx);
     Interp<MODE>::weights(ty, wy);
@@ -687,7 +943,6 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
       shift_weights<NT>(dwy, sy);
     }
     const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
-    const float gs_ = gval * scale;
     int ry = by - w.wy0, rx = bx - w.wx0;
     bool inwin = true;
     if (!WHOLE) {
@@ -696,24 +951,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     }
     float gix = 0.f, giy = 0.f;
     if (inwin) {
-      const int base = ry * w.WW + rx;
-#pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        float sxv = 0.f, sdx = 0.f;
-        const float gwy = gs_ * wy[a];
-#pragma unroll
-        for (int bb = 0; bb < NT; ++bb) {
-          const int cell = base + a * w.WW + bb;
-          const float val = win[cell];
-#ifndef ADV_NO_ATOMIC
-          atomicAdd(&acc[cell], fixed_from_float(gwy * wx[bb]));
-#endif
-          sxv = fmaf(val, wx[bb], sxv);
-          sdx = fmaf(val, dwx[bb], sdx);
-        }
-        gix = fmaf(wy[a], sdx, gix);
-        giy = fmaf(dwy[a], sxv, giy);
-      }
+      scatter_gather<MODE>(acc, win, ry * w.WW + rx, w.WW, wx, wy, dwx, dwy, gval * scale, gix, giy);
     } else {  // tiled schedule only
       const int lastrow = H - 1;
 #pragma unroll
@@ -726,17 +964,15 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
           float val = F[(int64_t)r * W + c];
           if (r == 0) val = m0; else if (r == lastrow) val = m1;
           atomicAdd(&GF[(int64_t)r * W + c], gval * wy[a] * wx[bb]);
-          sxv += val * wx[bb];
-          sdx += val * dwx[bb];
+          sxv = fmaf(val, wx[bb], sxv);
+          sdx = fmaf(val, dwx[bb], sdx);
         }
-        gix += wy[a] * sdx;
-        giy += dwy[a] * sxv;
+        gix = fmaf(wy[a], sdx, gix);
+        giy = fmaf(dwy[a], sxv, giy);
       }
     }
-    gix *= gval;
-    giy *= gval;
     float guv, gvv;
-    departure_backward(st, sa, ca, gix, giy, kx, ky, g.dt, guv, gvv);
+    departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
     GU[idx] = guv;
     GV[idx] = gvv;
   }
@@ -749,24 +985,16 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
       const int y = i / W, x = i - y * W;
       long long s = 0;
       geo_for_each_alias(y, x, H, W, p, [&](int ii, int jj) { s += (long long)acc[(ii + p) * Wp + jj + p]; });
-      float val = (float)((double)s * inv);
-      if (rowwave) {   // a row is one wave's lanes in one iteration
-        if (y == 0 || y == H - 1) val = wave_sum(val) / (float)W;
-        GF[i] = val;
-      } else {
-        win[i] = val;  // the float plane reuses the window storage
-      }
+      win[i] = (float)((double)s * inv);   // the float plane reuses the window storage
     }
-    if (!rowwave) {
-      __syncthreads();
-      if (wave < 2) {
-        float* row = win + (wave == 0 ? 0 : (H - 1) * W);
-        const float m = wave_row_mean(row, W);
-        for (int x = tid & 63; x < W; x += 64) row[x] = m;
-      }
-      __syncthreads();
-      for (int i = tid; i < P; i += NTH) GF[i] = win[i];
+    __syncthreads();
+    if (wave < 2) {
+      float* row = win + (wave == 0 ? 0 : (H - 1) * W);
+      const float m = wave_row_mean(row, W);
+      for (int x = tid & 63; x < W; x += 64) row[x] = m;
     }
+    __syncthreads();
+    for (int i = tid; i < P; i += NTH) GF[i] = win[i];
   } else {
     // flush the window once: one global float atomic per touched cell instead of 16 per point
     // (consecutive lanes -> consecutive cells: the 16 atomics per 64-byte line of one wave-instruction
@@ -815,16 +1043,22 @@ int check_adv(const char* name, int B, int K, int H, int W, int mode) {
   PD_REQUIRE(W % 2 == 0, "%s: Number of longitude points must be even", name);
   PD_REQUIRE(mode == PARADIS_INTERP_BILINEAR || mode == PARADIS_INTERP_BICUBIC,
              "%s: interpolation mode must be 1 (bilinear) or 2 (bicubic)", name);
-  PD_REQUIRE((int64_t)B * K < (1 << 30) && (int64_t)H * W < (1ll << 30), "%s: too large", name);
+  PD_REQUIRE((int64_t)B * K < (1 << 30) && (int64_t)H * W < (1ll << 24), "%s: too large", name);
   return 0;
 }
 
+// constants of the coordinate map, evaluated in double from the reference's fp32 buffers
+// (min_lat, min_lon, d_lat = max - min, d_lon: model/advection.py:67-72)
 AdvGeom make_geom(int H, int W, int p, float dt, float min_lat, float min_lon, float d_lat, float d_lon) {
-  AdvGeom g{H, W, p, dt, min_lat, min_lon, d_lat, d_lon, 0.f, 0.f, 0.f, 0.f};
-  g.r_lat = (float)(1.0 / (double)d_lat);
-  g.r_lon = (float)(1.0 / (double)d_lon);
-  g.r_wpm1 = (float)(1.0 / (double)(W + 2 * p - 1));
-  g.r_hpm1 = (float)(1.0 / (double)(H + 2 * p - 1));
+  AdvGeom g;
+  g.H = H; g.W = W; g.p = p;
+  g.ndt = -dt;
+  const double cx = ((double)W - 1.0) / (double)d_lon, cy = ((double)H - 1.0) / (double)d_lat;
+  const double per = 6.283185307179586476925286766559 * cx;
+  g.cx = (float)cx; g.cy = (float)cy; g.cxd = cx;
+  g.per = (float)per; g.inv_per = (float)(1.0 / per);
+  g.c0x = (float)((double)p - (double)min_lon * cx);
+  g.c0y = (float)((double)p - (double)min_lat * cy);
   return g;
 }
 
@@ -849,8 +1083,7 @@ int reserve_lds(K kernel, const char* what) {
 // `flags` of the C ABI (include/paradis_hip.h, PARADIS_ADVECT_*): schedule choice and window halo are
 // per-call arguments, the library keeps no mutable state
 bool use_tiled(size_t whole_bytes, int flags) {
-  const int sched = flags & PARADIS_ADVECT_SCHEDULE_MASK;
-  if (sched == PARADIS_ADVECT_TILED) return true;
+  if (flags & PARADIS_ADVECT_TILED) return true;
   return whole_bytes > WHOLE_LDS_LIMIT;
 }
 int halo_of(int flags, int dflt, bool backward) {
@@ -858,6 +1091,11 @@ int halo_of(int flags, int dflt, bool backward) {
   const int hb = (flags >> PARADIS_ADVECT_HALO_BWD_SHIFT) & 0xff;
   if (backward && hb) h = hb;
   return h == 0 ? dflt : std::min(h - 1, MAX_HALO);
+}
+// one wave per latitude row with scalar table loads: W == 64 and a grid whose latitude depends on the
+// row only and whose longitude depends on the column only (the caller vouches for it through `flags`)
+bool use_row64(int W, int flags) {
+  return W == 64 && (flags & PARADIS_ADVECT_SEPARABLE) && !(flags & PARADIS_ADVECT_GENERIC);
 }
 
 }  // namespace
@@ -877,6 +1115,14 @@ extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W) {
                          __VA_ARGS__);                                                                    \
   } while (0)
 
+#define ADV_LAUNCH_ROW64(KERNEL, grid, lds, ...)                                                             \
+  do {                                                                                                       \
+    if (mode == PARADIS_INTERP_BICUBIC)                                                                      \
+      hipLaunchKernelGGL((KERNEL<PARADIS_INTERP_BICUBIC>), dim3(grid), dim3(256), lds, st, __VA_ARGS__);     \
+    else                                                                                                     \
+      hipLaunchKernelGGL((KERNEL<PARADIS_INTERP_BILINEAR>), dim3(grid), dim3(256), lds, st, __VA_ARGS__);    \
+  } while (0)
+
 extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, float* out,
                                      const float* sin_lat, const float* cos_lat, const float* lon,
                                      int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs,
@@ -894,8 +1140,12 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   // 16-byte staging path: aligned planes, p even (bicubic), padded width even
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && a16(field) && (p % 2 == 0);
   if (!use_tiled(whole, flags)) {
-    ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
-               (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
+    if (use_row64(W, flags))
+      ADV_LAUNCH_ROW64(sl_advect_fwd_row64, planes, whole, field, u, v, out, sin_lat, cos_lat, lon, K, g, f_bs,
+                       uv_bs, o_bs, vec4);
+    else
+      ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
+                 (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_fwd");
     return 0;
   }
@@ -939,9 +1189,13 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                    (reinterpret_cast<uintptr_t>(field) & 15) == 0;
   const size_t whole = lds_of((size_t)(H + 2 * p) * (W + 2 * p));
   if (!use_tiled(whole, flags)) {
-    ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
-               cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
-               gf_bs, guv_bs, 0, 1, 1, vec4);
+    if (use_row64(W, flags))
+      ADV_LAUNCH_ROW64(sl_advect_bwd_row64, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
+                       K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, vec4);
+    else
+      ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
+                 cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
+                 gf_bs, guv_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_bwd");
     return 0;
   }

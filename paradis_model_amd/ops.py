@@ -27,7 +27,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import check, dptr, lib, require_hip, stream_ptr
+from ._lib import check, dptr, lib, stream_ptr
 
 ACT_CODES = {None: 0, "none": 0, "SiLU": 1, "GELU": 2}
 MODE_CODES = {"bilinear": 1, "bicubic": 2}
@@ -57,6 +57,15 @@ def _fake(name: str):
 
 def _autograd(name: str, setup, backward) -> None:
     torch.library.register_autograd(f"paradis::{name}", backward, setup_context=setup)
+
+
+def require_hip(*tensors) -> None:
+    """Device check of the Python wrappers (the dtype check sits in the kernels, behind the autocast
+    rule that widens bf16/fp16 inputs to fp32)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("paradis_model_amd ops run on the MI355X only: got a CPU tensor "
+                               "(there is no CPU fallback; use oracle/ for CPU checks)")
 
 
 def _f32(*tensors) -> None:
@@ -163,6 +172,8 @@ class AdvectGeometry:
         self.min_lon = float(lon.min())
         self.d_lat = float(lat.max() - lat.min())
         self.d_lon = float(lon.max() - lon.min())
+        # regular lat-lon grid: latitude depends on the row only, longitude on the column only
+        self.separable = bool((lat == lat[:, :1]).all()) and bool((lon == lon[:1, :]).all())
         self._dev = {}
 
     def tables(self, device):
@@ -305,15 +316,17 @@ def _advv_backward(ctx, gout):
 _autograd("sl_advect_vel", _advv_setup, _advv_backward)
 
 
-ADVECT_TILED = 2                    # include/paradis_hip.h PARADIS_ADVECT_TILED
+ADVECT_GENERIC, ADVECT_TILED, ADVECT_SEPARABLE = 1, 2, 4     # include/paradis_hip.h PARADIS_ADVECT_*
 # schedule hints applied when a call passes none (diagnostics: tools/advect_halo_sweep.py)
 ADVECT_FLAGS = int(os.environ.get("PARADIS_ADVECT_FLAGS", "0"), 0)
 
 
-def advect_flags(tiled: bool = False, halo: Optional[int] = None, halo_bwd: Optional[int] = None) -> int:
+def advect_flags(tiled: bool = False, halo: Optional[int] = None, halo_bwd: Optional[int] = None,
+                 generic: bool = False) -> int:
     """``flags`` of the advection ops: force the tiled schedule and/or its window halo (padded cells;
-    ``halo_bwd`` overrides it for the backward kernel)."""
-    return ((ADVECT_TILED if tiled else 0) | (((int(halo) + 1) << 8) if halo is not None else 0)
+    ``halo_bwd`` overrides it for the backward kernel), or the generic whole-plane kernel."""
+    return ((ADVECT_TILED if tiled else 0) | (ADVECT_GENERIC if generic else 0)
+            | (((int(halo) + 1) << 8) if halo is not None else 0)
             | (((int(halo_bwd) + 1) << 16) if halo_bwd is not None else 0))
 
 
@@ -321,8 +334,10 @@ def _geom_args(geom: AdvectGeometry, device, dt: float, mode: str, flags: Option
     if mode not in MODE_CODES:
         raise ValueError(f"interpolation must be one of {list(MODE_CODES)}")
     sl, cl, lo = geom.tables(device)
-    return (sl, cl, lo, float(dt), geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode],
-            ADVECT_FLAGS if flags is None else int(flags))
+    flags = ADVECT_FLAGS if flags is None else int(flags)
+    if geom.separable:
+        flags |= ADVECT_SEPARABLE
+    return sl, cl, lo, float(dt), geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode], flags
 
 
 def sl_advect_vel(field, vel, geom: AdvectGeometry, dt: float, mode: str = "bicubic", flags: Optional[int] = None):
