@@ -39,36 +39,70 @@ WORKLOADS = {
 }
 
 
-def pmc_mfma_busy():
-    """Matrix-pipe busy fraction of the GEMM kernels from the newest committed PMC summary
-    (profiles/*_mfma_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), same bench
-    command under rocprofv3 --pmc); {kernel: fraction} or None."""
+def _library_sha256():
+    import hashlib
+    from paradis_model_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def _profile(kind: str):
+    """Newest committed PMC summary of `kind` (profiles/<tag>_<kind>.json, written by
+    tools/profile_round.sh + tools/summarize_profile.py for this same bench command under rocprofv3
+    --pmc) with its provenance: the summary records the sha256 of the library it profiled; a summary of
+    another build is still reported but marked, and one whose kernels no longer exist in the loaded
+    library is dropped.  Returns (data, source) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_busy.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}.json")), key=os.path.getmtime)
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    return {k: v for k, v in data.items() if "gemm" in k} or None
+    meta = data.pop("_meta", {}) if isinstance(data, dict) else {}
+    src = {"from_profile": os.path.relpath(files[-1], ROOT), "profiled_commit": meta.get("commit"),
+           "same_library_build": meta.get("library_sha256") == _library_sha256() if meta.get("library_sha256") else None}
+    return data, src
+
+
+def _kernels_exist(names) -> bool:
+    """every profiled kernel name must still be a symbol of the loaded library"""
+    from paradis_model_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        blob = f.read()
+    return all(n.split("<")[0].split("(")[0].strip().encode() in blob for n in names)
+
+
+def pmc_mfma_busy():
+    """Matrix-pipe busy fraction of the GEMM kernels (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 *
+    1024 SIMDs)) from the committed PMC pass; NOT measured in this run: `source` says where it comes from."""
+    data, src = _profile("mfma_busy")
+    if not data:
+        return None
+    vals = {k: v for k, v in data.items() if "gemm" in k}
+    if not vals or not _kernels_exist(vals):
+        return None
+    return {"values": vals, "source": src}
 
 
 def pmc_traffic(substr: str):
-    """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/*_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes with the gfx950 2x read-side correction of
-    MI355X_MICROARCH.md; produced by tools/profile_round.sh for this same bench command).
-    Launch-weighted mean over the kernels whose name contains `substr`; None if no profile exists."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        data = json.load(f)
+    """HBM bytes per launch of the kernels whose name contains `substr` from the committed rocprofv3 PMC
+    passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x read-side correction of
+    MI355X_MICROARCH.md); launch-weighted mean.  Counters cannot be collected inside a timed run, so
+    this is a read-back: returns (bytes, source) with the provenance, (None, None) without a usable profile."""
+    data, src = _profile("traffic")
+    if not data:
+        return None, None
     num = den = 0.0
+    names = []
     for name, rec in data.items():
         if substr in name and "hbm_bytes_per_launch" in rec:
             num += rec["hbm_bytes_per_launch"] * rec.get("launches", 1)
             den += rec.get("launches", 1)
-    return num / den if den else None
+            names.append(name)
+    if not den or not _kernels_exist(names):
+        return None, None
+    src = dict(src, kernels=names)
+    return num / den, src
 
 
 def usable_cores() -> int:
@@ -148,6 +182,8 @@ def main():
                     help="pointwise GEMM arithmetic: exact 3-way bf16 split on the bf16 MFMA (default) or f32 MFMA")
     ap.add_argument("--no-exact-leg", action="store_true",
                     help="skip the second timed loop with the exact f32-MFMA GEMMs (reported as exact_f32_gemm)")
+    ap.add_argument("--bucket-mb", type=int, default=32, help="DDP gradient bucket size (N>1)")
+    ap.add_argument("--static-graph", action="store_true", help="DDP static_graph=True (N>1)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
@@ -169,6 +205,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1 and os.environ.get("PARADIS_SHARE_GPU0") != "1":
+        # one process per GPU: every rank must own a distinct device of this node
+        ids = [None] * world
+        torch.distributed.all_gather_object(ids, (os.uname().nodename, torch.cuda.current_device()))
+        if len(set(ids)) != world:
+            raise SystemExit(f"ranks share a device: {ids}")
 
     nlat, nlon, poles, B, S = WORKLOADS[args.workload]
     if "_fwd_" in args.workload:
@@ -183,7 +225,7 @@ def main():
     torch.manual_seed(cfg.init.seed)
     model = Paradis(stub_datamodule(cfg), cfg, lg, og).to(dev)
     loss_fn = build_loss(cfg, lat_deg).to(dev)
-    ddp = wrap_ddp(model, device_ids=[local])
+    ddp = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, static_graph=args.static_graph)
     step = TrainStep(ddp, loss_fn, cfg, num_common=lay.num_common_features,
                      n_inputs=cfg.dataset.n_time_inputs)
     batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234 + rank, device=dev)
@@ -249,6 +291,8 @@ def main():
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
                    "optimizer": args.optimizer, "parallelism": f"dp{world}",
+                   "ddp": ({"bucket_cap_mb": args.bucket_mb, "static_graph": bool(args.static_graph),
+                            "backend": torch.distributed.get_backend()} if world > 1 else None),
                    "gemm_arithmetic": ("fp32 via exact 3-way bf16 split on bf16 MFMA, fp32 accumulate"
                                        if args.gemm == "split" else "fp32 MFMA"),
                    "mode": "forward-only" if args.forward_only else "train",
@@ -271,12 +315,13 @@ def main():
             else:
                 kname = "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)"
                 peak = MFMA_F32_PEAK_TFLOPS
+            gemm_traffic, gemm_src = pmc_traffic("pw_gemm")
             out["roofline"] = {"kernel": kname,
                                "bound": "mfma", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak,
                                "flops": "algorithmic 2*M*N*K per GEMM (fp32-equivalent)"
                                         + ("; executed bf16 MFMA rate = 6x achieved, peak = 2500/6" if args.gemm == "split" else ""),
-                               "traffic": pmc_traffic("pw_gemm"),
+                               "traffic": gemm_traffic, "traffic_source": gemm_src,
                                "launches": n, "avg_launch_ms": ms / n,
                                "flops_per_launch": flops / n,
                                "share_of_step": ms / (1e3 * elapsed),
@@ -285,8 +330,9 @@ def main():
             if key in s:
                 r = s[key]
                 ach = r["work"] / (r["ms"] * 1e-3) / 1e9
+                tr, tr_src = pmc_traffic(key)
                 out[name] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
+                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
                              "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
                              "bytes_per_launch": r["work"] / r["launches"]}
     if exact is not None:

@@ -80,7 +80,7 @@ int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
 
 /* ---- a7 (depthwise half of SepConv, reference model/blocks.py:101-113) and the static
  * encoder's GeoCyclicPadding(3)+Conv2d(groups=C) (reference model/paradis.py:189-190):
- * k x k per-channel stencil on the virtual geocyclic halo. w [C,k,k]; bias [C] or NULL; k in {3,5,7}. */
+ * k x k per-channel stencil on the virtual geocyclic halo. w [C,k,k]; bias [C] or NULL; k odd, 1..11. */
 int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
                            int B, int C, int H, int W, int k, void* stream);
 int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx,

@@ -8,6 +8,9 @@
 #define WAVE 64
 
 void paradis_set_error(const char* fmt, ...);
+// PARADIS_DETERMINISTIC=1 (read once): every reduction that would otherwise finish with float atomics
+// runs in a fixed order (bit-identical gradients run to run), at a small cost; see DESIGN.md section 5b
+bool paradis_deterministic();
 
 #define PD_REQUIRE(cond, ...)                 \
   do {                                        \

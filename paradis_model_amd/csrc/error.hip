@@ -1,5 +1,6 @@
 // Thread-local error string + ABI version for libparadis_hip.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -9,6 +10,14 @@ void paradis_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+bool paradis_deterministic() {
+  static const int on = [] {
+    const char* e = getenv("PARADIS_DETERMINISTIC");
+    return (e && e[0] && e[0] != '0') ? 1 : 0;
+  }();
+  return on != 0;
 }
 
 extern "C" const char* paradis_last_error(void) { return g_err; }

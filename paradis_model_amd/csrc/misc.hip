@@ -311,7 +311,7 @@ extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, co
     // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
     if (Cin <= 16) {
       if (hipMemsetAsync(gm8, 0, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
-      const int och = 32;
+      const int och = paradis_deterministic() ? Co : 32;   // one chunk: a single add per element, fixed order
       hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och),
                          dim3(256), 0, st, Pw, gmap, gm8, Cin, Co, P, och);
     } else {
@@ -403,6 +403,7 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
   }
   if (!gmap && !gbias) return 0;
   int pchunks = std::max(1, std::min((P + 255) / 256, std::max(1, 2048 / C)));
+  if (paradis_deterministic()) pchunks = 1;   // one workgroup per channel: no atomics between chunks
   hipLaunchKernelGGL(bias_grads_kernel, dim3((unsigned)((int64_t)C * pchunks)), dim3(256), 0, st, dz, gmap,
                      gbias, B, C, P, dz_bs, pchunks);
   PD_CHECK_LAUNCH("bias_grads");
@@ -450,7 +451,7 @@ extern "C" int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
   if (hipMemsetAsync(gm8, 0, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
-  const int och = 32;
+  const int och = paradis_deterministic() ? Co : 32;
   hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och), dim3(256),
                      0, st, Pw, gmap, gm8, Cin, Co, P, och);
   PD_CHECK_LAUNCH("global_bias_proj_bwd");

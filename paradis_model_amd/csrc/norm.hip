@@ -365,10 +365,12 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
   }
 }
 
-// gw[c] += sum_k partial[k][0][c], gb[c] += sum_k partial[k][1][c]; grid (ceil(C/256), row chunks)
+// Two-stage reduction of the per-block partial sums in a fixed order (no atomics: bit-reproducible):
+// stage 1, grid (ceil(C/256), chunks): chunk[y][0][c] = sum over the chunk's rows of partial[k][0][c] (and [1]);
+// stage 2, grid ceil(C/256): gw[c] = sum_y chunk[y][0][c], gb[c] = sum_y chunk[y][1][c].
 __global__ void __launch_bounds__(256)
-channel_norm_bwd_fused_finish(const float* __restrict__ partial, float* __restrict__ gw,
-                              float* __restrict__ gb, int C, int nblk, int rows_per_chunk) {
+channel_norm_bwd_fused_finish(const float* __restrict__ partial, float* __restrict__ chunk, int C, int nblk,
+                              int rows_per_chunk) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int k0 = blockIdx.y * rows_per_chunk, k1 = min(k0 + rows_per_chunk, nblk);
@@ -377,8 +379,22 @@ channel_norm_bwd_fused_finish(const float* __restrict__ partial, float* __restri
     a += partial[(int64_t)k * 2 * C + c];
     d += partial[(int64_t)k * 2 * C + C + c];
   }
-  atomicAdd(&gw[c], a);
-  atomicAdd(&gb[c], d);
+  chunk[(int64_t)blockIdx.y * 2 * C + c] = a;
+  chunk[(int64_t)blockIdx.y * 2 * C + C + c] = d;
+}
+
+__global__ void __launch_bounds__(256)
+channel_norm_bwd_fused_finish2(const float* __restrict__ chunk, float* __restrict__ gw, float* __restrict__ gb,
+                               int C, int chunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, d = 0.f;
+  for (int y = 0; y < chunks; ++y) {
+    a += chunk[(int64_t)y * 2 * C + c];
+    d += chunk[(int64_t)y * 2 * C + C + c];
+  }
+  gw[c] = a;
+  gb[c] = d;
 }
 
 int dw_chunks(int B, int C, int P) {
@@ -439,7 +455,8 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
 
 extern "C" size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P) {
   const size_t three_kernel = (size_t)C * dw_chunks(std::max(B, 1), C, P) * 2 * sizeof(float);
-  const size_t fused = (size_t)std::max(B, 1) * ((P + 31) / 32) * 2 * C * sizeof(float);
+  const size_t nblk = (size_t)std::max(B, 1) * ((P + 31) / 32);
+  const size_t fused = (nblk + (nblk + 63) / 64) * 2 * C * sizeof(float);   // per-block partials + per-chunk sums
   return std::max(three_kernel, fused) + 256;
 }
 
@@ -494,14 +511,12 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     else
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<36, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
                          w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
-    if (hipMemsetAsync(gw, 0, C * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(gb, 0, C * sizeof(float), st) != hipSuccess) {
-      paradis_set_error("channel_norm_bwd: memset failed");
-      return 2;
-    }
-    const int rows = 64;
-    hipLaunchKernelGGL(channel_norm_bwd_fused_finish, dim3((C + 255) / 256, (nblk + rows - 1) / rows),
-                       dim3(256), 0, st, partial, gw, gb, C, nblk, rows);
+    const int rows = 64, chunks = (nblk + rows - 1) / rows;
+    float* chunk = partial + (size_t)nblk * 2 * C;
+    hipLaunchKernelGGL(channel_norm_bwd_fused_finish, dim3((C + 255) / 256, chunks), dim3(256), 0, st, partial,
+                       chunk, C, nblk, rows);
+    hipLaunchKernelGGL(channel_norm_bwd_fused_finish2, dim3((C + 255) / 256), dim3(256), 0, st, chunk, gw, gb, C,
+                       chunks);
     PD_CHECK_LAUNCH("channel_norm_bwd(fused)");
     return 0;
   }

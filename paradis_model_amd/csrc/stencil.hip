@@ -364,9 +364,11 @@ upsample_lonp_kernel(const float* __restrict__ src, float* __restrict__ dst, int
 
 int check_dw(const char* name, int B, int C, int H, int W, int k) {
   PD_REQUIRE(B >= 0 && C >= 1 && H >= 2 && W >= 2, "%s: bad shape", name);
-  PD_REQUIRE(k == 3 || k == 5 || k == 7, "%s: kernel size %d not supported (3,5,7)", name, k);
+  PD_REQUIRE(k >= 1 && k <= 11 && (k & 1), "%s: kernel size %d not supported (odd sizes 1..11)", name, k);
   PD_REQUIRE(W % 2 == 0, "%s: Number of longitude points must be even", name);
   PD_REQUIRE((k - 1) / 2 <= H - 2 && (k - 1) <= W, "%s: grid %dx%d too small for k=%d", name, H, W, k);
+  // the analytic halo folding of the data gradient is verified for halos that do not overlap themselves
+  PD_REQUIRE(k <= 7 || (H >= 2 * k && W >= 2 * k), "%s: k=%d needs a grid of at least %dx%d", name, k, 2 * k, 2 * k);
   PD_REQUIRE((int64_t)B * C * (((H + TH - 1) / TH) * ((W + TW - 1) / TW)) < (1ll << 31), "%s: too large", name);
   return 0;
 }
@@ -387,9 +389,12 @@ static int whole_plane_vec4(const float* src, int H, int W, int k) {
 
 #define DISPATCH_K(k, CALL)          \
   switch (k) {                       \
+    case 1: { constexpr int KK = 1; CALL; } break; \
     case 3: { constexpr int KK = 3; CALL; } break; \
     case 5: { constexpr int KK = 5; CALL; } break; \
-    default: { constexpr int KK = 7; CALL; } break; \
+    case 7: { constexpr int KK = 7; CALL; } break; \
+    case 9: { constexpr int KK = 9; CALL; } break; \
+    default: { constexpr int KK = 11; CALL; } break; \
   }
 
 extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,

@@ -165,7 +165,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
-def wrap_ddp(model, *, bucket_cap_mb: int = 32, device_ids: Optional[Sequence[int]] = None):
+def wrap_ddp(model, *, bucket_cap_mb: int = 32, device_ids: Optional[Sequence[int]] = None,
+             static_graph: bool = False):
     """Batch-sharded data parallelism (the reference's only strategy, ``train.py:49``): full replica
     per GPU, bucketed gradient all-reduce (RCCL over xGMI) overlapped with backward.  Geometry
     buffers are deterministic functions of the grid, so buffer broadcast is disabled; the graph is
@@ -175,7 +176,7 @@ def wrap_ddp(model, *, bucket_cap_mb: int = 32, device_ids: Optional[Sequence[in
     return torch.nn.parallel.DistributedDataParallel(
         model, device_ids=list(device_ids) if device_ids is not None else None,
         broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
-        static_graph=False)
+        static_graph=bool(static_graph))
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -88,8 +88,10 @@ class SepConv(nn.Module):
     def __init__(self, input_dim: int, output_dim: int, mesh_size: tuple, kernel_size: int = 3,
                  bias: bool = True):
         super().__init__()
-        if kernel_size not in (3, 5, 7):
-            raise NotImplementedError("SepConv HIP stencil supports kernel_size 3, 5 or 7")
+        if kernel_size % 2 == 0 or not 1 <= kernel_size <= 11:
+            # (the reference's own padding arithmetic, (k-1)//2 per side, only preserves the grid for odd k)
+            raise NotImplementedError("SepConv: the HIP depthwise stencil supports odd kernel_size 1..11; "
+                                      f"got {kernel_size}")
         self.padding = (kernel_size - 1) // 2
         self.geo_padding = GeoCyclicPadding(self.padding)
         self.depthwise = nn.Conv2d(input_dim, input_dim, kernel_size, groups=input_dim, bias=False)

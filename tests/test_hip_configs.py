@@ -132,6 +132,8 @@ def test_cfg2_full_batch_rollout_properties():
             per.append(float(lb))
     mean = sum(per) / B
     assert abs(mean - float(total)) <= 2e-6 * abs(mean), (mean, float(total))
+    del model, batch, loss_fn
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------

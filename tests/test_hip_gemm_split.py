@@ -152,3 +152,69 @@ def test_batched_gemm_split_vs_exact():
             torch.cuda.synchronize()
             errs[split] = _err(C, ref)
         assert errs[True] <= 1.25 * errs[False] + 1e-7 and errs[True] <= 2e-6, ((T, M, K, N), errs)
+
+
+def _fwd_only(ops, split, x, w):
+    keep = ops.GEMM_SPLIT
+    ops.GEMM_SPLIT = split
+    try:
+        with torch.no_grad():
+            return ops.pointwise(x.cuda(), w.cuda()).cpu()
+    finally:
+        ops.GEMM_SPLIT = keep
+
+
+def test_split_extreme_magnitudes(ops):
+    """Edge semantics of the h/m/l split next to the exact f32 kernel (documented in DESIGN.md 4.1b):
+      * operands of magnitude 1e+-30 whose products are O(1): fp32-level result (bf16 has fp32's exponent
+        range, nothing over- or underflows in the split);
+      * operands below ~1e-33: the m / l terms (2^-8, 2^-16 of the operand) fall below fp32's smallest
+        normal number and are flushed - the split degrades gracefully towards bf16 precision of THAT
+        operand (<= 2^-15 at 1e-35, <= 2^-7 at 1e-37..1e-38), where the exact kernel keeps fp32 precision.
+        Activations and gradients of this model sit 20+ decades above that; PARADIS_GEMM=exact is the
+        answer for data that does not;
+      * |x| within half a bf16 ulp of FLT_MAX (>= 3.39e38) rounds to +-inf in the leading term: such an
+        operand gives NaN where the exact kernel may still be finite;
+      * Inf / NaN operands: every output they touch is non-finite in both arithmetics (the split turns
+        Inf into NaN: Inf - Inf in the residual), every other output is untouched."""
+    g = torch.Generator().manual_seed(77)
+    B, Ci, Co, H, W = 1, 64, 48, 8, 16
+    base_x = torch.randn(B, Ci, H, W, generator=g)
+    base_w = torch.randn(Co, Ci, generator=g) * Ci ** -0.5
+    ref = torch.einsum("oc,bchw->bohw", base_w.double(), base_x.double())
+    for sx, sw in ((1e30, 1e-30), (1e-30, 1e30)):
+        x, w = base_x * sx, base_w * sw
+        want = torch.einsum("oc,bchw->bohw", w.double(), x.double())
+        ys, ye = _fwd_only(ops, True, x, w), _fwd_only(ops, False, x, w)
+        assert torch.isfinite(ys).all()
+        es, ee = _err(ys, want), _err(ye, want)
+        assert es <= 1.25 * ee + 1e-7 and es <= 2e-6, (sx, es, ee)
+    # subnormal low terms of a tiny operand: graceful loss of its low bits, never garbage
+    for tiny, bound in ((1e-35, 2.0 ** -15), (1e-37, 2.0 ** -7)):
+        for x, w in ((base_x * tiny, base_w / tiny), (base_x / tiny * 1e-2, base_w * tiny * 1e2)):
+            want = torch.einsum("oc,bchw->bohw", w.double(), x.double())
+            ys = _fwd_only(ops, True, x, w)
+            assert torch.isfinite(ys).all() and _err(ys, want) <= bound, (tiny, _err(ys, want))
+    # the top half-ulp of the fp32 range
+    x = base_x.clone()
+    x[0, 3, 2, 5] = 3.0e38
+    w = base_w * 1e-38
+    ys, ye = _fwd_only(ops, True, x, w), _fwd_only(ops, False, x, w)
+    assert torch.isfinite(ys).all() and torch.isfinite(ye).all()
+    x[0, 3, 2, 5] = 3.4e38              # rounds to +inf as a bf16 leading term
+    ys, ye = _fwd_only(ops, True, x, w), _fwd_only(ops, False, x, w)
+    assert torch.isfinite(ye).all() and not torch.isfinite(ys[0, :, 2, 5]).any()
+    # Inf and NaN operands: same set of non-finite outputs in both arithmetics
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        x = base_x.clone()
+        x[0, 7, 1, 4] = bad
+        ys, ye = _fwd_only(ops, True, x, base_w), _fwd_only(ops, False, x, base_w)
+        assert torch.equal(torch.isfinite(ys), torch.isfinite(ye)), bad
+        assert not torch.isfinite(ys[0, :, 1, 4]).any()
+        keep = torch.isfinite(ys)
+        assert float((ys[keep].double() - ref[keep]).abs().max() / ref.abs().max()) <= 2e-6
+        w = base_w.clone()
+        w[5, 9] = bad
+        ys, ye = _fwd_only(ops, True, base_x, w), _fwd_only(ops, False, base_x, w)
+        assert torch.equal(torch.isfinite(ys), torch.isfinite(ye)), bad
+        assert not torch.isfinite(ys[0, 5]).any() and torch.isfinite(ys[0, :5]).all()

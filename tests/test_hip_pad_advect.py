@@ -132,3 +132,22 @@ def test_advect_channel_slice_inputs(ops):
     veld = vel.cuda()
     got = ops.sl_advect(f.cuda(), veld[:, :K], veld[:, K:], ops.AdvectGeometry(lg, og), 0.2, "bicubic")
     assert rms_rel(got.cpu(), want) < 1e-5
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_advect_nan_cotangent_propagates(ops, tiled):
+    """A NaN (or Inf) cotangent must give a NaN field gradient, like a float scatter would (the
+    fixed-point scale comes from max |cotangent|; a NaN must not be dropped by the maximum)."""
+    H, W, B, K = 32, 64, 1, 2
+    _, lg, og = make_grid(H, W, False)
+    f, u, v, ct = (seeded(70 + i, B, K, H, W, scale=0.3 if i else 1.0) for i in range(4))
+    for bad in (float("nan"), float("inf")):
+        c = ct.clone()
+        c[0, 1, 7, 9] = bad
+        flags = ops.advect_flags(tiled=True, halo=6) if tiled else 0
+        fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
+        ops.sl_advect(fd, ud, vd, ops.AdvectGeometry(lg, og), 0.2, "bicubic", flags=flags).backward(c.cuda())
+        gf = fd.grad.cpu()
+        assert not bool(torch.isfinite(gf[0, 1]).any()) or bool(torch.isnan(gf[0, 1]).any())
+        assert bool(torch.isnan(gf[0, 1]).any()), "NaN cotangent lost"
+        assert bool(torch.isfinite(gf[0, 0]).all()), "other planes must stay finite"

@@ -8,11 +8,30 @@ import json
 import os
 import sys
 
+import hashlib
+import subprocess
+
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
+
+
+def provenance():
+    """what was profiled: sha256 of the library (bench.py compares it with the build it runs) and the
+    commit, from the environment (the GPU box has no .git) or from git"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "paradis_model_amd", "libparadis_hip.so")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+    commit = os.environ.get("PARADIS_COMMIT")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"],
+                                             stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            commit = None
+    return {"library_sha256": sha, "commit": commit}
 
 
 def short(name):
@@ -55,7 +74,10 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         traffic[k]["launches"] = n
 for k, v in traffic.items():
     v["hbm_bytes_per_launch"] = v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)
+META = provenance()
+traffic["_meta"] = META
 json.dump(traffic, open(os.path.join(DST, f"{TAG}_traffic.json"), "w"), indent=1, sort_keys=True)
+del traffic["_meta"]
 
 # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs) against
 # GRBM_GUI_ACTIVE (summed over the 8 XCDs) x 256 CUs x 4 SIMDs
@@ -78,7 +100,7 @@ if path:
     keep = {k for k, v in mfma.items() if v >= 0.005}
     mfma = {k: round(v, 4) for k, v in mfma.items() if k in keep}
     clock = {k: round(v, 3) for k, v in clock.items() if k in keep}
-    json.dump(mfma, open(os.path.join(DST, f"{TAG}_mfma_busy.json"), "w"), indent=1, sort_keys=True)
+    json.dump(dict(mfma, _meta=META), open(os.path.join(DST, f"{TAG}_mfma_busy.json"), "w"), indent=1, sort_keys=True)
     json.dump(clock, open(os.path.join(DST, f"{TAG}_mfma_clock_ghz.json"), "w"), indent=1, sort_keys=True)
 
 tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
