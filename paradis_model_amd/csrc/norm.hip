@@ -374,13 +374,13 @@ channel_norm_bwd_fused_finish(const float* __restrict__ partial, float* __restri
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int k0 = blockIdx.y * rows_per_chunk, k1 = min(k0 + rows_per_chunk, nblk);
-  float a = 0.f, d = 0.f;
+  double a = 0.0, d = 0.0;   // the long sums run in double: what is left is the rounding of the 32-pixel block sums
   for (int k = k0; k < k1; ++k) {
-    a += partial[(int64_t)k * 2 * C + c];
-    d += partial[(int64_t)k * 2 * C + C + c];
+    a += (double)partial[(int64_t)k * 2 * C + c];
+    d += (double)partial[(int64_t)k * 2 * C + C + c];
   }
-  chunk[(int64_t)blockIdx.y * 2 * C + c] = a;
-  chunk[(int64_t)blockIdx.y * 2 * C + C + c] = d;
+  chunk[(int64_t)blockIdx.y * 2 * C + c] = (float)a;
+  chunk[(int64_t)blockIdx.y * 2 * C + C + c] = (float)d;
 }
 
 __global__ void __launch_bounds__(256)
@@ -388,13 +388,13 @@ channel_norm_bwd_fused_finish2(const float* __restrict__ chunk, float* __restric
                                int C, int chunks) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float a = 0.f, d = 0.f;
+  double a = 0.0, d = 0.0;
   for (int y = 0; y < chunks; ++y) {
-    a += chunk[(int64_t)y * 2 * C + c];
-    d += chunk[(int64_t)y * 2 * C + C + c];
+    a += (double)chunk[(int64_t)y * 2 * C + c];
+    d += (double)chunk[(int64_t)y * 2 * C + C + c];
   }
-  gw[c] = a;
-  gb[c] = d;
+  gw[c] = (float)a;
+  gb[c] = (float)d;
 }
 
 int dw_chunks(int B, int C, int P) {

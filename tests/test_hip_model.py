@@ -58,7 +58,9 @@ def test_reduced_model_vs_reference_golden(variant, fuse_projection, split_gemm,
         if err > worst[1]:
             worst = (n, err)
     print("worst grad", worst)
-    assert worst[1] <= 1e-3, worst
+    # measured 4-6e-5 (variants b, c) and 4.4-5.2e-4 (variant a: one bias of the velocity network, whose
+    # gradient is a sum over the ill-conditioned points next to the poles; same figure in both GEMM arithmetics)
+    assert worst[1] <= (8e-4 if variant == "a" else 1.5e-4), worst
 
 
 def test_two_step_rollout_vs_reference_golden():
@@ -119,13 +121,13 @@ def _oracle_grads(model, spec, x, ct, lg, og, dtype):
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
 
-def _check_grads_by_fp64_protocol(model, g32, g64, factor=8.0, floor=2e-5):
+def _check_grads_by_fp64_protocol(model, g32, g64, factor=6.0, floor=2e-5):
     """the HIP gradient's distance to the fp64 oracle against the CPU fp32 oracle's own
     distance (the velocity path amplifies fp32 coordinate rounding; a few ill-conditioned points
     near the poles decide the maximum of a weight gradient).  Measured on the default model
-    (tools/grad_probe.py): over all 335 parameters the HIP error is 2.6x the CPU-fp32 error in the
-    median and <= 6.6x at worst, in absolute terms ~1e-5 rms (1e-3 in the velocity networks, where the
-    CPU itself has 3e-4).  The factor is the accumulation order: an MFMA accumulator takes the K
+    (tools/grad_probe.py, round 2): over all 335 parameters the HIP error is 2.4x the CPU-fp32 error in the
+    median; the largest ratios (up to 10) belong to gradients whose absolute error is below 2e-5 (the
+    floor), the largest ratio among the others is 5 (velocity networks: 3.6e-4 where the CPU has 7e-5).  The factor is the accumulation order: an MFMA accumulator takes the K
     products of a dot product one after the other (512 updates for K = 1024), the CPU's vector units
     keep 16 partial sums per accumulator - sqrt(512/64) = 2.8."""
     worst = ("", 0.0, 0.0)
