@@ -617,6 +617,166 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
   }
 }
 
+
+// Tile geometry shared by the two row-wave tiled kernels: waves 2r and 2r+1 own the two 64-column halves
+// of tile rows r, r + NW/2, ...; lanes beyond a ragged tile edge load clamped addresses and store nothing.
+struct TileRowLane {
+  int rs, rstep;        // first tile row of this wave, row step
+  int cbase;            // image column of lane 0 (clamped inside the plane)
+  unsigned lx;          // lane offset (clamped inside the tile)
+  bool active;
+  __device__ __forceinline__ TileRowLane(int wave, int nwaves, unsigned lane, int tx0, int tw, int W) {
+    const int ch = wave & 1;
+    rs = wave >> 1; rstep = nwaves >> 1;
+    const int first = ch * 64;
+    active = first + (int)lane < tw;
+    cbase = min(tx0 + first, W - 1);
+    const int last = max(tw - 1 - first, 0);
+    lx = min(lane, (unsigned)last);
+  }
+};
+
+// window-relative tap block of a point in float arithmetic (every value an integer below 2^24): returns
+// true when the NT x NT block lies inside the window AND the plane clamp did not move it; `cell` = index
+// of tap (0,0) in the window
+template <int MODE>
+__device__ __forceinline__ bool tap_block_window(float ix, float iy, float Hpf, float Wpf, float Wf, float wx0f,
+                                                 float wy0f, float WWf, float WHf, float& tx, float& ty, int& cell) {
+  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
+  tx = __builtin_amdgcn_fractf(ix);
+  ty = __builtin_amdgcn_fractf(iy);
+  const float x0f = ix - tx, y0f = iy - ty;
+  const float xc = __builtin_amdgcn_fmed3f(x0f, (float)(-OFF0), Wpf - (float)(NT + OFF0));
+  const float yc = __builtin_amdgcn_fmed3f(y0f, (float)(-OFF0), Hpf - (float)(NT + OFF0));
+  float rx = (xc + (float)OFF0) - wx0f;
+  const float ry = (yc + (float)OFF0) - wy0f;
+  rx = rx < 0.f ? rx + Wf : (rx > WWf - (float)NT ? rx - Wf : rx);   // the window may straddle the date line
+  const float rxc = __builtin_amdgcn_fmed3f(rx, 0.f, WWf - (float)NT);
+  const float ryc = __builtin_amdgcn_fmed3f(ry, 0.f, WHf - (float)NT);
+  cell = (int)fmaf(ryc, WWf, rxc);
+  return xc == x0f && yc == y0f && rxc == rx && ryc == ry;
+}
+
+// Tiled schedule on a separable grid, one wave per 64 columns of a tile row (scalar sin/cos(lat) loads,
+// per-lane longitude, scalar row pointers, float tap blocks): same arithmetic as the row64 kernel, the
+// window and the L2 fallback of the generic tiled kernel.
+template <int MODE>
+__global__ void __launch_bounds__(TILED_THREADS_FWD)
+sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__ u,
+                      const float* __restrict__ v, float* __restrict__ out,
+                      const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                      const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
+                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = Interp<MODE>::NT, NTH = TILED_THREADS_FWD;
+  const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x / tiles, tile = blockIdx.x - plane * tiles;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
+  const int ty0 = (tile / tiles_x) * TILE_HF, tx0 = (tile % tiles_x) * TILE_W;
+  const int th = min(TILE_HF, H - ty0), tw = min(TILE_W, W - tx0);
+  Window w{ty0 + p - halo, tx0 + p - halo, TILE_HF + 2 * halo + NT, TILE_W + 2 * halo + NT};
+  float* win = smem;
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  const TileRowLane tl(wave, NTH / 64, lane, tx0, tw, W);
+
+  float qu[ADV_PF], qv[ADV_PF];
+#pragma unroll
+  for (int d = 0; d < ADV_PF; ++d) {
+    const int j = (ty0 + min(tl.rs + tl.rstep * d, th - 1)) * W + tl.cbase;
+    qu[d] = srow(U + j)[tl.lx]; qv[d] = srow(V + j)[tl.lx];
+  }
+  const float lonc = lon_cells(srow(lon + tl.cbase)[tl.lx], g);
+  stage_window(win, F, w, H, W, p, true, m0, m1, NTH);
+  __syncthreads();
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp, Wf = (float)W, wx0f = (float)w.wx0, wy0f = (float)w.wy0,
+              WWf = (float)w.WW, WHf = (float)w.WH;
+  // general path of a point: any tap origin, taps from the window or through the index map from L2
+  auto slow_point = [&](float ix, float iy) -> float {
+    float tx, ty, wx[NT], wy[NT];
+    int bx, by, sx, sy;
+    tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
+    Interp<MODE>::weights(tx, wx);
+    Interp<MODE>::weights(ty, wy);
+    shift_weights<NT>(wx, sx);
+    shift_weights<NT>(wy, sy);
+    int ry = by - w.wy0, rx = bx - w.wx0;
+    if (rx < 0) rx += W; else if (rx > w.WW - NT) rx -= W;
+    const bool inwin = ry >= 0 && ry <= w.WH - NT && rx >= 0 && rx <= w.WW - NT;
+    float acc = 0.f;
+    if (inwin) {
+      const float* base = win + ry * w.WW + rx;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        float rowacc = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[a * w.WW + bb], wx[bb], rowacc);
+        acc = fmaf(rowacc, wy[a], acc);
+      }
+    } else {
+      const int lastrow = H - 1;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        float rowacc = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb) {
+          int r, c;
+          geo_src(by + a - p, bx + bb - p, H, W, r, c);
+          float val = F[(int64_t)r * W + c];
+          if (r == 0) val = m0; else if (r == lastrow) val = m1;
+          rowacc = fmaf(val, wx[bb], rowacc);
+        }
+        acc = fmaf(rowacc, wy[a], acc);
+      }
+    }
+    return acc;
+  };
+  for (int yl0 = tl.rs; yl0 < th; yl0 += tl.rstep * ADV_PF) {
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) {
+      const int yl = yl0 + tl.rstep * d;          // wave-uniform
+      const float cu = qu[d], cv = qv[d];
+      {
+        const int j = (ty0 + min(yl + tl.rstep * ADV_PF, th - 1)) * W + tl.cbase;
+        qu[d] = srow(U + j)[tl.lx]; qv[d] = srow(V + j)[tl.lx];
+      }
+      if (yl < th) {
+        const int y = ty0 + yl;
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+        float ix, iy, tx, ty;
+        departure(cu, cv, sa, ca, lonc, g, ix, iy, nullptr);
+        int cell;
+        const bool fast = tap_block_window<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, wy0f, WWf, WHf, tx, ty, cell);
+        float acc;
+        if (fast) {
+          float wx[NT], wy[NT];
+          Interp<MODE>::weights(tx, wx);
+          Interp<MODE>::weights(ty, wy);
+          const float* base = win + cell;
+          acc = 0.f;
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            float rowacc = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[a * w.WW + bb], wx[bb], rowacc);
+            acc = fmaf(rowacc, wy[a], acc);
+          }
+        } else {
+          acc = slow_point(ix, iy);
+        }
+        if (tl.active) srow(O + y * W + tl.cbase)[tl.lx] = acc;
+      }
+    }
+  }
+}
+
 // ======================================================================================
 // backward
 // ======================================================================================
@@ -1014,6 +1174,162 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
   }
 }
 
+
+// Backward of the tiled schedule on a separable grid, one wave per 64 columns of a tile row (see
+// sl_advect_fwd_tilerow); window accumulators, flush and the global-atomic fallback as in the generic
+// tiled kernel below.
+template <int MODE>
+__global__ void __launch_bounds__(TILED_THREADS_BWD, 4)   // two workgroups per CU: <= 128 VGPRs
+sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ field,
+                      const float* __restrict__ u, const float* __restrict__ v,
+                      float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
+                      const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                      const float* __restrict__ lon, const float* __restrict__ fmeans,
+                      const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
+                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = Interp<MODE>::NT, NTH = TILED_THREADS_BWD;
+  const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x / tiles, tile = blockIdx.x - plane * tiles;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* GO = gout + (int64_t)b * go_bs + (int64_t)k * P;
+  float* GF = gfield + (int64_t)b * gf_bs + (int64_t)k * P;
+  float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
+  float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
+  const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+  const int th = min(TILE_H, H - ty0), tw = min(TILE_W, W - tx0);
+  Window w{ty0 + p - halo, tx0 + p - halo, TILE_H + 2 * halo + NT, TILE_W + 2 * halo + NT};
+  const int wn = w.WH * w.WW, wn2 = (wn + 1) & ~1;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);  // [wn] fixed-point sums
+  float* win = smem + 2 * wn2;                                             // [wn]  F~ window
+  float* misc = win + wn2;
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
+  const TileRowLane tl(wave, NTH / 64, lane, tx0, tw, W);
+
+  float qu[ADV_PF], qv[ADV_PF], qg[ADV_PF];
+#pragma unroll
+  for (int d = 0; d < ADV_PF; ++d) {
+    const int j = (ty0 + min(tl.rs + tl.rstep * d, th - 1)) * W + tl.cbase;
+    qu[d] = srow(U + j)[tl.lx]; qv[d] = srow(V + j)[tl.lx]; qg[d] = srow(GO + j)[tl.lx];
+  }
+  const float lonc = lon_cells(srow(lon + tl.cbase)[tl.lx], g);
+  stage_window(win, F, w, H, W, p, true, m0, m1, NTH);
+  for (int i = tid; i < wn; i += NTH) acc[i] = 0ull;
+  unsigned gmaxb = max(abs_bits(gm0), abs_bits(gm1));
+  for (int yl = tl.rs; yl < th; yl += tl.rstep)
+    gmaxb = max(gmaxb, abs_bits(srow(GO + (ty0 + yl) * W + tl.cbase)[tl.lx]));
+  const float mxall = reduce_gmax(gmaxb, misc, NTH / 64);    // its barrier also closes the staging
+  float scale, inv_scale;
+  fixed_point_scale(mxall, scale, inv_scale);
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp, Wf = (float)W, wx0f = (float)w.wx0, wy0f = (float)w.wy0,
+              WWf = (float)w.WW, WHf = (float)w.WH;
+  // general path of a point: any tap origin; taps against the window or, outside it, against global
+  // memory through the index map (float atomics on the field gradient)
+  auto slow_point = [&](float ix, float iy, float gval, float& gix, float& giy) {
+    float tx, ty, wx[NT], wy[NT], dwx[NT], dwy[NT];
+    int bx, by, sx, sy;
+    tap_origin<MODE>(ix, iy, Hp, Wp, bx, by, sx, sy, tx, ty);
+    Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+    Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+    shift_weights<NT>(wx, sx); shift_weights<NT>(dwx, sx);
+    shift_weights<NT>(wy, sy); shift_weights<NT>(dwy, sy);
+    int ry = by - w.wy0, rx = bx - w.wx0;
+    if (rx < 0) rx += W; else if (rx > w.WW - NT) rx -= W;
+    const bool inwin = ry >= 0 && ry <= w.WH - NT && rx >= 0 && rx <= w.WW - NT;
+    if (inwin) {
+      scatter_gather<MODE>(acc, win, ry * w.WW + rx, w.WW, wx, wy, dwx, dwy, gval * scale, gix, giy);
+      return;
+    }
+    gix = 0.f; giy = 0.f;
+    const int lastrow = H - 1;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      float sxv = 0.f, sdx = 0.f;
+#pragma unroll
+      for (int bb = 0; bb < NT; ++bb) {
+        int r, c;
+        geo_src(by + a - p, bx + bb - p, H, W, r, c);
+        float val = F[(int64_t)r * W + c];
+        if (r == 0) val = m0; else if (r == lastrow) val = m1;
+        atomicAdd(&GF[(int64_t)r * W + c], gval * wy[a] * wx[bb]);
+        sxv = fmaf(val, wx[bb], sxv);
+        sdx = fmaf(val, dwx[bb], sdx);
+      }
+      gix = fmaf(wy[a], sdx, gix);
+      giy = fmaf(dwy[a], sxv, giy);
+    }
+  };
+  for (int yl0 = tl.rs; yl0 < th; yl0 += tl.rstep * ADV_PF) {
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) {
+      const int yl = yl0 + tl.rstep * d;          // wave-uniform
+      const float cu = qu[d], cv = qv[d], cgo = qg[d];
+      {
+        const int j = (ty0 + min(yl + tl.rstep * ADV_PF, th - 1)) * W + tl.cbase;
+        qu[d] = srow(U + j)[tl.lx]; qv[d] = srow(V + j)[tl.lx]; qg[d] = srow(GO + j)[tl.lx];
+      }
+      if (yl < th) {
+        const int y = ty0 + yl;
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+        float ix, iy, tx, ty;
+        DepState st;
+        departure(cu, cv, sa, ca, lonc, g, ix, iy, &st);
+        int cell;
+        const bool fast = tap_block_window<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, wy0f, WWf, WHf, tx, ty, cell);
+        const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
+        float gix = 0.f, giy = 0.f;
+        if (tl.active) {
+          if (fast) {
+            float wx[NT], wy[NT], dwx[NT], dwy[NT];
+            Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+            Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+            scatter_gather<MODE>(acc, win, cell, w.WW, wx, wy, dwx, dwy, gval * scale, gix, giy);
+          } else {
+            slow_point(ix, iy, gval, gix, giy);
+          }
+          float guv, gvv;
+          departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
+          srow(GU + y * W + tl.cbase)[tl.lx] = guv;
+          srow(GV + y * W + tl.cbase)[tl.lx] = gvv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush the window once: one global float atomic per touched cell instead of 16 per point.  A thread
+  // keeps its window column (longitude wrap and pole shift computed once) and walks down the rows.
+  const double inv = (double)inv_scale;
+  {
+    const int cols = w.WW < NTH ? w.WW : NTH, rpp = NTH / cols;
+    const int r0 = tid / cols, c0 = tid - r0 * cols;
+    if (r0 < rpp) {
+      for (int lc = c0; lc < w.WW; lc += cols) {
+        int jj = (w.wx0 + lc - p) % W;
+        if (jj < 0) jj += W;
+        int jm = jj + (W >> 1);
+        if (jm >= W) jm -= W;
+        for (int lr = r0; lr < w.WH; lr += rpp) {
+          const long long sv = (long long)acc[lr * w.WW + lc];
+          const int r = w.wy0 + lr;
+          if (sv == 0 || r < 0 || r >= Hp) continue;
+          const int ii = r - p;
+          const int sr = ii < 0 ? -ii : (ii >= H ? 2 * (H - 1) - ii : ii);
+          const int sc = (ii < 0 || ii >= H) ? jm : jj;
+          atomicAdd(&GF[(int64_t)sr * W + sc], (float)((double)sv * inv));
+        }
+      }
+    }
+  }
+}
+
 // ---- pole-row helpers of the tiled schedule ---------------------------------------------
 __global__ void __launch_bounds__(256)
 pole_row_means(const float* __restrict__ src, float* __restrict__ means, int planes, int K, int H,
@@ -1164,8 +1480,25 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
         reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
       return 2;
   }
-  ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
-             cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
+  if (flags & PARADIS_ADVECT_SEPARABLE && !(flags & PARADIS_ADVECT_GENERIC)) {
+    static PerDeviceOnce once_row;
+    if (once_row.first()) {
+      if (reserve_lds(&sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>, "sl_advect_fwd: cannot reserve LDS") ||
+          reserve_lds(&sl_advect_fwd_tilerow<PARADIS_INTERP_BILINEAR>, "sl_advect_fwd: cannot reserve LDS"))
+        return 2;
+    }
+    if (mode == PARADIS_INTERP_BICUBIC)
+      hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
+                         dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
+                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
+    else
+      hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
+                         dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
+                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
+  } else {
+    ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
+               cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
+  }
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, out, planes, K, H, W, o_bs);
   PD_CHECK_LAUNCH("sl_advect_fwd(tiled)");
   return 0;
@@ -1221,9 +1554,28 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
         reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS"))
       return 2;
   }
-  ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
-             gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-             f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4);
+  if (flags & PARADIS_ADVECT_SEPARABLE && !(flags & PARADIS_ADVECT_GENERIC)) {
+    static PerDeviceOnce once_row;
+    if (once_row.first()) {
+      if (reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC>, "sl_advect_bwd: cannot reserve LDS") ||
+          reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR>, "sl_advect_bwd: cannot reserve LDS"))
+        return 2;
+    }
+    if (mode == PARADIS_INTERP_BICUBIC)
+      hipLaunchKernelGGL((sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
+                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
+                         (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
+                         tx, tiles);
+    else
+      hipLaunchKernelGGL((sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
+                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
+                         (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
+                         tx, tiles);
+  } else {
+    ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
+               gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
+               f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4);
+  }
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");
   return 0;

@@ -47,7 +47,7 @@ def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6, generic=
     """force_gmem: use the tiled schedule (window + global fallback) regardless of plane size;
     a small halo forces most taps through the fallback path.  generic: the whole-plane kernel with
     per-point table loads instead of the one-wave-per-row kernel of W == 64 grids."""
-    flags = ops.advect_flags(tiled=True, halo=halo) if force_gmem else ops.advect_flags(generic=generic)
+    flags = ops.advect_flags(tiled=force_gmem, halo=halo if force_gmem else None, generic=generic)
     geom = ops.AdvectGeometry(lg, og)
     fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
     y = ops.sl_advect(fd, ud, vd, geom, dt, mode, flags=flags)
@@ -57,7 +57,7 @@ def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6, generic=
 
 
 @pytest.mark.parametrize("force_gmem,halo,generic", [(False, 6, False), (False, 6, True), (True, 6, False),
-                                                     (True, 0, False)])
+                                                     (True, 0, False), (True, 6, True), (True, 0, True)])
 def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic):
     """Tolerance protocol of SURVEY.md 8c(iii): rms-rel vs CPU fp32 <= 1e-5 and error vs the fp64
     golden <= 1.5x the CPU-fp32 golden's own error vs fp64 (+ a small absolute floor)."""
