@@ -4,7 +4,7 @@
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slots; MI355X_MICROARCH.md)
 #   3. --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (matrix-pipe utilisation per kernel)
 # Summaries are then written by tools/summarize_profile.py into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-exact-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/stats -- $CMD > $R/gpurun_out/prof_$TAG.stats.log 2>&1
