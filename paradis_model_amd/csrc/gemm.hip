@@ -70,11 +70,7 @@ __device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_
     if (KC) {
       const int row = row0 + (tid / TPR) + RPP * i, k = k0 + (tid % TPR) * 4;
       const float* p = base + (int64_t)row * ld + k;
-#ifdef GEMM_UNGUARDED
-      if (true) {
-#else
       if (vec_ok && row < rows && k + 3 < K) {
-#endif
         r[i] = *reinterpret_cast<const float4*>(p);
       } else {
         float t[4];
@@ -85,11 +81,7 @@ __device__ __forceinline__ void slab_load(const float* __restrict__ base, int64_
     } else {
       const int k = k0 + (tid >> 5) + 8 * i, row = row0 + (tid & 31) * 4;
       const float* p = base + (int64_t)k * ld + row;
-#ifdef GEMM_UNGUARDED
-      if (true) {
-#else
       if (vec_ok && k < K && row + 3 < rows) {
-#endif
         r[i] = *reinterpret_cast<const float4*>(p);
       } else {
         float t[4];
@@ -312,28 +304,16 @@ pw_gemm_kernel(GemmArgs g) {
   }
   __syncthreads();
 
-  // Diagnostic ablations (tools/gemm_variants.py): GEMM_NO_STAGE, GEMM_NO_BARRIER, GEMM_NO_LDSREAD
   for (int t = 0; t < T; ++t) {
-#ifdef GEMM_NO_STAGE
-    const int cur = 0;
-#else
     const int cur = t & 1;
-#ifndef GEMM_NO_GLOAD
     if (t + 1 < T) fetch(t + 1);
-#endif
-#endif
     const float* As = stageA(cur) + wm * 64 + li + lh * LDA;
     const float* Bs = stageB(cur) + wn * 64 + li + lh * LDB;
     float a0 = As[0], a1 = As[32], b0 = Bs[0], b1 = Bs[32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-#ifdef GEMM_NO_LDSREAD
-      na0 = a0 + 1.0f; na1 = a1; nb0 = b0; nb1 = b1;
-      if (false) {
-#else
       if (kk + 1 < BK / 2) {
-#endif
         na0 = As[(2 * kk + 2) * LDA]; na1 = As[(2 * kk + 2) * LDA + 32];
         nb0 = Bs[(2 * kk + 2) * LDB]; nb1 = Bs[(2 * kk + 2) * LDB + 32];
       }
@@ -343,20 +323,11 @@ pw_gemm_kernel(GemmArgs g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
-#ifndef GEMM_NO_STAGE
     if (t + 1 < T) {
-#ifdef GEMM_NO_LDSSTORE
-#pragma unroll
-      for (int i = 0; i < NV; ++i) { asm volatile("" ::"v"(ra[i].x), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].w)); }
-#else
       slab_store<A_KC, BK>(stageA(cur ^ 1), ra);
       slab_store<B_KC, BK>(stageB(cur ^ 1), rb);
-#endif
     }
-#endif
-#ifndef GEMM_NO_BARRIER
     __syncthreads();
-#endif
   }
 
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
@@ -434,34 +405,21 @@ pw_gemm_dma_kernel(GemmArgs g) {
   for (int t = 0; t < T; ++t) {
     // tile t must have landed; up to S-2 younger tiles (4 DMAs each per wave) stay in flight
     const int pending = min(S - 2, T - 1 - t);
-#ifndef DMA_NO_BARRIER   // diagnostic ablations (tools/gemm_variants.py): DMA_NO_BARRIER / _ISSUE / _LDSREAD / _EPILOGUE
     if (pending >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else if (pending == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     // the stage of tile t-1 is free now (every wave has passed its MFMAs): refill it
-#ifndef DMA_NO_ISSUE
     if (t + S - 1 < T) issue(t + S - 1);
-#endif
     const float* As = lds + (t % S) * (2 * DTILE) + wm * 64 + li + lh * BM;
     const float* Bs = As - wm * 64 + DTILE + wn * 64;
-#ifdef DMA_NO_LDSREAD
-    float a0 = 1.0f + t, a1 = 2.0f, b0 = 3.0f, b1 = 0.5f + lane;
-    (void)As; (void)Bs;
-#else
     float a0 = As[0], a1 = As[32], b0 = Bs[0], b1 = Bs[32];
-#endif
 #pragma unroll
     for (int kk = 0; kk < DBK / 2; ++kk) {
       float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-#ifdef DMA_NO_LDSREAD
-      na0 = a0 + 1.f; na1 = a1; nb0 = b0; nb1 = b1;
-#else
       if (kk + 1 < DBK / 2) {
         na0 = As[(2 * kk + 2) * BM]; na1 = As[(2 * kk + 2) * BM + 32];
         nb0 = Bs[(2 * kk + 2) * BN]; nb1 = Bs[(2 * kk + 2) * BN + 32];
       }
-#endif
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -469,11 +427,7 @@ pw_gemm_dma_kernel(GemmArgs g) {
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
   }
-#ifdef DMA_NO_EPILOGUE
-  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) g.C[0] = 1.f;
-#else
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
-#endif
 }
 
 // ======================================================================================
@@ -675,8 +629,8 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 #define SPLIT_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 // The six partial products of one 32x32 block, smallest first.  (An order in which consecutive MFMAs
 // share an operand register, snaking over the four blocks of a wave tile, measured +0.5 % - nothing -
-// once the A/B alternated the variants; tools/gemm_variants.py: a fixed order of variants shows 3-5 %
-// in favour of whichever runs later.)
+// once the A/B alternated the variants: a fixed order of variants shows 3-5 % in favour of whichever
+// runs later.)
 #define SPLIT_BLOCK(AH, AM, AL, BH, BM_, BL, C) \
   SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AL, BH, C); SPLIT_MFMA(AH, BL, C); \
   SPLIT_MFMA(AM, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C)
@@ -686,13 +640,6 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 struct SplitFrags { u32x4 a[3][2], b[3][2]; };
 template <int PA, int PB>
 __device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs, SplitFrags& f) {
-#ifdef SPLIT_READ_PLANE_ORDER   // diagnostic: plane by plane
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    f.a[s][0] = As[s * PA]; f.a[s][1] = As[s * PA + 32];
-    f.b[s][0] = Bs[s * PB]; f.b[s][1] = Bs[s * PB + 32];
-  }
-#else
   // in the order of first use by split_tile_mfma (block (0,0): m.m, l.h, h.l first), so that the counted
   // lgkmcnt waits let the first MFMAs start after two reads instead of seven
   f.a[1][0] = As[PA];          f.b[1][0] = Bs[PB];
@@ -700,7 +647,6 @@ __device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs
   f.a[0][0] = As[0];           f.b[2][0] = Bs[2 * PB];
   f.b[1][1] = Bs[PB + 32];     f.b[0][1] = Bs[32];          f.b[2][1] = Bs[2 * PB + 32];
   f.a[1][1] = As[PA + 32];     f.a[2][1] = As[2 * PA + 32]; f.a[0][1] = As[32];
-#endif
 }
 // ... then the 24 MFMAs
 __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&acc)[2][2]) {
@@ -811,18 +757,12 @@ pw_gemm_split_kernel(GemmArgs g) {
   // would make every barrier wait for the activation loads that are meant to stay in flight
   if (T > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-  // diagnostic ablations (tools/gemm_variants.py): SPLIT_NO_FETCH / _DMA / _LDSREAD / _STORE / _BARRIER / _EPILOGUE / _INTERLEAVE
   auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
     const u32x4* As = img + (2 + t % SA) * SIMG + lh * SCH + wm * 64 + li;
     const u32x4* Bs = img + cur * SIMG + lh * SCH + wn * 64 + li;
     const bool dmaA = t + DA < T, ldB = t + 2 < T;
-#ifndef SPLIT_NO_DMA
     if (dmaA) issueA(t + DA);
-#endif
-#ifndef SPLIT_NO_FETCH
     if (ldB) fetchB(t + 2, xload);
-#endif
     // xsplit (tile t+1) was loaded a step ago; younger operations: this step's 3 DMA and 8 loads
     if (dmaA && ldB) USE_X(xsplit, 11);
     else if (ldB) USE_X(xsplit, 8);
@@ -831,55 +771,32 @@ pw_gemm_split_kernel(GemmArgs g) {
     // bookkeeping falls back to lgkmcnt(0) in front of the first MFMA; inside one block the waits are
     // counted and the first MFMA starts after two of the twelve reads).
     SplitFrags f;
-#ifdef SPLIT_NO_LDSREAD
-#pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_)
-#pragma unroll
-      for (int i_ = 0; i_ < 2; ++i_) {
-        f.a[s_][i_] = (u32x4){0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u};
-        f.b[s_][i_] = (u32x4){0x3f803f80u, 0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u + (uint32_t)s_};
-      }
-    (void)As; (void)Bs;
-#else
     split_tile_read<2 * SCH, 2 * SCH>(As, Bs, f);
-#endif
     // One basic block for every tile, the last included (its split writes a stage that nobody reads any
     // more): a second copy of the MFMA block behind a branch costs 32 accumulator moves per tile.
     split_tile_mfma(f, acc);
-#ifndef SPLIT_NO_STORE
     {
       u32x4 h, m, l;
       split8(xsplit, h, m, l);
-#ifndef SPLIT_NO_INTERLEAVE   // one MFMA : three VALU of the split.  Isolated 1024^2 launches run 2.8 % faster
       // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
-#ifndef SPLIT_NO_LDSREAD
       __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // all fragment reads first, in first-use order
-#endif
 #pragma unroll
       for (int i = 0; i < 24; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
-#endif
       u32x4* o = Bst + (cur ^ 1) * SIMG;
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
     }
-#endif
-#ifndef SPLIT_NO_BARRIER
     // weight tile t+1 landed (its DMA is DA steps old: 8 loads of that step + 11 operations per step since
     // are younger), own ds_writes done, the loads of t+2 and the younger DMAs still in flight
     if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(8 + 11 * (DA - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
   };
   for (int t = 0; t < T; t += 2) {
     step(t, 0, xb[0], xb[1]);
     if (t + 1 < T) step(t + 1, 1, xb[1], xb[0]);
   }
-#ifdef SPLIT_NO_EPILOGUE
-  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] + xb[0][0] + xb[1][0] == 123.456f) g.C[0] = 1.f;
-  return;
-#endif
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
@@ -978,13 +895,11 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     // one basic block for every tile; the last tile's split is surplus (stage nobody reads, keep = 0)
     split_tile_mfma(f, acc);
     split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
-#ifndef WGRAD_NO_INTERLEAVE
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the two splits
     }
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   for (int t = 0; t < T; t += 2) {
