@@ -269,13 +269,11 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
         else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
       }
       float a = g[i] * xh, d = g[i];       // dead pixels hold zeros
-#ifndef NORM_NO_SHUFFLE
 #pragma unroll
       for (int o = NPB / 2; o > 0; o >>= 1) {
         a += __shfl_xor(a, o, NPB);
         d += __shfl_xor(d, o, NPB);
       }
-#endif
       if (px == 0) { pw[c] = a; pw[C + c] = d; }
     }
   }
