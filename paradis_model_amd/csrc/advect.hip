@@ -16,7 +16,7 @@
 //
 //   * Sample coordinates.  The reference forms  lon_d = remainder(lon_a + atan2(n,d) + 2pi, 2pi),
 //     pix = (lon_d - min)/d_lon (W-1), normalises to [-1,1] and ATen un-normalises again: ten fp32
-//     roundings per axis.  Here  ix = wrap(lon_a cx + atan2(n,d) cx, period) + c0x  and
+//     roundings per axis.  Here  ix = wrap(lon_a cx + c0x + atan2(n,d) cx, [c0x, c0x + period))  and
 //     iy = asin(s) cy + c0y  with cx = (W-1)/d_lon, cy = (H-1)/d_lat, period = 2 pi cx and the offsets
 //     evaluated in double on the host (two FMAs and a floor per axis).  Same mathematical function;
 //     its distance to the fp64 evaluation is HALF the CPU-fp32 reference's own (x: 1.4e-6 vs 3.4e-6
@@ -69,6 +69,8 @@ struct AdvGeom {
   float cx, cy;           // cells per radian: (W-1)/d_lon, (H-1)/d_lat
   float per, inv_per;     // longitude period in cells (2 pi cx) and its reciprocal
   float c0x, c0y;         // p - min_lon cx,  p - min_lat cy
+  float qoff;             // -c0x / period: the wrap is taken on [c0x, c0x + period)
+  double c0xd;            // c0x in double: folded into the longitude table (lon_cells)
   double cxd;             // cx in double: lon -> cells conversion of the longitude table
 };
 
@@ -107,8 +109,21 @@ __device__ __forceinline__ void sincos_reduced(float x, float& s, float& c) {
 // sin/cos of the two rotation angles of a point.  |angle| < 0.78 (< pi/4: the reduction's k is 0 and
 // r = x exactly) for every lane of the wave is the normal case - displacements of less than 45 degrees
 // per step - and needs no reduction and no quadrant selects: same bits, 10 instead of ~35 operations.
+// |r| <= 1/8: the series two terms shorter, same error bounds (sin 0.51 ulp, cos 1.07 ulp)
+__device__ __forceinline__ void sincos_kernel_small(float r, float& ps, float& pc) {
+  const float z = r * r;
+  ps = fmaf(fmaf(8.3333310e-3f, z, -1.6666667e-1f) * z, r, r);
+  pc = fmaf(4.1666668e-2f * z, z, fmaf(-0.5f, z, 1.0f));
+}
+
 __device__ __forceinline__ void sincos_pair(float phi, float lam, float& sp, float& cp, float& sl, float& cl) {
-  if (__all(fmaxf(fabsf(phi), fabsf(lam)) < 0.78f)) {
+  const float big = fmaxf(fabsf(phi), fabsf(lam));
+  if (__all(big < 0.125f)) {     // displacements below 7 degrees per step: the usual case
+    sincos_kernel_small(phi, sp, cp);
+    sincos_kernel_small(lam, sl, cl);
+    return;
+  }
+  if (__all(big < 0.78f)) {
     sincos_kernel(phi, sp, cp);
     sincos_kernel(lam, sl, cl);
     return;
@@ -191,10 +206,9 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
   const float n = cp * sl;
   const float d = fmaf(cc, ca, -(sp * sa));
   const float a = atan2_wave(n, d);
-  const float t = fmaf(a, g.cx, lonc);                 // unwrapped departure longitude in cells
-  const float q = floorf(t * g.inv_per);
-  const float m = fmaf(-q, g.per, t);                  // in [0, period) up to one rounding
-  ix = m + g.c0x;
+  const float t = fmaf(a, g.cx, lonc);                 // unwrapped departure longitude in padded cells
+  const float q = floorf(fmaf(t, g.inv_per, g.qoff));
+  ix = fmaf(-q, g.per, t);                             // in [c0x, c0x + period) up to one rounding
   iy = fmaf(lat_d, g.cy, g.c0y);
   if (st) {
     st->sp = sp; st->cp = cp; st->sl = sl; st->cl = cl; st->s = s; st->n = n; st->d = d;
@@ -205,14 +219,17 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
 // becomes a global access with a scalar base and a 32-bit vector offset (no 64-bit vector address
 // arithmetic per load: 7 half-rate VALU operations per access in the first version of these loops).
 template <typename T>
-__device__ __forceinline__ T* srow(T* p) {
+using global_ptr = __attribute__((address_space(1))) T*;   // explicit: an integer-built pointer would be `flat`
+template <typename T>
+__device__ __forceinline__ global_ptr<T> srow(T* p) {
   const uint64_t a = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  return (T*)(((uint64_t)hi << 32) | lo);
+  return (global_ptr<T>)(((uint64_t)hi << 32) | lo);
 }
 
-__device__ __forceinline__ float lon_cells(float lon, const AdvGeom& g) { return (float)((double)lon * g.cxd); }
+// arrival longitude in padded cells: lon cx + c0x, one rounding
+__device__ __forceinline__ float lon_cells(float lon, const AdvGeom& g) { return (float)fma((double)lon, g.cxd, g.c0xd); }
 
 // ---- interpolation weights -------------------------------------------------------------------
 // (the weights and tap sums are not coordinate-critical - an ulp of a weight is 1e-7 relative in the
@@ -416,64 +433,189 @@ __device__ __forceinline__ float sample_whole(const float* win, float ix, float 
   return acc;
 }
 
-// W == 64, separable grid: one workgroup (4 waves) per plane, wave w owns rows w, w+4, ...
+// Value of one arrival point from a whole-plane window that is XR = 1 column wider than the padded plane
+// (column Wp repeats the wrap): for finite inputs the tap block then always lies inside the window -
+// ix is in [p - eps, W + p + eps], iy within half a cell of the grid's latitude range - so the forward
+// needs neither clamps nor the edge path.  A non-finite coordinate makes every weight NaN and a garbage
+// index, and LDS reads beyond the allocation return 0: the result is NaN, as it should be.
+constexpr int ROW64_XR = 1;
+// velocities and output are touched once per launch: non-temporal
+#define ADV_LD(p) __builtin_nontemporal_load(p)
+#define ADV_ST(v, p) __builtin_nontemporal_store(v, p)
 template <int MODE>
+__device__ __forceinline__ float sample_wide(const float* win, float ix, float iy, int WS, float WSf) {
+  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
+  const float tx = __builtin_amdgcn_fractf(ix), ty = __builtin_amdgcn_fractf(iy);
+  float wx[NT], wy[NT];
+  Interp<MODE>::weights(tx, wx);
+  Interp<MODE>::weights(ty, wy);
+  const int cell = (int)fmaf(iy - ty, WSf, ix - tx);
+  const float* base = win + OFF0 * (WS + 1) + cell;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    float rowacc = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[a * WS + bb], wx[bb], rowacc);
+    acc = fmaf(rowacc, wy[a], acc);
+  }
+  return acc;
+}
+
+// W == 64, separable grid: a workgroup (4 waves) walks ROW64_CHUNK consecutive planes, wave w owns rows
+// w, w+4, ... of each.  The planes are software pipelined through two LDS windows:
+//   - the interior of plane n+1 goes global -> LDS by DMA (one 256-byte row per global_load_lds_dword)
+//     while plane n is computed: no staging registers, no staging latency on the critical path;
+//   - halo columns and the mirrored rows beyond the poles are copies of interior cells, filled LDS -> LDS;
+//   - the velocity prefetch runs ADV_PF rows ahead ACROSS plane boundaries.
+// XR = ROW64_XR: global grid (the host checked the coordinate range), wide window, unclamped taps;
+// XR = 0: any other grid, taps outside the padded plane count as zero like ATen's grid_sample.
+constexpr int ROW64_CHUNK = 4;   // 1 and 12 (one workgroup per resident slot) measured 3-6 % slower
+typedef __attribute__((address_space(3))) void* adv_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* adv_gbl_ptr_t;
+
+// velocity prefetch cursor of a wave: ADV_PF rows ahead of the row being computed, across plane boundaries.
+// Element offsets, not pointers: the loads must stay `global` with a scalar base (srow).
+struct VelCursor {
+  int64_t off, uv_bs;      // offset of the cursor's plane in u and in v
+  int plane, last, b, k, K, y, wave, H, P;
+  int yend;                // wave + 4 * (row slots per plane): ceil(H / 4) rounded up to a multiple of 2 ADV_PF
+  __device__ __forceinline__ void load(const float* __restrict__ u, const float* __restrict__ v, unsigned lane,
+                                       float& a, float& c) {
+    const int64_t j = off + min(y, H - 1) * 64;
+    a = ADV_LD(&srow(u + j)[lane]);
+    c = ADV_LD(&srow(v + j)[lane]);
+    y += 4;
+    if (y >= yend && plane + 1 < last) {   // (past the last plane: keeps reloading its last row)
+      ++plane; y = wave;
+      if (++k == K) { k = 0; ++b; }
+      off = (int64_t)b * uv_bs + (int64_t)k * P;
+    }
+  }
+};
+
+// One 256-byte row global -> LDS by DMA (M0 = LDS row start, lane -> +4 bytes), both addresses wave-uniform.
+// Inline assembly on purpose: with the builtin the compiler's wait-count pass treats the vector memory
+// counter as unordered while a DMA is pending and turns every wait for a prefetched velocity into vmcnt(0).
+// Hidden from it, its counted waits only become stricter (they count fewer newer operations than there are).
+__device__ __forceinline__ void dma_row_to_lds(const float* grow, unsigned lane_bytes, float* lds_row) {
+  const uint64_t a = (uint64_t)grow;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const uint64_t base = ((uint64_t)hi << 32) | lo;
+  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(adv_lds_ptr_t)lds_row);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+               :: "s"(m), "v"(lane_bytes), "s"(base) : "memory");   // (M0 is reserved: the compiler keeps nothing in it across statements)
+}
+
+// One plane of the pipeline.  The interior of the NEXT plane goes global -> LDS by DMA, one row per row
+// iteration, while this plane is computed.  That the DMA INTO cur - issued one plane earlier - has landed
+// is the caller's counted wait.
+template <int MODE, int XR>
+__device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __restrict__ nxt,
+                                            const float* __restrict__ field, int64_t next_off, bool has_next,
+                                            float* __restrict__ O, const float* __restrict__ u,
+                                            const float* __restrict__ v, VelCursor& vc, float (&qu)[ADV_PF],
+                                            float (&qv)[ADV_PF], const float* __restrict__ sin_lat,
+                                            const float* __restrict__ cos_lat, float lonc, const AdvGeom& g,
+                                            int wave, unsigned lane, bool fill_halo) {
+  constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;
+  const int H = g.H, Hp = H + 2 * p, tid = threadIdx.x;
+  // halo columns (p left, p + XR right) and the p mirrored rows beyond each pole are copies of interior
+  // cells; the two pole rows are written whole by pole_rows_to_mean_lds
+  if (fill_halo) {
+    constexpr int hc = 2 * p + XR;
+    const int nrow_cells = 2 * p * WS, nhalo = nrow_cells + H * hc;
+    for (int q = tid; q < nhalo; q += 256) {
+      int lr, lc;
+      if (q < nrow_cells) {
+        const int rr = q / WS;
+        lc = q - rr * WS;
+        lr = rr < p ? rr : H + rr;
+      } else {
+        const int e = q - nrow_cells, rr = e / hc, cc = e - rr * hc;
+        lr = rr + p;
+        lc = cc < p ? cc : W + cc;
+      }
+      if (lr == p || lr == H - 1 + p) continue;
+      int sr, sc;
+      geo_src(lr - p, lc - p, H, W, sr, sc);
+      cur[lr * WS + lc] = cur[(sr + p) * WS + sc + p];
+    }
+  }
+  pole_rows_to_mean_lds(cur, H, W, p, WS);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt: loads stay in flight)
+  const float Hpf = (float)Hp, WSf = (float)WS;
+  // one row: consume the velocities in (cu, cv), refill the slot (nu, nv) from the cursor
+  auto do_row = [&](int y, float cu, float cv, float& nu, float& nv) {
+    if (has_next && y < H) dma_row_to_lds(field + next_off + y * W, 4 * lane, nxt + (y + p) * WS + p);
+    vc.load(u, v, lane, nu, nv);
+    if (y < H) {
+      const float sa = sin_lat[y * W], ca = cos_lat[y * W];   // uniform address: scalar loads
+      float ix, iy;
+      departure(cu, cv, sa, ca, lonc, g, ix, iy, nullptr);
+      float acc = XR ? sample_wide<MODE>(cur, ix, iy, WS, WSf) : sample_whole<MODE>(cur, ix, iy, Hp, WS, Hpf, WSf);
+      if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
+      ADV_ST(acc, &srow(O + y * W)[lane]);
+    }
+  };
+  // Two register sets that swap roles (qu/qv -> ru/rv -> qu/qv): a load never targets a register whose old
+  // value is still needed, so there is no copy of a just-loaded register - and no vmcnt(0) - at the back edge.
+  float ru[ADV_PF], rv[ADV_PF];
+  for (int y0 = wave; y0 < vc.yend; y0 += 8 * ADV_PF) {   // the cursor's slot count: the same for every wave
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) do_row(y0 + 4 * d, qu[d], qv[d], ru[d], rv[d]);
+#pragma unroll
+    for (int d = 0; d < ADV_PF; ++d) do_row(y0 + 4 * (ADV_PF + d), ru[d], rv[d], qu[d], qv[d]);
+  }
+}
+
+template <int MODE, int XR>
 __global__ void __launch_bounds__(256)
 sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u,
                     const float* __restrict__ v, float* __restrict__ out,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lon, int K, AdvGeom g, int64_t f_bs, int64_t uv_bs,
-                    int64_t o_bs, int vec4) {
+                    int64_t o_bs, int planes, int chunk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int W = 64;
-  const int H = g.H, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;   // WS: window row stride
+  const int H = g.H, P = H * W, Hp = H + 2 * p;
   const int tid = threadIdx.x;
   const unsigned lane = tid & 63;   // unsigned: row pointer (scalar) + 32-bit lane offset addressing
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int plane = blockIdx.x;
-  const int b = plane / K, k = plane - b * K;
-  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
-  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
-  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
-  float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
-  float* win = smem;
+  const int first = blockIdx.x * chunk, last = min(first + chunk, planes);
+  int b = first / K, k = first - b * K;
 
-  // operands of the first rows are in flight while the window is staged
+  VelCursor vc;
+  vc.uv_bs = uv_bs; vc.plane = first; vc.last = last; vc.b = b; vc.k = k; vc.K = K;
+  vc.y = wave; vc.wave = wave; vc.H = H; vc.P = P;
+  vc.yend = wave + 4 * (((H + 3) / 4 + 2 * ADV_PF - 1) / (2 * ADV_PF) * (2 * ADV_PF));
+  vc.off = (int64_t)b * uv_bs + (int64_t)k * P;
   float qu[ADV_PF], qv[ADV_PF];
 #pragma unroll
-  for (int d = 0; d < ADV_PF; ++d) {
-    const int j = min(wave + 4 * d, H - 1) * W;
-    qu[d] = srow(U + j)[lane]; qv[d] = srow(V + j)[lane];
-  }
+  for (int d = 0; d < ADV_PF; ++d) vc.load(u, v, lane, qu[d], qv[d]);
   const float lonc = lon_cells(lon[lane], g);
-  if (vec4) stage_plane_vec4(win, F, H, W, p);
-  else {
-    Window w{0, 0, Hp, Wp};
-    stage_window(win, F, w, H, W, p, false, 0.f, 0.f, 256);
+  float* cur = smem;
+  float* nxt = smem + Hp * WS;
+  {   // the first plane of the chunk is staged through registers, halo included
+    Window w{0, 0, Hp, WS};
+    stage_window(cur, field + (int64_t)b * f_bs + (int64_t)k * P, w, H, W, p, false, 0.f, 0.f, 256);
   }
-  __syncthreads();
-  pole_rows_to_mean_lds(win, H, W, p, Wp);
-  __syncthreads();
-
-  const float Hpf = (float)Hp, Wpf = (float)Wp;
-  for (int y0 = wave; y0 < H; y0 += 4 * ADV_PF) {
-#pragma unroll
-    for (int d = 0; d < ADV_PF; ++d) {
-      const int y = y0 + 4 * d;                 // wave-uniform
-      const float cu = qu[d], cv = qv[d];
-      {
-        const int j = min(y + 4 * ADV_PF, H - 1) * W;
-        qu[d] = srow(U + j)[lane]; qv[d] = srow(V + j)[lane];
-      }
-      if (y < H) {
-        const float sa = sin_lat[y * W], ca = cos_lat[y * W];   // uniform address: scalar loads
-        float ix, iy;
-        departure(cu, cv, sa, ca, lonc, g, ix, iy, nullptr);
-        float acc = sample_whole<MODE>(win, ix, iy, Hp, Wp, Hpf, Wpf);
-        if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
-        srow(O + y * W)[lane] = acc;
-      }
-    }
+  for (int plane = first; plane < last; ++plane) {
+    // `cur` has landed and every wave is done reading `nxt`.  A wave issues its last DMA at the top of its
+    // last row; two loads and one store (at least) follow.  Loads complete in issue order, so with at most
+    // 2 operations outstanding the DMA - older than both loads - is in LDS whatever the store did; the
+    // barrier covers the other waves' rows.
+    if (plane != first) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int nb = b, nk = k + 1;
+    if (nk == K) { nk = 0; ++nb; }
+    const bool has_next = plane + 1 < last;
+    const int64_t next_off = has_next ? (int64_t)nb * f_bs + (int64_t)nk * P : 0;
+    row64_plane<MODE, XR>(cur, nxt, field, next_off, has_next, out + (int64_t)b * o_bs + (int64_t)k * P, u, v, vc,
+                          qu, qv, sin_lat, cos_lat, lonc, g, wave, lane, plane != first);
+    float* t = cur; cur = nxt; nxt = t;
+    b = nb; k = nk;
   }
 }
 
@@ -1373,7 +1515,9 @@ AdvGeom make_geom(int H, int W, int p, float dt, float min_lat, float min_lon, f
   const double per = 6.283185307179586476925286766559 * cx;
   g.cx = (float)cx; g.cy = (float)cy; g.cxd = cx;
   g.per = (float)per; g.inv_per = (float)(1.0 / per);
-  g.c0x = (float)((double)p - (double)min_lon * cx);
+  g.c0xd = (double)p - (double)min_lon * cx;
+  g.c0x = (float)g.c0xd;
+  g.qoff = (float)(-g.c0xd / per);
   g.c0y = (float)((double)p - (double)min_lat * cy);
   return g;
 }
@@ -1407,6 +1551,16 @@ int halo_of(int flags, int dflt, bool backward) {
   const int hb = (flags >> PARADIS_ADVECT_HALO_BWD_SHIFT) & 0xff;
   if (backward && hb) h = hb;
   return h == 0 ? dflt : std::min(h - 1, MAX_HALO);
+}
+// Does every tap block of a finite departure point lie inside a whole-plane window with `xr` extra
+// columns?  ix = [0, period] + c0x, iy = [-pi/2, pi/2] cy + c0y, each with a margin for rounding; true for
+// the global grids of the reference (period = W cells, latitudes from pole to pole).
+bool taps_stay_inside(const AdvGeom& g, int NT, int xr) {
+  const int off0 = NT == 4 ? -1 : 0;
+  const double eps = 1e-2, hpi = 1.5707963267948966;
+  const double x_lo = std::floor((double)g.c0x - eps) + off0, x_hi = std::floor((double)g.per + g.c0x + eps) + off0 + NT - 1;
+  const double y_lo = std::floor(-hpi * g.cy + g.c0y - eps) + off0, y_hi = std::floor(hpi * g.cy + g.c0y + eps) + off0 + NT - 1;
+  return x_lo >= 0 && x_hi <= g.W + 2 * g.p + xr - 1 && y_lo >= 0 && y_hi <= g.H + 2 * g.p - 1;
 }
 // one wave per latitude row with scalar table loads: W == 64 and a grid whose latitude depends on the
 // row only and whose longitude depends on the column only (the caller vouches for it through `flags`)
@@ -1456,10 +1610,25 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   // 16-byte staging path: aligned planes, p even (bicubic), padded width even
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && a16(field) && (p % 2 == 0);
   if (!use_tiled(whole, flags)) {
-    if (use_row64(W, flags))
-      ADV_LAUNCH_ROW64(sl_advect_fwd_row64, planes, whole, field, u, v, out, sin_lat, cos_lat, lon, K, g, f_bs,
-                       uv_bs, o_bs, vec4);
-    else
+    if (use_row64(W, flags)) {
+      const bool wide = taps_stay_inside(g, NT, ROW64_XR);
+      const size_t lds = 2 * (size_t)(H + 2 * p) * (W + 2 * p + (wide ? ROW64_XR : 0)) * sizeof(float);
+      static PerDeviceOnce once64;
+      if (once64.first()) {
+        if (reserve_lds(&sl_advect_fwd_row64<PARADIS_INTERP_BICUBIC, ROW64_XR>, "sl_advect_fwd: cannot reserve LDS") ||
+            reserve_lds(&sl_advect_fwd_row64<PARADIS_INTERP_BICUBIC, 0>, "sl_advect_fwd: cannot reserve LDS") ||
+            reserve_lds(&sl_advect_fwd_row64<PARADIS_INTERP_BILINEAR, ROW64_XR>, "sl_advect_fwd: cannot reserve LDS") ||
+            reserve_lds(&sl_advect_fwd_row64<PARADIS_INTERP_BILINEAR, 0>, "sl_advect_fwd: cannot reserve LDS"))
+          return 2;
+      }
+      const int chunk = ROW64_CHUNK, groups = (planes + chunk - 1) / chunk;
+#define ROW64_FWD(MODE_, XR_)                                                                              \
+      hipLaunchKernelGGL((sl_advect_fwd_row64<MODE_, XR_>), dim3(groups), dim3(256), lds, st, field, u, v, out, \
+                         sin_lat, cos_lat, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk)
+      if (mode == PARADIS_INTERP_BICUBIC) { if (wide) ROW64_FWD(PARADIS_INTERP_BICUBIC, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BICUBIC, 0); }
+      else { if (wide) ROW64_FWD(PARADIS_INTERP_BILINEAR, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BILINEAR, 0); }
+#undef ROW64_FWD
+    } else
       ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
                  (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_fwd");

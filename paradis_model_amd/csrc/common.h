@@ -107,14 +107,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Whole geocyclic-padded plane [(H+2p) x (W+2p)] into LDS, 16-byte path: the H x W interior is a plain copy (one float4
-// load + two 8-byte LDS writes per four cells); only the 2p halo columns and 2p mirrored rows go
-// through the index map.  ~4 loads and ~60 VALU instructions per thread instead of 10 and ~300.
-// Needs W % 4 == 0 and a 16-byte aligned plane.
-__device__ __forceinline__ void stage_plane_vec4(float* win, const float* __restrict__ F, int H, int W, int p) {
-  const int Wp = W + 2 * p, Hp = H + 2 * p, tid = threadIdx.x;
+// Whole geocyclic-padded plane [(H+2p) x (W+2p+xr)] into LDS, 16-byte path: the H x W interior is a plain copy (one float4
+// load + two 8-byte LDS writes per four cells); only the halo columns (p on the left, p + xr on the right) and the 2p
+// mirrored rows go through the index map.  ~4 loads and ~60 VALU instructions per thread instead of 10 and ~300.
+// Needs W % 4 == 0, a 16-byte aligned plane, p and xr even (8-byte aligned LDS rows).
+__device__ __forceinline__ void stage_plane_vec4(float* win, const float* __restrict__ F, int H, int W, int p, int xr = 0) {
+  const int Wp = W + 2 * p + xr, Hp = H + 2 * p, tid = threadIdx.x;
   const int w4 = W >> 2, nvec = H * w4;
-  const int nhalo_rows = 2 * p * Wp, nhalo = nhalo_rows + H * 2 * p;
+  const int hc = 2 * p + xr;
+  const int nhalo_rows = 2 * p * Wp, nhalo = nhalo_rows + H * hc;
   constexpr int VB = 2, HB = 2;
   const float4* F4 = reinterpret_cast<const float4*>(F);
   for (int v0 = tid, k0 = tid; v0 < nvec || k0 < nhalo; v0 += 256 * VB, k0 += 256 * HB) {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void stage_plane_vec4(float* win, const float* __rest
         lc = k - rr * Wp;
         lr = rr < p ? rr : Hp - 2 * p + rr;
       } else {                       // left / right halo columns of the interior rows
-        const int e = k - nhalo_rows, rr = e / (2 * p), cc = e - rr * 2 * p;
+        const int e = k - nhalo_rows, rr = e / hc, cc = e - rr * hc;
         lr = rr + p;
         lc = cc < p ? cc : W + cc;
       }
@@ -146,7 +147,7 @@ __device__ __forceinline__ void stage_plane_vec4(float* win, const float* __rest
       const int v = v0 + 256 * j;
       if (v < nvec) {
         const int y = v / w4, x4 = v - y * w4;
-        float2* d = reinterpret_cast<float2*>(win + (y + p) * Wp + p + 4 * x4);   // 8-byte aligned (p even, Wp even)
+        float2* d = reinterpret_cast<float2*>(win + (y + p) * Wp + p + 4 * x4);   // 8-byte aligned (p, Wp even)
         d[0] = make_float2(q[j].x, q[j].y);
         d[1] = make_float2(q[j].z, q[j].w);
       }

@@ -1,0 +1,16 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from paradis_model_amd import ops
+from paradis_model_amd.harness import make_grids
+B, K, H, W = 32, 768, 32, 64
+_, lg, og = make_grids(H, W, False)
+geom = ops.AdvectGeometry(lg, og)
+f = torch.randn(B, K, H, W, device="cuda")
+vel = torch.randn(B, 2 * K, H, W, device="cuda") * float(sys.argv[1] if len(sys.argv) > 1 else 0.05)
+x = torch.randn(64 << 20, device="cuda")
+for _ in range(3000):
+    x = x * 1.0001
+with torch.no_grad():
+    for _ in range(200):
+        ops.sl_advect_vel(f, vel, geom, 0.196887 / 8, "bicubic")
+torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: the advection gather kernels in isolation against their algorithmic bytes
 (16 B/point forward, 28 B/point backward) at the BASELINE shapes.
-    python tools/advect_bench.py [vel_scale ...]      (default scales 0.05 0.5)"""
+    python tools/advect_bench.py [vel_scale ...]      (default scales 0.05 0.5; ADVECT_BENCH_ONLY=32x64 for one shape)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,6 +28,8 @@ def main():
     for _ in range(3000):     # ~2 s of warm-up: measurements taken cold read 20-30 % slow
         x = x * 1.0001
     for (B, K, H, W, poles) in ((32, 768, 32, 64, False), (8, 768, 128, 256, False), (1, 768, 721, 1440, True)):
+        if os.environ.get("ADVECT_BENCH_ONLY", f"{H}x{W}") != f"{H}x{W}":
+            continue
         _, lg, og = make_grids(H, W, poles)
         geom = ops.AdvectGeometry(lg, og)
         pts = B * K * H * W
