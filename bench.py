@@ -7,8 +7,8 @@ ERA5-shaped batch of 32 samples per GPU (configs[1]: 32x64 grid, default 60 M-pa
 fp32).  N>1: one process per GPU (torchrun), batch-sharded DDP over RCCL, weak scaling.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the pointwise GEMMs: fp32 in /
-fp32 accumulate / fp32 out, by default as exact 3-way bf16 splits on the bf16 matrix pipe, with
---gemm exact on the f32 MFMA; timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the
+fp32 accumulate / fp32 out, by default as two f16 terms of the per-tensor scaled operands on the f16
+matrix pipe (--gemm bf16x3: exact 3-way bf16 splits; --gemm exact: f32 MFMA); timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the
 reference path, timed on the host cores on a bounded sample).
 """
 import argparse
@@ -178,8 +178,11 @@ def main():
     ap.add_argument("--checkpoint", action="store_true", help="per-layer activation checkpointing")
     ap.add_argument("--optimizer", default="adamw", choices=["adamw", "muon", "normuon"],
                     help="adamw = the measured configuration (SURVEY 8d); normuon = the reference's shipped default")
-    ap.add_argument("--gemm", default=os.environ.get("PARADIS_GEMM", "split"), choices=["split", "exact"],
-                    help="pointwise GEMM arithmetic: exact 3-way bf16 split on the bf16 MFMA (default) or f32 MFMA")
+    ap.add_argument("--gemm", default=os.environ.get("PARADIS_GEMM", "f16x2"),
+                    choices=["f16x2", "bf16x3", "split", "exact"],
+                    help="pointwise GEMM arithmetic (all fp32 in/accumulate/out): f16x2 = two f16 terms of the per-tensor "
+                         "scaled operands, 3 products on the f16 MFMA (default); bf16x3 (= split) = exact three bf16 "
+                         "terms, 6 products on the bf16 MFMA; exact = f32 MFMA")
     ap.add_argument("--no-exact-leg", action="store_true",
                     help="skip the second timed loop with the exact f32-MFMA GEMMs (reported as exact_f32_gemm)")
     ap.add_argument("--bucket-mb", type=int, default=32, help="DDP gradient bucket size (N>1)")
@@ -197,7 +200,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    ops.GEMM_SPLIT = args.gemm == "split"
+    if args.gemm == "split":
+        args.gemm = "bf16x3"
+    ops.GEMM_SCHEME = ops._SCHEMES[args.gemm]
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
@@ -258,8 +263,8 @@ def main():
     # The same K steps with the exact f32-MFMA GEMMs, timed the same way and reported beside the headline
     # (`value` is the default arithmetic: fp32 through the bf16 split).
     exact = None
-    if args.gemm == "split" and not args.no_exact_leg:
-        ops.GEMM_SPLIT = False
+    if args.gemm != "exact" and not args.no_exact_leg:
+        ops.GEMM_SCHEME = ops.GEMM_EXACT
         for _ in range(min(args.warmup, 2)):
             step(batch)
         barrier()
@@ -270,7 +275,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         e_exact = max_over_ranks(time.perf_counter() - t1, dev)
-        ops.GEMM_SPLIT = True
+        ops.GEMM_SCHEME = ops._SCHEMES[args.gemm]
         exact = {"value": world * B * args.steps / e_exact, "unit": "samples/s",
                  "ms_per_step": 1e3 * e_exact / args.steps, "gemm_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
 
@@ -293,8 +298,10 @@ def main():
                    "optimizer": args.optimizer, "parallelism": f"dp{world}",
                    "ddp": ({"bucket_cap_mb": args.bucket_mb, "static_graph": bool(args.static_graph),
                             "backend": torch.distributed.get_backend()} if world > 1 else None),
-                   "gemm_arithmetic": ("fp32 via exact 3-way bf16 split on bf16 MFMA, fp32 accumulate"
-                                       if args.gemm == "split" else "fp32 MFMA"),
+                   "gemm_arithmetic": {"f16x2": "fp32 via two f16 terms of the per-tensor scaled operands (22 significand "
+                                                "bits), 3 products on f16 MFMA, fp32 accumulate",
+                                       "bf16x3": "fp32 via exact 3-way bf16 split on bf16 MFMA, fp32 accumulate",
+                                       "exact": "fp32 MFMA"}[args.gemm],
                    "mode": "forward-only" if args.forward_only else "train",
                    "activation_checkpointing": bool(args.checkpoint),
                    "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
@@ -308,10 +315,15 @@ def main():
             ms = sum(g["ms"] for g in gem)
             n = sum(g["launches"] for g in gem)
             ach = flops / (ms * 1e-3) / 1e12
-            if args.gemm == "split":
-                kname = ("pw_gemm_split_kernel/pw_gemm_wgrad_split_kernel (fwd+dgrad+wgrad; fp32 operands as "
+            products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS}.get(args.gemm)
+            if args.gemm == "bf16x3":
+                kname = ("pw_gemm_split_kernel<3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
                          "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
-                peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS
+                peak = MFMA_BF16_PEAK_TFLOPS / products
+            elif args.gemm == "f16x2":
+                kname = ("pw_gemm_split_kernel<2>/pw_gemm_wgrad_split_kernel<2> (fwd+dgrad+wgrad; fp32 operands as "
+                         "2 f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)")
+                peak = MFMA_BF16_PEAK_TFLOPS / products
             else:
                 kname = "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)"
                 peak = MFMA_F32_PEAK_TFLOPS
@@ -320,7 +332,8 @@ def main():
                                "bound": "mfma", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak,
                                "flops": "algorithmic 2*M*N*K per GEMM (fp32-equivalent)"
-                                        + ("; executed bf16 MFMA rate = 6x achieved, peak = 2500/6" if args.gemm == "split" else ""),
+                                        + (f"; executed 16-bit MFMA rate = {products}x achieved, peak = 2500/{products}"
+                                           if products else ""),
                                "traffic": gemm_traffic, "traffic_source": gemm_src,
                                "launches": n, "avg_launch_ms": ms / n,
                                "flops_per_launch": flops / n,

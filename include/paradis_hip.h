@@ -50,7 +50,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 3: `flags` of sl_advect_*; the process-global debug setters are gone */
+int paradis_abi_version(void);   /* 4: GEMM `scheme` arguments, paradis_amax_partials (3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -101,18 +101,33 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  * Y[b] = epi( W[M,K] * X[b][K,N] ),  epi(v) = res + act(v + bias[m] + map[m,n]).
  * bias/map/res/zpre may be NULL.  zpre (if given) receives the pre-activation value.
  *
- * Two arithmetic paths, both fp32 in / fp32 accumulate / fp32 out:
- *   - exact: v_mfma_f32_32x32x2_f32 (an fmaf chain over k);
- *   - split: each fp32 operand is decomposed exactly into three bf16 terms and the product is
+ * Three arithmetic schemes, all fp32 in / fp32 accumulate / fp32 out (`scheme` arguments):
+ *   - PARADIS_GEMM_EXACT:  v_mfma_f32_32x32x2_f32 (an fmaf chain over k);
+ *   - PARADIS_GEMM_BF16X3: each fp32 operand is decomposed exactly into three bf16 terms and the product is
  *     accumulated from the six partial products >= 2^-16 on v_mfma_f32_32x32x16_bf16 (relative
- *     truncation 2^-23 per product, fewer accumulation roundings: error vs fp64 not above the exact
- *     path's).  Selected per call by passing the split weight image (fwd, dgrad) / split != 0 (wgrad). */
-size_t paradis_pw_gemm_split_bytes(int M, int K);   /* bytes of the split image of an [M,K] A operand */
-/* split image of A = W[M,K] (transpose 0; out: split_bytes(M,K)) or of A = W^T (transpose 1; out:
- * split_bytes(K,M)) from row-major W[M,K] */
-int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, void* out, void* stream);
+ *     truncation 2^-23 per product, fewer accumulation roundings: error vs fp64 not above the exact path's);
+ *   - PARADIS_GEMM_F16X2:  each operand TENSOR is scaled by a power of two that puts its largest magnitude
+ *     into [2^14, 2^15) and every value is written as two f16 terms (22 significand bits; values more than
+ *     ~2^17 below the tensor's maximum keep an absolute accuracy of 2^-39 max|x|); three partial products on
+ *     v_mfma_f32_32x32x16_f16, result unscaled in the epilogue.  Error vs fp64 of a K = 1024 product: that of
+ *     an fp32 SGEMM.  Needs the tensors' largest magnitudes: paradis_amax_partials for activations, the
+ *     weight image carries its own.
+ * fwd / dgrad take the split image of their weight operand (NULL with PARADIS_GEMM_EXACT). */
+#define PARADIS_GEMM_EXACT 0
+#define PARADIS_GEMM_F16X2 2
+#define PARADIS_GEMM_BF16X3 3
+#define PARADIS_AMAX_PARTIALS 1024
+/* partials[PARADIS_AMAX_PARTIALS] <- bit patterns of partial maxima of |x| over B blocks of `inner`
+ * contiguous floats (block stride bs); the tensor's maximum is the (unsigned) maximum of the words, a NaN
+ * anywhere makes it a NaN pattern.  One read pass, no atomics, no pre-zeroing. */
+int paradis_amax_partials(const float* x, int B, int64_t inner, int64_t bs, uint32_t* partials, void* stream);
+size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme);   /* bytes of the split image of an [M,K] A operand */
+/* split image of A = W[M,K] (transpose 0; out: split_bytes(M,K,scheme)) or of A = W^T (transpose 1; out:
+ * split_bytes(K,M,scheme)) from row-major W[M,K]; scheme = PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 */
+int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, int scheme, void* out, void* stream);
 int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
-                        const void* Wsplit /* optional split image of Wt (takes precedence), or NULL */,
+                        const void* Wsplit /* split image of Wt for `scheme`, NULL for PARADIS_GEMM_EXACT */,
+                        int scheme, const uint32_t* x_amax /* amax partials of X: PARADIS_GEMM_F16X2 only */,
                         const float* X, const float* bias, const float* map,
                         const float* m8 /* [cin,N] */, const float* pwT /* [cin,M] */, int cin,
                         /* ^ optional low-rank bias applied on the fly: + sum_c pwT[c,m]*m8[c,n] (GlobalBias
@@ -121,16 +136,19 @@ int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
                         int act, void* stream);
 /* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend);
- * WTsplit: optional split image of W^T (paradis_pw_gemm_split_weights(..., transpose=1)), or NULL */
-int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const float* dY, const float* zpre,
+ * WTsplit: split image of W^T (paradis_pw_gemm_split_weights(..., transpose=1)), NULL for PARADIS_GEMM_EXACT */
+int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme,
+                          const uint32_t* dy_amax /* amax partials of dY: PARADIS_GEMM_F16X2 only */,
+                          const float* dY, const float* zpre,
                           const float* addend, float* dX, int B, int M, int K, int N, int64_t dy_bs,
                           int64_t z_bs, int64_t add_bs, int64_t dx_bs, int act, void* stream);
 /* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; gbias[M] = sum_{b,n} dY (optional, NULL to skip; fused
  * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes;
- * split != 0 asks for the bf16-split path (used when N % 16 == 0 and the rows are 16-B aligned) */
+ * a split scheme is used when N % 16 == 0 and the rows are 16-B aligned (the exact kernels run otherwise) */
 size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N);
 int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias,
-                          int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs, int split,
+                          int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
+                          const uint32_t* dy_amax, const uint32_t* x_amax /* PARADIS_GEMM_F16X2 only */,
                           void* workspace, void* stream);
 
 /* ---- a8: ChannelNorm (reference model/blocks.py:118-134): per-pixel, unbiased variance.
@@ -228,7 +246,7 @@ int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, int rows, in
                       int normuon, int split /* Newton-Schulz products on the bf16-split GEMM */,
                       void* workspace, void* stream);
 /* Plain batched GEMM C_b[M,N] = A_b[M,K] B_b[K,N] (row-major; AT = optional [K,M] transposes of A_b,
- * enabling the LDS-DMA kernel; split_ws = optional nbatch * paradis_pw_gemm_split_bytes(M,K) bytes of
+ * enabling the LDS-DMA kernel; split_ws = optional nbatch * paradis_pw_gemm_split_bytes(M,K,PARADIS_GEMM_BF16X3) bytes of
  * scratch selecting the bf16-split arithmetic) used by the Newton-Schulz iteration. */
 int paradis_bgemm(const float* A, const float* AT, const float* B, float* C, int nbatch, int M, int K, int N,
                   int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs, void* split_ws, void* stream);

@@ -52,6 +52,9 @@ struct GemmArgs {
   float* rowsum;              // wgrad only: [nbatch][M] partial row sums of A (= bias gradient), or NULL
   // low-rank bias map applied on the fly: acc[m,n] += sum_c pw[c*M + m] * m8[c*N + n]  (M % 4 == 0)
   const float* m8; const float* pw; int cin;
+  // f16x2 scheme: where the operands' max |value| comes from.  a_amax: one word (bits of max |A|, weight
+  // image tail) for fwd/dgrad, PARADIS_AMAX_PARTIALS words for wgrad; b_amax: PARADIS_AMAX_PARTIALS words.
+  const uint32_t* a_amax; const uint32_t* b_amax;
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -574,11 +577,61 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // which would serialise the DMA rings; vector-typed reads do not get that wait.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SBK = 16;                  // k depth of a tile = one bf16 MFMA
+constexpr int SBK = 16;                  // k depth of a tile = one bf16 / f16 MFMA
 constexpr int SCH = 128;                 // chunks per k-half row of an unpadded image
-constexpr int SIMG = 3 * 2 * SCH;        // chunks per operand per stage (12 KiB)
 constexpr int SCHP = 128 + 8;            // padded variant (wgrad: lane pairs write both k-halves of a row)
-constexpr int SIMGP = 3 * 2 * SCHP;
+// NP = number of planes of an operand image = terms of the split: 3 = bf16 h/m/l (exact, six products),
+// 2 = f16 h/l of the scaled value (22 significand bits, three products)
+constexpr int simg(int np) { return np * 2 * SCH; }      // chunks per operand per stage (12 / 8 KiB)
+constexpr int simgp(int np) { return np * 2 * SCHP; }
+constexpr int SIMG = simg(3);
+
+// ---- f16x2 scheme ------------------------------------------------------------------------------
+// x' = x 2^e with e chosen per TENSOR so that max |x'| lies in [2^14, 2^15) (fp16 holds 65504);
+// h = f16(x'), l = f16(x' - h): x' = h + l up to 2^-23 |x'|, and - fp16 being a fixed-point format below
+// 2^-14 - up to 2^-25 absolutely, i.e. 2^-39 of the tensor's largest magnitude.  a b is accumulated in
+// fp32 from  al bh + ah bl + ah bh  (dropped: al bl <= 2^-22 |ab|); the f16 MFMA forms the 11x11-bit
+// products exactly.  The result is unscaled by 2^-(ea+eb) in the epilogue (two exact multiplications).
+// Error against fp64 of a K = 1024 product of N(0,1) operands: 5.1e-7 of max |C| (SGEMM: 5.8e-7); what
+// it gives up against the bf16x3 scheme is elements more than ~2^17 below their tensor's maximum, which
+// keep an ABSOLUTE accuracy of 2^-39 max|x| instead of a relative one.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// scale 2^e and its inverse from the bits of max |x| (biased exponent E: e = 14 - (E - 127)); a zero or
+// tiny maximum takes the largest scale.  A non-finite maximum (an Inf or NaN somewhere in the tensor) has no
+// meaningful scale: the scale becomes NaN and with it the whole product - loudly wrong, never silently rescaled.
+__device__ __forceinline__ void scale_from_amax(uint32_t amax_bits, float& s, float& inv) {
+  int E = (int)((amax_bits >> 23) & 0xffu);
+  const bool finite = E != 255;
+  E = E < 15 ? 15 : E;
+  s = finite ? __uint_as_float((uint32_t)(268 - E) << 23) : __uint_as_float(0x7fc00000u);
+  inv = __uint_as_float((uint32_t)(E - 14) << 23);
+}
+
+// max of PARADIS_AMAX_PARTIALS (= 1024) words, by a 256-thread workgroup; every thread gets the result
+__device__ __forceinline__ uint32_t reduce_amax_partials(const uint32_t* __restrict__ p) {
+  __shared__ uint32_t red[4];
+  const int tid = threadIdx.x;
+  uint32_t m = max(max(p[tid], p[tid + 256]), max(p[tid + 512], p[tid + 768]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = max(max(red[0], red[1]), max(red[2], red[3]));
+  __syncthreads();
+  return m;
+}
+
+// (x0, x1) 2^e -> packed halves h, l.  v_fma_mix*: fp32 FMA, result rounded once to f16; x s and
+// x s - h are exact in fp32, so h and l are the correctly rounded values.
+__device__ __forceinline__ void split2_pair(float x0, float x1, float s, uint32_t& h, uint32_t& l) {
+  uint32_t hh, ll;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "v"(s), "v"(hh));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(s), "v"(hh));
+  h = hh; l = ll;
+}
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   const f32x2 v = {a, b};
@@ -599,6 +652,42 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, 
   h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
   m = (u32x4){mm[0], mm[1], mm[2], mm[3]};
   l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+__device__ __forceinline__ void split8_f16(const float (&x)[8], float s, u32x4& h, u32x4& l) {
+  uint32_t hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split2_pair(x[2 * i], x[2 * i + 1], s, hh[i], ll[i]);
+  h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+  l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+// max |x| over B blocks of `inner` contiguous floats (block stride bs) -> PARADIS_AMAX_PARTIALS words, one
+// per workgroup (bits of a non-negative float order like unsigned integers; a NaN is larger than Inf and
+// so survives).  The consumers take the maximum of the words: no atomics, no zero-fill, deterministic.
+__global__ void __launch_bounds__(256)
+amax_partials_kernel(const float* __restrict__ x, int B, int64_t inner, int64_t bs, int vec, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  if (vec) {
+    const int64_t n4 = inner >> 2, total = n4 * B;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t b = i / n4, j = i - b * n4;
+      const uint4 q = *reinterpret_cast<const uint4*>(x + b * bs + 4 * j);
+      m = max(max(m, q.x & 0x7fffffffu), max(q.y & 0x7fffffffu, max(q.z & 0x7fffffffu, q.w & 0x7fffffffu)));
+    }
+  } else {
+    const int64_t total = inner * B;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t b = i / inner, j = i - b * inner;
+      m = max(m, __float_as_uint(x[b * bs + j]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  __shared__ uint32_t red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
 // Image of A[m,k] = W[m*rs + k*cs] (rs/cs select W or W^T), zero padded to [MT*128, KT*16]:
@@ -626,6 +715,33 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
   }
 }
 
+// f16x2 image: out[((mt*KT + kt)*2 + s)*256 + half*128 + row]; `tail` = the words behind the image:
+// [0] = bits of max |W| (written here, read by the GEMMs), [4 ..) = the amax partials of W (input)
+__global__ void __launch_bounds__(256)
+split_weights_f16_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
+                         u32x4* __restrict__ out, uint32_t* __restrict__ tail) {
+  const uint32_t amax = reduce_amax_partials(tail + 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0) tail[0] = amax;
+  float sc, inv;
+  scale_from_amax(amax, sc, inv);
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+    const int row = (int)(u & 127), half = (int)((u >> 7) & 1);
+    const int64_t tile = u >> 8;
+    const int kt = (int)(tile % KT), mt = (int)(tile / KT);
+    const int m = mt * BM + row;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kt * SBK + half * 8 + j;
+      x[j] = (m < M && k < K) ? W[(int64_t)m * rs + (int64_t)k * cs] : 0.f;
+    }
+    u32x4 h, l;
+    split8_f16(x, sc, h, l);
+    u32x4* o = out + tile * simg(2) + half * SCH + row;
+    o[0] = h; o[2 * SCH] = l;
+  }
+}
+
 #define SPLIT_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 // The six partial products of one 32x32 block, smallest first.  (An order in which consecutive MFMAs
 // share an operand register, snaking over the four blocks of a wave tile, measured +0.5 % - nothing -
@@ -634,28 +750,53 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 #define SPLIT_BLOCK(AH, AM, AL, BH, BM_, BL, C) \
   SPLIT_MFMA(AM, BM_, C); SPLIT_MFMA(AL, BH, C); SPLIT_MFMA(AH, BL, C); \
   SPLIT_MFMA(AM, BH, C);  SPLIT_MFMA(AH, BM_, C); SPLIT_MFMA(AH, BH, C)
+#define SPLIT_MFMA16(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
 
 // one k-tile: fragments of both operands from the images at As/Bs (chunk pointers at this lane's
 // row of block 0, k-half lh), plane stride PA/PB chunks ...
-struct SplitFrags { u32x4 a[3][2], b[3][2]; };
-template <int PA, int PB>
-__device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs, SplitFrags& f) {
-  // in the order of first use by split_tile_mfma (block (0,0): m.m, l.h, h.l first), so that the counted
-  // lgkmcnt waits let the first MFMAs start after two reads instead of seven
-  f.a[1][0] = As[PA];          f.b[1][0] = Bs[PB];
-  f.a[2][0] = As[2 * PA];      f.b[0][0] = Bs[0];
-  f.a[0][0] = As[0];           f.b[2][0] = Bs[2 * PB];
-  f.b[1][1] = Bs[PB + 32];     f.b[0][1] = Bs[32];          f.b[2][1] = Bs[2 * PB + 32];
-  f.a[1][1] = As[PA + 32];     f.a[2][1] = As[2 * PA + 32]; f.a[0][1] = As[32];
+template <int NP> struct SplitFrags { u32x4 a[NP][2], b[NP][2]; };
+template <int NP, int PA, int PB>
+__device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs, SplitFrags<NP>& f) {
+  // in the order of first use by split_tile_mfma (block (0,0): m.m, l.h, h.l first; l.h, h.l for two
+  // planes), so that the counted lgkmcnt waits let the first MFMAs start after two reads
+  if constexpr (NP == 3) {
+    f.a[1][0] = As[PA];          f.b[1][0] = Bs[PB];
+    f.a[2][0] = As[2 * PA];      f.b[0][0] = Bs[0];
+    f.a[0][0] = As[0];           f.b[2][0] = Bs[2 * PB];
+    f.b[1][1] = Bs[PB + 32];     f.b[0][1] = Bs[32];          f.b[2][1] = Bs[2 * PB + 32];
+    f.a[1][1] = As[PA + 32];     f.a[2][1] = As[2 * PA + 32]; f.a[0][1] = As[32];
+  } else {
+    f.a[1][0] = As[PA];          f.b[0][0] = Bs[0];
+    f.a[0][0] = As[0];           f.b[1][0] = Bs[PB];
+    f.b[0][1] = Bs[32];          f.b[1][1] = Bs[PB + 32];
+    f.a[1][1] = As[PA + 32];     f.a[0][1] = As[32];
+  }
 }
-// ... then the 24 MFMAs
-__device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&acc)[2][2]) {
+// ... then the 24 (12) MFMAs, smallest products first
+template <int NP>
+__device__ __forceinline__ void split_tile_mfma(const SplitFrags<NP>& f, f32x16 (&acc)[2][2]) {
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-      SPLIT_BLOCK(f.a[0][tm], f.a[1][tm], f.a[2][tm], f.b[0][tn], f.b[1][tn], f.b[2][tn], acc[tm][tn]);
+      if constexpr (NP == 3) {
+        SPLIT_BLOCK(f.a[0][tm], f.a[1][tm], f.a[2][tm], f.b[0][tn], f.b[1][tn], f.b[2][tn], acc[tm][tn]);
+      } else {
+        SPLIT_MFMA16(f.a[1][tm], f.b[0][tn], acc[tm][tn]);
+        SPLIT_MFMA16(f.a[0][tm], f.b[1][tn], acc[tm][tn]);
+        SPLIT_MFMA16(f.a[0][tm], f.b[0][tn], acc[tm][tn]);
+      }
     }
+}
+
+// f16x2: C = 2^-(ea+eb) acc, two exact multiplications (their product may lie outside the fp32 range)
+__device__ __forceinline__ void split_unscale(f32x16 (&acc)[2][2], float inv_a, float inv_b) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * inv_a) * inv_b;
 }
 
 // fwd / dgrad:  C_b = epi( A . B_b ),  A = split weight image (g.A, batch stride g.a_bs chunks),
@@ -671,9 +812,11 @@ __device__ __forceinline__ void split_tile_mfma(const SplitFrags& f, f32x16 (&ac
 #ifndef SPLIT_ASTAGES
 #define SPLIT_ASTAGES 2   // weight-image ring depth (2: DMA one tile ahead, 48 KiB, 3 WGs/CU; 4: three ahead, 72 KiB, 2 WGs/CU)
 #endif
+template <int NP>
 __global__ void __launch_bounds__(256, SPLIT_ASTAGES == 2 ? 3 : 2)
 pw_gemm_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SIMG = simg(NP);                     // (shadows the bf16 constant)
   u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 activation stages][SIMG] | [SPLIT_ASTAGES weight stages][SIMG]
   constexpr int SA = SPLIT_ASTAGES, DA = SA - 1;     // weight ring depth, DMA distance in tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -703,13 +846,31 @@ pw_gemm_split_kernel(GemmArgs g) {
   }
   const int bn = min(n0 + (tid & 127), g.N - 1);
 
+  float sc_b = 1.f, inv_a = 1.f, inv_b = 1.f;       // f16x2: activation scale, inverse scales of both operands
+  if constexpr (NP == 2) {
+    float sc_a;
+    scale_from_amax(reduce_amax_partials(g.b_amax), sc_b, inv_b);
+    scale_from_amax(g.a_amax[0], sc_a, inv_a);
+  }
+
   float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
   auto issueA = [&](int t) __attribute__((always_inline)) {
     const u32x4* a = Ag + (int64_t)t * SIMG;
     u32x4* la = img + (2 + t % SA) * SIMG + wave * 64;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NP; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a + i * 256), (lds_ptr_t)(la + i * 256), 16, 0, 0);
+  };
+  auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
+    if constexpr (NP == 3) {
+      u32x4 h, m, l;
+      split8(x, h, m, l);
+      o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+    } else {
+      u32x4 h, l;
+      split8_f16(x, sc_b, h, l);
+      o[0] = h; o[2 * SCH] = l;
+    }
   };
   // Activation loads are issued from inline asm (saddr form: scalar row base + 32-bit lane offset, no
   // vector address arithmetic) so that the compiler does not account for them: on this loop its own
@@ -748,11 +909,7 @@ pw_gemm_split_kernel(GemmArgs g) {
   fetchB(0, xb[0]);
   USE_X(xb[0], 0);
   if (T > 1) fetchB(1, xb[1]);
-  {
-    u32x4 h, m, l;
-    split8(xb[0], h, m, l);
-    Bst[0] = h; Bst[2 * SCH] = m; Bst[4 * SCH] = l;
-  }
+  split_store(xb[0], Bst);
   // raw barriers with counted waits: __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier and
   // would make every barrier wait for the activation loads that are meant to stay in flight
   if (T > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -763,40 +920,36 @@ pw_gemm_split_kernel(GemmArgs g) {
     const bool dmaA = t + DA < T, ldB = t + 2 < T;
     if (dmaA) issueA(t + DA);
     if (ldB) fetchB(t + 2, xload);
-    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's 3 DMA and 8 loads
-    if (dmaA && ldB) USE_X(xsplit, 11);
+    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's NP DMA and 8 loads
+    if (dmaA && ldB) { if constexpr (NP == 3) USE_X(xsplit, 11); else USE_X(xsplit, 10); }
     else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
     // The fragment reads sit in the block of the MFMAs (behind the branches above the compiler's lgkmcnt
     // bookkeeping falls back to lgkmcnt(0) in front of the first MFMA; inside one block the waits are
     // counted and the first MFMA starts after two of the twelve reads).
-    SplitFrags f;
-    split_tile_read<2 * SCH, 2 * SCH>(As, Bs, f);
+    SplitFrags<NP> f;
+    split_tile_read<NP, 2 * SCH, 2 * SCH>(As, Bs, f);
     // One basic block for every tile, the last included (its split writes a stage that nobody reads any
     // more): a second copy of the MFMA block behind a branch costs 32 accumulator moves per tile.
-    split_tile_mfma(f, acc);
-    {
-      u32x4 h, m, l;
-      split8(xsplit, h, m, l);
-      // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // all fragment reads first, in first-use order
+    split_tile_mfma<NP>(f, acc);
+    split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+    // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
 #pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      u32x4* o = Bst + (cur ^ 1) * SIMG;
-      o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+    for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 3 : 2, 0);
     }
-    // weight tile t+1 landed (its DMA is DA steps old: 8 loads of that step + 11 operations per step since
+    // weight tile t+1 landed (its DMA is DA steps old: 8 loads of that step + 8 + NP operations per step since
     // are younger), own ds_writes done, the loads of t+2 and the younger DMAs still in flight
-    if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(8 + 11 * (DA - 1)) : "memory");
+    if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(8 + (8 + NP) * (DA - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   for (int t = 0; t < T; t += 2) {
     step(t, 0, xb[0], xb[1]);
     if (t + 1 < T) step(t + 1, 1, xb[1], xb[0]);
   }
+  if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
@@ -808,9 +961,11 @@ pw_gemm_split_kernel(GemmArgs g) {
 // per tile.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int NP>
 __global__ void __launch_bounds__(256, 3)
 pw_gemm_wgrad_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SIMGP = simgp(NP);
   u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A|B][SIMGP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -853,6 +1008,11 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
                          __builtin_amdgcn_sched_barrier(0); } while (0)
   const bool do_rowsum = g.rowsum != nullptr && nt == 0;
   float rs = 0.f;
+  float sc_a = 1.f, sc_b = 1.f, inv_a = 1.f, inv_b = 1.f;
+  if constexpr (NP == 2) {
+    scale_from_amax(reduce_amax_partials(g.a_amax), sc_a, inv_a);
+    scale_from_amax(reduce_amax_partials(g.b_amax), sc_b, inv_b);
+  }
   auto split_store = [&](const Regs& r, int st, bool keep) __attribute__((always_inline)) {
     const float xa[8] = {r.a0.x, r.a0.y, r.a0.z, r.a0.w, r.a1.x, r.a1.y, r.a1.z, r.a1.w};
     const float xb[8] = {r.b0.x, r.b0.y, r.b0.z, r.b0.w, r.b1.x, r.b1.y, r.b1.z, r.b1.w};
@@ -860,13 +1020,22 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     // last tile works on stale registers that may hold NaNs)
     const float add = ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
     rs += keep ? add : 0.f;
-    u32x4 ha, ma, la, hb, mb, lb;
-    split8(xa, ha, ma, la);
-    split8(xb, hb, mb, lb);
     u32x4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
-    o[0] = ha; o[2 * SCHP] = ma; o[4 * SCHP] = la;
-    o += SIMGP;
-    o[0] = hb; o[2 * SCHP] = mb; o[4 * SCHP] = lb;
+    if constexpr (NP == 3) {
+      u32x4 ha, ma, la, hb, mb, lb;
+      split8(xa, ha, ma, la);
+      split8(xb, hb, mb, lb);
+      o[0] = ha; o[2 * SCHP] = ma; o[4 * SCHP] = la;
+      o += SIMGP;
+      o[0] = hb; o[2 * SCHP] = mb; o[4 * SCHP] = lb;
+    } else {
+      u32x4 ha, la, hb, lb;
+      split8_f16(xa, sc_a, ha, la);
+      split8_f16(xb, sc_b, hb, lb);
+      o[0] = ha; o[2 * SCHP] = la;
+      o += SIMGP;
+      o[0] = hb; o[2 * SCHP] = lb;
+    }
   };
 
   f32x16 acc[2][2];
@@ -887,16 +1056,16 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
   auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
     const u32x4* As = img + cur * 2 * SIMGP + lh * SCHP + wm * 64 + li;
     const u32x4* Bs = img + (cur * 2 + 1) * SIMGP + lh * SCHP + wn * 64 + li;
-    SplitFrags f;
-    split_tile_read<2 * SCHP, 2 * SCHP>(As, Bs, f);
+    SplitFrags<NP> f;
+    split_tile_read<NP, 2 * SCHP, 2 * SCHP>(As, Bs, f);
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < T) { fetch(rload); USE_R(rsplit, 4); }
     else USE_R(rsplit, 0);
     // one basic block for every tile; the last tile's split is surplus (stage nobody reads, keep = 0)
-    split_tile_mfma(f, acc);
+    split_tile_mfma<NP>(f, acc);
     split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
+    for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the two splits
     }
@@ -912,6 +1081,7 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     const int m = m0 + srow;
     if (sh == 0 && m < g.M) g.rowsum[(int64_t)bz * g.M + m] = rs;
   }
+  if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
@@ -984,24 +1154,43 @@ int launch_gemm(const GemmArgs& g, int grid, hipStream_t st) {
                     : launch_gemm_bk<A_KC, B_KC, 16>(g, grid, st);
 }
 
-constexpr size_t SPLIT_LDS = (size_t)(2 + SPLIT_ASTAGES) * SIMG * 16, SPLIT_LDS_WGRAD = (size_t)2 * 2 * SIMGP * 16;
+constexpr size_t split_lds(int np) { return (size_t)(2 + SPLIT_ASTAGES) * simg(np) * 16; }
+constexpr size_t split_lds_wgrad(int np) { return (size_t)2 * 2 * simgp(np) * 16; }
+constexpr int AMAX_WORDS = PARADIS_AMAX_PARTIALS;
+// f16x2 weight image: the planes, then 16 bytes ([0] = bits of max |W|), then the amax partials of W
+constexpr size_t F16_TAIL_BYTES = 16 + (size_t)AMAX_WORDS * 4;
 
-int64_t split_image_chunks(int M, int K) {
-  return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * SIMG;
+int64_t split_image_chunks(int M, int K, int np = 3) {
+  return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * simg(np);
 }
 
-int launch_split(const GemmArgs& d, hipStream_t st) {
+bool known_scheme(int scheme) {
+  return scheme == PARADIS_GEMM_EXACT || scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2;
+}
+
+int launch_amax(const float* x, int B, int64_t inner, int64_t bs, uint32_t* out, hipStream_t st) {
+  const int vec = (inner % 4 == 0) && (bs % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipLaunchKernelGGL(amax_partials_kernel, dim3(AMAX_WORDS), dim3(256), 0, st, x, B, inner, bs, vec, out);
+  return 0;
+}
+
+template <int NP>
+int launch_split_np(const GemmArgs& d, hipStream_t st) {
   const int grid = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.nbatch;
   static PerDeviceOnce once;
-  if (SPLIT_LDS > 64 * 1024 && once.first()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS) != hipSuccess) {
+  if (split_lds(NP) > 64 * 1024 && once.first()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_kernel<NP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds(NP)) != hipSuccess) {
       paradis_set_error("pw_gemm(split): cannot reserve LDS");
       return 2;
     }
   }
-  hipLaunchKernelGGL(pw_gemm_split_kernel, dim3(grid), dim3(256), SPLIT_LDS, st, d);
+  hipLaunchKernelGGL(pw_gemm_split_kernel<NP>, dim3(grid), dim3(256), split_lds(NP), st, d);
   return 0;
+}
+// scheme: PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 (the latter with d.a_amax / d.b_amax set)
+int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
+  return scheme == PARADIS_GEMM_F16X2 ? launch_split_np<2>(d, st) : launch_split_np<3>(d, st);
 }
 
 int check_gemm(const char* name, int B, int M, int K, int N) {
@@ -1025,33 +1214,70 @@ extern "C" void paradis_debug_set_gemm_dma(int stages) { g_dma_stages = stages <
 extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = stages < 2 ? 0 : (stages > 3 ? 3 : stages); }
 #endif
 
-extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K) {
-  return M >= 1 && K >= 1 ? (size_t)split_image_chunks(M, K) * 16 : 0;
+extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme) {
+  if (M < 1 || K < 1) return 0;
+  if (scheme == PARADIS_GEMM_F16X2) return (size_t)split_image_chunks(M, K, 2) * 16 + F16_TAIL_BYTES;
+  return scheme == PARADIS_GEMM_BF16X3 ? (size_t)split_image_chunks(M, K, 3) * 16 : 0;
 }
 
-// Split image (h/m/l bf16 planes, tile order) of A = W[M,K] (transpose = 0) or of A = W^T[K,M]
-// (transpose = 1, from the same row-major W[M,K]); out holds split_bytes(M,K) resp. split_bytes(K,M).
-extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, void* out,
+extern "C" int paradis_amax_partials(const float* x, int B, int64_t inner, int64_t bs, uint32_t* partials,
+                                     void* stream) {
+  PD_REQUIRE(partials != nullptr && B >= 0 && inner >= 0 && (x != nullptr || B == 0 || inner == 0),
+             "amax_partials: bad arguments");
+  launch_amax(x, B, inner, bs, partials, (hipStream_t)stream);
+  PD_CHECK_LAUNCH("amax_partials");
+  return 0;
+}
+
+// Split image (tile order) of A = W[M,K] (transpose = 0) or of A = W^T[K,M] (transpose = 1, from the same
+// row-major W[M,K]); out holds split_bytes(M,K,scheme) resp. split_bytes(K,M,scheme).  BF16X3: h/m/l bf16
+// planes.  F16X2: h/l f16 planes of W 2^e and, behind them, the bits of max |W|.
+extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, int scheme, void* out,
                                              void* stream) {
   PD_REQUIRE(W != nullptr && out != nullptr && M >= 1 && K >= 1, "pw_gemm_split_weights: bad arguments");
+  PD_REQUIRE(scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2, "pw_gemm_split_weights: unknown scheme %d", scheme);
   const int AM = transpose ? K : M, AK = transpose ? M : K;
   const int KT = (AK + SBK - 1) / SBK;
   const int64_t units = (int64_t)((AM + BM - 1) / BM) * KT * 256;
   const int blocks = (int)std::min<int64_t>((units + 255) / 256, 4096);
-  hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
-                     (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units,
-                     (int64_t)0, (int64_t)0, (u32x4*)out);
+  if (scheme == PARADIS_GEMM_F16X2) {
+    uint32_t* tail = reinterpret_cast<uint32_t*>((char*)out + (size_t)split_image_chunks(AM, AK, 2) * 16);
+    launch_amax(W, 1, (int64_t)M * K, 0, tail + 4, (hipStream_t)stream);
+    hipLaunchKernelGGL(split_weights_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W,
+                       (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units, (u32x4*)out, tail);
+  } else {
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
+                       (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units,
+                       (int64_t)0, (int64_t)0, (u32x4*)out);
+  }
   PD_CHECK_LAUNCH("pw_gemm_split_weights");
   return 0;
 }
 
-extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void* Wsplit, const float* X,
+namespace {
+// A = split image at `img` of an [AM, AK] matrix; F16X2 needs the activations' amax partials
+int run_split(GemmArgs d, const void* img, int AM, int AK, int scheme, const uint32_t* b_amax, const char* what,
+              hipStream_t st) {
+  d.A = (const float*)img; d.a_bs = 0;
+  if (scheme == PARADIS_GEMM_F16X2) {
+    if (b_amax == nullptr) { paradis_set_error(what); return 1; }
+    d.a_amax = reinterpret_cast<const uint32_t*>((const char*)img + (size_t)split_image_chunks(AM, AK, 2) * 16);
+    d.b_amax = b_amax;
+  }
+  return launch_split(d, scheme, st);
+}
+}  // namespace
+
+extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void* Wsplit, int scheme,
+                                   const uint32_t* x_amax, const float* X,
                                    const float* bias, const float* map, const float* m8,
                                    const float* pwT, int cin, const float* res, float* Y, float* zpre,
                                    int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
                                    int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
+  PD_REQUIRE(known_scheme(scheme) && (Wsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
+             "pw_gemm_fwd: scheme %d needs %s weight image", scheme, scheme ? "a" : "no");
   PD_REQUIRE((m8 == nullptr) == (pwT == nullptr) && (pwT == nullptr || (cin >= 1 && M % 4 == 0)),
              "pw_gemm_fwd: projected bias needs m8, pwT, cin >= 1 and M %% 4 == 0");
   if (B == 0) return 0;
@@ -1064,10 +1290,9 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
   g.zout_bs = (int64_t)M * N; g.act = act;
   g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
-  if (Wsplit != nullptr) {   // bf16-split image of the weights: split kernel (any shape)
-    GemmArgs d = g;
-    d.A = (const float*)Wsplit; d.a_bs = 0;
-    if (int e = launch_split(d, (hipStream_t)stream)) return e;
+  if (Wsplit != nullptr) {   // split image of the weights: split kernel (any shape)
+    if (int e = run_split(g, Wsplit, M, K, scheme, x_amax, "pw_gemm_fwd: the f16x2 scheme needs x_amax",
+                          (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("pw_gemm_fwd(split)");
     return 0;
   }
@@ -1112,7 +1337,7 @@ extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, f
                        (int64_t)K, (int64_t)1, M, K, KT, units, a_bs, chunks, (u32x4*)split_ws);
     GemmArgs d = g;
     d.A = (const float*)split_ws; d.a_bs = chunks;
-    if (int e = launch_split(d, (hipStream_t)stream)) return e;
+    if (int e = launch_split(d, PARADIS_GEMM_BF16X3, (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("bgemm(split)");
     return 0;
   }
@@ -1130,13 +1355,16 @@ extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, f
   return 0;
 }
 
-extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const float* dY, const float* zpre,
+extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme, const uint32_t* dy_amax,
+                                     const float* dY, const float* zpre,
                                      const float* addend, float* dX, int B, int M, int K, int N,
                                      int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
                                      int act, void* stream) {
   // W is [M,K] (M = Co, K = Ci); result dX is [K,N] per sample: GEMM with M' = K, K' = M.
   if (int e = check_gemm("pw_gemm_dgrad", B, K, M, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_dgrad: unknown activation code %d", act);
+  PD_REQUIRE(known_scheme(scheme) && (WTsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
+             "pw_gemm_dgrad: scheme %d needs %s weight image", scheme, scheme ? "a" : "no");
   if (B == 0) return 0;
   GemmArgs g{};
   g.A = Wt; g.B = dY; g.C = dX; g.M = K; g.N = N; g.K = M;
@@ -1145,10 +1373,9 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, const
   g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
   g.stagger = g_stagger;
   const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
-  if (WTsplit != nullptr) {   // bf16-split image of W^T
-    GemmArgs d = g;
-    d.A = (const float*)WTsplit; d.a_bs = 0;
-    if (int e = launch_split(d, (hipStream_t)stream)) return e;
+  if (WTsplit != nullptr) {   // split image of W^T
+    if (int e = run_split(g, WTsplit, K, M, scheme, dy_amax, "pw_gemm_dgrad: the f16x2 scheme needs dy_amax",
+                          (hipStream_t)stream)) return e;
     PD_CHECK_LAUNCH("pw_gemm_dgrad(split)");
     return 0;
   }
@@ -1173,18 +1400,22 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
                                   int64_t dz_bs, void* stream);
 
 extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias, int B,
-                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, int split,
-                                     void* workspace, void* stream) {
+                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
+                                     const uint32_t* dy_amax, const uint32_t* x_amax, void* workspace,
+                                     void* stream) {
   // dW[M,K] = sum_b dY[b][M,N] . X[b][K,N]^T : GEMM with M'=M, N'=K, K'=N, reduced over samples.
   if (int e = check_gemm("pw_gemm_wgrad", 1, M, N, K)) return e;
+  PD_REQUIRE(known_scheme(scheme), "pw_gemm_wgrad: unknown scheme %d", scheme);
+  PD_REQUIRE(scheme != PARADIS_GEMM_F16X2 || (dy_amax != nullptr && x_amax != nullptr),
+             "pw_gemm_wgrad: the f16x2 scheme needs dy_amax and x_amax");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
     if (hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
     if (gbias && hipMemsetAsync(gbias, 0, (size_t)M * sizeof(float), st) != hipSuccess) return 2;
     return 0;
   }
-  // split != 0: both operands go through the bf16 split (same layout requirements as the LDS-DMA kernel)
-  const bool use_split = split != 0 && wgrad_vec_layout(N, dy_bs, x_bs, dY, X);
+  // a split scheme: both operands are split in registers (same layout requirements as the LDS-DMA kernel)
+  const bool use_split = scheme != PARADIS_GEMM_EXACT && wgrad_vec_layout(N, dy_bs, x_bs, dY, X);
   const bool dma = use_split || wgrad_dma_ok(N, dy_bs, x_bs, dY, X);   // "dma" = kernels with fused row sums
   const int S = use_split ? wgrad_splits(B, M, K, N, SBK, 3)
                           : dma ? wgrad_splits(B, M, K, N, DBK, wgrad_dma_wgs())
@@ -1203,8 +1434,11 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.stagger = g_stagger;
   g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-  if (use_split) {
-    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel, dim3(grid), dim3(256), SPLIT_LDS_WGRAD, st, g);
+  if (use_split && scheme == PARADIS_GEMM_F16X2) {
+    g.a_amax = dy_amax; g.b_amax = x_amax;
+    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<2>, dim3(grid), dim3(256), split_lds_wgrad(2), st, g);
+  } else if (use_split) {
+    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<3>, dim3(grid), dim3(256), split_lds_wgrad(3), st, g);
   } else if (dma) {
     const size_t bytes = (size_t)g_wgrad_dma_stages * 2 * DTILE * sizeof(float);
     if (g_wgrad_dma_stages == 2)

@@ -18,7 +18,7 @@
 extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, float* C, int nbatch, int M,
                              int K, int N, int64_t a_bs, int64_t at_bs, int64_t b_bs, int64_t c_bs,
                              void* split_ws, void* stream);
-extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K);
+
 
 namespace {
 
@@ -160,7 +160,7 @@ extern "C" size_t paradis_muon_ws_bytes(int T, int rows, int cols) {
   // U, X, XT, Xnew (T x n each), A, A2, B' (T x m x m each), scalars; then the bf16-split images of the
   // left operands of the Newton-Schulz products (T x [m, max(rows, cols)], 256-B aligned)
   const size_t floats = (up64(n * T)) * 4 + up64(m * m * T) * 3 + up64(3 * (size_t)T) + 64;
-  return floats * sizeof(float) + (size_t)T * paradis_pw_gemm_split_bytes((int)m, std::max(rows, cols)) + 256;
+  return floats * sizeof(float) + (size_t)T * paradis_pw_gemm_split_bytes((int)m, std::max(rows, cols), PARADIS_GEMM_BF16X3) + 256;
 }
 
 // One Muon (normuon = 0) or NorMuon (normuon = 1) step on T same-shaped weight matrices w_t[rows, cols]

@@ -807,16 +807,36 @@ def global_bias_m8(A, U, V):
 #     y = residual + act(W x + bias + bias_map)
 # (reference model/blocks.py:86,110 + :196 + activation + the residual adds of paradis.py:246,253)
 # ---------------------------------------------------------------------------
-# Arithmetic of the pointwise GEMMs (include/paradis_hip.h, a6): True = bf16-split products on the
-# bf16 matrix pipe (fp32 in/accumulate/out, error vs fp64 not above the exact path's: see
-# tests/test_hip_gemm_split.py), False = exact f32 MFMA chain.  PARADIS_GEMM=exact selects the latter.
-GEMM_SPLIT = os.environ.get("PARADIS_GEMM", "split") != "exact"
+# Arithmetic of the pointwise GEMMs (include/paradis_hip.h, a6), all fp32 in / accumulate / out:
+#   "f16x2"  (default) two f16 terms of the per-tensor scaled operands, three products on the f16 matrix pipe
+#            (22 significand bits; error vs fp64 that of an fp32 SGEMM: tests/test_hip_gemm_split.py);
+#   "bf16x3" three bf16 terms, six products: exact decomposition, error not above the f32 MFMA path's;
+#   "exact"  the f32 MFMA chain.
+# PARADIS_GEMM selects ("split" = bf16x3, the name of earlier rounds).
+GEMM_EXACT, GEMM_F16X2, GEMM_BF16X3 = 0, 2, 3
+_SCHEMES = {"exact": GEMM_EXACT, "f16x2": GEMM_F16X2, "bf16x3": GEMM_BF16X3, "split": GEMM_BF16X3}
+AMAX_PARTIALS = 1024
 
-# bf16 h/m/l tile images of the weights (split GEMMs) are rebuilt only when the weights change:
+
+def _scheme_from_env() -> int:
+    name = os.environ.get("PARADIS_GEMM", "f16x2")
+    if name not in _SCHEMES:
+        raise ValueError(f"PARADIS_GEMM={name!r}: choose between {'|'.join(_SCHEMES)}")
+    return _SCHEMES[name]
+
+
+GEMM_SCHEME = _scheme_from_env()
+
+
+def gemm_scheme_name() -> str:
+    return {GEMM_EXACT: "exact", GEMM_F16X2: "f16x2", GEMM_BF16X3: "bf16x3"}[GEMM_SCHEME]
+
+
+# split tile images of the weights (split GEMMs) are rebuilt only when the weights change:
 # keyed on the parameter object, its data pointer, its autograd version (every torch in-place update
 # bumps it) and WEIGHT_EPOCH, which the HIP optimisers bump (their kernels write through raw pointers).
 WEIGHT_EPOCH = 0
-_IMAGES = {}     # (id(weight), transpose) -> (weakref, data_ptr, version, epoch, image)
+_IMAGES = {}     # (id(weight), transpose, scheme) -> (weakref, data_ptr, version, epoch, image)
 
 
 def weights_updated() -> None:
@@ -826,22 +846,25 @@ def weights_updated() -> None:
 
 
 def _drop_images(wid: int) -> None:
-    _IMAGES.pop((wid, False), None)
-    _IMAGES.pop((wid, True), None)
+    for scheme in (GEMM_F16X2, GEMM_BF16X3):
+        _IMAGES.pop((wid, False, scheme), None)
+        _IMAGES.pop((wid, True, scheme), None)
 
 
 def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool) -> Tensor:
-    key = (id(weight), transpose)
+    scheme = GEMM_SCHEME
+    key = (id(weight), transpose, scheme)
     ent = _IMAGES.get(key)
     ver = weight._version
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == ver and \
             ent[3] == WEIGHT_EPOCH:
         return ent[4]
     w2 = weight.reshape(Co, Ci).contiguous()
-    nbytes = lib.paradis_pw_gemm_split_bytes(Ci, Co) if transpose else lib.paradis_pw_gemm_split_bytes(Co, Ci)
+    nbytes = lib.paradis_pw_gemm_split_bytes(Ci, Co, scheme) if transpose else \
+        lib.paradis_pw_gemm_split_bytes(Co, Ci, scheme)
     out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, dptr(out), stream_ptr()),
-          "pw_gemm_split_weights")
+    check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, scheme, dptr(out),
+                                            stream_ptr()), "pw_gemm_split_weights")
     if isinstance(weight, torch.nn.Parameter) or weight.is_leaf:
         wid = id(weight)
         try:
@@ -852,10 +875,34 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool) -> Tensor:
     return out
 
 
+@_define("amax_partials(Tensor x) -> Tensor")
+def _amax_partials(x):
+    """int32[AMAX_PARTIALS]: bit patterns of partial maxima of |x| ([B,C,H,W], channel-sliced views allowed);
+    the f16x2 GEMMs take the maximum of the words as the tensor's largest magnitude.  One read pass."""
+    _f32(x)
+    x, x_bs = _plane_view(x)
+    B, C, H, W = x.shape
+    out = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
+    check(lib.paradis_amax_partials(dptr(x), B, C * H * W, x_bs, dptr(out), stream_ptr()), "amax_partials")
+    return out
+
+
+@_fake("amax_partials")
+def _(x):
+    return x.new_empty(AMAX_PARTIALS, dtype=torch.int32)
+
+
+def _amax_for_gemm(x):
+    """amax partials of a GEMM operand when the scheme needs them, else None"""
+    return _amax_partials(x) if GEMM_SCHEME == GEMM_F16X2 else None
+
+
 @_define("pointwise(Tensor x, Tensor weight, Tensor? bias, Tensor? bmap, Tensor? residual, int act, "
-         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z) -> (Tensor, Tensor)")
+         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z) "
+         "-> (Tensor, Tensor, Tensor)")
 def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z):
-    """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z).
+    """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z);
+    third = amax partials of x (f16x2 scheme; empty otherwise), kept for the weight gradient.
 
     Activation-gradient hand-off between two chained ops (GMBlock drives it):
       * ``defer_act_grad`` (producer): the op's backward receives d(pre-activation) directly and
@@ -885,8 +932,12 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         pwt = pw.t().contiguous()   # [cin, Co]: four consecutive output rows per 16-byte load
     z = torch.empty_like(y) if (save_z and act != 0) else y.new_empty(0)
     w2 = w2t = wsp = None
-    if GEMM_SPLIT:
-        wsp = _split_image(weight, Co, Ci, False)   # bf16 h/m/l planes in tile order
+    x_amax = x.new_empty(0, dtype=torch.int32)
+    if GEMM_SCHEME != GEMM_EXACT:
+        wsp = _split_image(weight, Co, Ci, False)   # split planes in tile order
+        if GEMM_SCHEME == GEMM_F16X2:
+            x_amax = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
+            check(lib.paradis_amax_partials(dptr(x), B, Ci * P, x_bs, dptr(x_amax), stream_ptr()), "amax_partials")
     else:
         w2 = weight.reshape(Co, Ci).contiguous()
         if Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
@@ -897,17 +948,19 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         w2 = weight.reshape(Co, Ci)
         if not w2.is_contiguous():
             w2 = w2.contiguous()
-    _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), dptr(x), dptr(bias),
+    _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), GEMM_SCHEME,
+              dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
               dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
               dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
-    return y, z
+    return y, z, x_amax
 
 
 @_fake("pointwise")
 def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z):
     B, _, H, W = x.shape
     y = x.new_empty(B, weight.shape[0], H, W)
-    return y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0))
+    return (y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0)),
+            x.new_empty(AMAX_PARTIALS if GEMM_SCHEME == GEMM_F16X2 else 0, dtype=torch.int32))
 
 
 @_define("act_backward(Tensor gy, Tensor z, int act) -> Tensor")
@@ -924,9 +977,10 @@ def _(gy, z, act):
     return gy.new_empty(gy.shape)
 
 
-@_define("pw_gemm_dgrad(Tensor dz, Tensor weight, Tensor? zmul, int x_act) -> Tensor")
-def _pw_gemm_dgrad(dz, weight, zmul, x_act):
-    """gx = W^T dz (* act'(zmul) when the producing layer deferred its activation gradient)."""
+@_define("pw_gemm_dgrad(Tensor dz, Tensor weight, Tensor? zmul, int x_act, Tensor? dz_amax) -> Tensor")
+def _pw_gemm_dgrad(dz, weight, zmul, x_act, dz_amax):
+    """gx = W^T dz (* act'(zmul) when the producing layer deferred its activation gradient).
+    dz_amax: amax partials of dz (f16x2 scheme; computed here when missing)."""
     _f32(dz, weight, zmul)
     dz = dz.contiguous()
     B, Co, H, W = dz.shape
@@ -936,25 +990,28 @@ def _pw_gemm_dgrad(dz, weight, zmul, x_act):
     w2 = weight.reshape(Co, Ci)
     if not w2.is_contiguous():
         w2 = w2.contiguous()
-    wtsp = _split_image(weight, Co, Ci, True) if GEMM_SPLIT else None
+    wtsp = _split_image(weight, Co, Ci, True) if GEMM_SCHEME != GEMM_EXACT else None
+    if GEMM_SCHEME == GEMM_F16X2 and dz_amax is None:
+        dz_amax = _amax_partials(dz)
     if zmul is not None:
         zmul = zmul.contiguous()
-    _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), dptr(dz),
+    _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), GEMM_SCHEME,
+              dptr(dz_amax) if GEMM_SCHEME == GEMM_F16X2 else None, dptr(dz),
               dptr(zmul) if x_act != 0 else None, None, dptr(gx), B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P,
               x_act, stream_ptr())
     return gx
 
 
 @_fake("pw_gemm_dgrad")
-def _(dz, weight, zmul, x_act):
+def _(dz, weight, zmul, x_act, dz_amax):
     B, Co, H, W = dz.shape
     return dz.new_empty(B, weight.numel() // Co, H, W)
 
 
-@_define("pw_gemm_wgrad(Tensor dz, Tensor x, bool want_bias) -> (Tensor, Tensor)")
-def _pw_gemm_wgrad(dz, x, want_bias):
+@_define("pw_gemm_wgrad(Tensor dz, Tensor x, bool want_bias, Tensor? dz_amax, Tensor? x_amax) -> (Tensor, Tensor)")
+def _pw_gemm_wgrad(dz, x, want_bias, dz_amax, x_amax):
     """gW[Co,Ci] = sum over samples and points of dz x^T; the bias gradient (row sums of dz) falls out
-    of the same pass."""
+    of the same pass.  dz_amax / x_amax: amax partials (f16x2 scheme; computed here when missing)."""
     _f32(dz, x)
     dz = dz.contiguous()
     x, x_bs = _plane_view(x)
@@ -963,13 +1020,19 @@ def _pw_gemm_wgrad(dz, x, want_bias):
     gw = torch.empty(Co, Ci, dtype=dz.dtype, device=dz.device)
     gb = torch.empty(Co if want_bias else 0, dtype=dz.dtype, device=dz.device)
     ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), dz.device)
+    f16 = GEMM_SCHEME == GEMM_F16X2
+    if f16 and (dz_amax is None or dz_amax.numel() == 0):
+        dz_amax = _amax_partials(dz)
+    if f16 and (x_amax is None or x_amax.numel() == 0):
+        x_amax = _amax_partials(x)
     _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), dptr(gb) if want_bias else None,
-              B, Co, Ci, P, Co * P, x_bs, 1 if GEMM_SPLIT else 0, dptr(ws), stream_ptr())
+              B, Co, Ci, P, Co * P, x_bs, GEMM_SCHEME, dptr(dz_amax) if f16 else None,
+              dptr(x_amax) if f16 else None, dptr(ws), stream_ptr())
     return gw, gb
 
 
 @_fake("pw_gemm_wgrad")
-def _(dz, x, want_bias):
+def _(dz, x, want_bias, dz_amax, x_amax):
     Co, Ci = dz.shape[1], x.shape[1]
     return dz.new_empty(Co, Ci), dz.new_empty(Co if want_bias else 0)
 
@@ -1012,17 +1075,17 @@ def _(gmap, m8, pw):
 
 def _pw_setup(ctx, inputs, output):
     x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z = inputs
-    y, z = output
-    ctx.save_for_backward(x, weight, z, x_pre, m8, pw)
+    y, z, x_amax = output
+    ctx.save_for_backward(x, weight, z, x_pre, m8, pw, x_amax)
     ctx.meta = (act, bias is not None, bmap is not None, residual is not None,
                 x_act if x_pre is not None else 0, bool(defer))
     # z carries no gradient; without this autograd would materialise a full-size zero tensor for it
-    ctx.mark_non_differentiable(z)
+    ctx.mark_non_differentiable(z, x_amax)
     ctx.set_materialize_grads(False)
 
 
-def _pw_backward(ctx, gy, gz=None):
-    x, weight, z, x_pre, m8, pw = ctx.saved_tensors
+def _pw_backward(ctx, gy, gz=None, gamax=None):
+    x, weight, z, x_pre, m8, pw, x_amax = ctx.saved_tensors
     act, has_bias, has_map, has_res, x_act, deferred = ctx.meta
     need = ctx.needs_input_grad
     if gy is None:
@@ -1034,14 +1097,16 @@ def _pw_backward(ctx, gy, gz=None):
     else:
         dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
     gx = gw = gb = gmap = gm8 = gpw = None
+    # one pass over dz serves both of its GEMMs
+    dz_amax = _amax_for_gemm(dz) if (need[0] or need[1]) else None
     if need[0]:
-        gx = _pw_gemm_dgrad(dz, weight, x_pre if x_act != 0 else None, x_act)
+        gx = _pw_gemm_dgrad(dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax)
     want_b = has_bias and need[2]
     want_p = has_proj and (need[9] or need[10])
     want_m = (has_map and need[3]) or want_p
     if need[1]:
         fused_b = want_b and not want_m     # bias gradient = row sums of dz: fused into the wgrad GEMM
-        gw, gbf = _pw_gemm_wgrad(dz, x, fused_b)
+        gw, gbf = _pw_gemm_wgrad(dz, x, fused_b, dz_amax, x_amax)
         gw = gw.reshape(weight.shape)
         if fused_b:
             gb, want_b = gbf, False
@@ -1076,8 +1141,8 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     save_z = bool(defer_act_grad)
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
-    y, z = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad),
-                      m8, pw, save_z)
+    y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad),
+                         m8, pw, save_z)
     return (y, z) if defer_act_grad else y
 
 

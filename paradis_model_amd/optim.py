@@ -141,7 +141,7 @@ class Muon(AdamW):
     """Muon with the constructor of ``dion.Muon`` as the reference calls it (trainer.py:347-354):
     parameter groups carry ``algorithm`` ("muon" / "normuon" for 2-D-flattened weights, "adamw" for
     the rest, see ``build_param_groups``).  The matrix update runs in one C-ABI call per weight
-    (``paradis_muon_step``: fp32 Newton-Schulz on the GEMMs of ``ops`` - bf16-split or exact f32 MFMA as ``ops.GEMM_SPLIT`` says - no Triton); AdamW groups use the fused kernel
+    (``paradis_muon_step``: fp32 Newton-Schulz on the GEMMs of ``ops`` - bf16x3 split unless ``ops.GEMM_SCHEME`` is exact - no Triton); AdamW groups use the fused kernel
     of the base class.  ``dion`` is neither vendored nor pinned by the reference: the algorithm is
     restated from its published form (oracle/muon_oracle.py), parity unpinned."""
 
@@ -256,7 +256,7 @@ class Muon(AdamW):
                                         _adjusted_lr(lr, full, group["adjust_lr"]), group["mu"],
                                         group["muon_beta2"], group["weight_decay"], group["eps"],
                                         int(bool(group["nesterov"])), int(normuon),
-                                        1 if ops.GEMM_SPLIT else 0, dptr(c["ws"]), st),
+                                        1 if ops.GEMM_SCHEME != ops.GEMM_EXACT else 0, dptr(c["ws"]), st),
                   "muon_step")
         ops.weights_updated()
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/paradis_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.lib.paradis_abi_version() == 3
+    assert _lib.lib.paradis_abi_version() == 4
 
 
 def test_argument_validation_without_gpu():
@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu():
     assert L.paradis_dwconv_geo_fwd(None, None, None, None, 1, 4, 16, 32, 4, None) == 1   # even kernel
     assert L.paradis_sl_advect_fwd(None, None, None, None, None, None, None, 1, 1, 16, 32, 0, 0, 0,
                                    0.1, 0.0, 0.0, 1.0, 1.0, 3, 0, None, None) == 1        # bad mode
-    assert L.paradis_pw_gemm_fwd(None, None, None, None, None, None, None, None, 0, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None) == 1
+    assert L.paradis_pw_gemm_fwd(None, None, None, 0, None, None, None, None, None, None, 0, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None) == 1
     assert L.paradis_avgpool_geo_fwd(None, None, 1, 16, 32, 0, None) == 1      # stride < 1
     # data feed (row f4): window longer than the series; unknown forcing code; no variables
     import ctypes

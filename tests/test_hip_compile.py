@@ -119,11 +119,11 @@ def test_opcheck_registrations():
 
 
 def test_weight_image_cache_follows_weight_updates():
-    """The bf16-split weight images are cached across calls; an in-place torch update (version counter),
+    """The split weight images are cached across calls; an in-place torch update (version counter),
     an optimiser step through the C ABI (WEIGHT_EPOCH) and a new tensor at the same address must all be
     seen."""
     from paradis_model_amd import ops
-    if not ops.GEMM_SPLIT:
+    if ops.GEMM_SCHEME == ops.GEMM_EXACT:
         pytest.skip("exact f32 GEMMs keep no weight images")
     x = torch.randn(2, 32, 8, 16, device="cuda")
     w = torch.nn.Parameter(torch.randn(48, 32, 1, 1, device="cuda"))

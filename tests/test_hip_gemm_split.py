@@ -1,10 +1,13 @@
-"""The bf16-split pointwise GEMMs (fp32 in / fp32 accumulate / fp32 out on the bf16 matrix pipe) against
+"""The split pointwise GEMMs (fp32 in / fp32 accumulate / fp32 out on the bf16 / f16 matrix pipe) against
 the exact f32-MFMA kernels and an fp64 evaluation of the same product.
 
-Claim under test (include/paradis_hip.h, a6): the split path is an fp32 GEMM, not a reduced-precision one:
-its error against fp64 is not above the exact f32 chain's.  Bounds written here:
+Claim under test (include/paradis_hip.h, a6): the split paths are fp32 GEMMs, not reduced-precision ones:
+their error against fp64 is not above the exact f32 chain's.  Bounds written here, for "bf16x3" (exact
+three-term decomposition) and for "f16x2" (two f16 terms of the per-tensor scaled operands, the default):
   * max |split - fp64| / max |fp64|  <=  1.25 x the same figure of the exact kernel + 1e-7, and
-  * <= 2e-6 absolutely (an fp32 dot product of length <= 1024 with |x|,|w| ~ 1 sits at ~3e-7)."""
+  * <= 2e-6 absolutely (an fp32 dot product of length <= 1024 with |x|,|w| ~ 1 sits at ~3e-7).
+What f16x2 gives up - relative accuracy of elements far below their TENSOR's largest magnitude - and its
+all-or-nothing treatment of non-finite operands have their own tests below."""
 import pytest
 import torch
 
@@ -28,9 +31,12 @@ def ops():
     return _ops
 
 
-def _run(ops, split, x, w, b, res, ct, act):
-    keep = ops.GEMM_SPLIT
-    ops.GEMM_SPLIT = split
+SPLIT_SCHEMES = ["f16x2", "bf16x3"]
+
+
+def _run(ops, scheme, x, w, b, res, ct, act):
+    keep = ops.GEMM_SCHEME
+    ops.GEMM_SCHEME = ops._SCHEMES[scheme]
     try:
         ds = [t.detach().clone().cuda().requires_grad_(True) for t in (x, w, b, res)]
         y = ops.pointwise(ds[0], ds[1], ds[2], None, ds[3], act)
@@ -38,7 +44,7 @@ def _run(ops, split, x, w, b, res, ct, act):
         torch.cuda.synchronize()
         return [y.detach()] + [d.grad for d in ds[:3]]
     finally:
-        ops.GEMM_SPLIT = keep
+        ops.GEMM_SCHEME = keep
 
 
 def _fp64(x, w, b, res, ct, act):
@@ -59,15 +65,16 @@ def _err(a, ref):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W", SHAPES)
 @pytest.mark.parametrize("act", [None, "SiLU"])
-def test_split_not_less_accurate_than_exact_f32(ops, B, Ci, Co, H, W, act):
+@pytest.mark.parametrize("scheme", SPLIT_SCHEMES)
+def test_split_not_less_accurate_than_exact_f32(ops, scheme, B, Ci, Co, H, W, act):
     x = seeded(1, B, Ci, H, W)
     w = seeded(2, Co, Ci, scale=Ci ** -0.5)
     b = seeded(3, Co, scale=0.1)
     res = seeded(5, B, Co, H, W)
     ct = seeded(6, B, Co, H, W)
     ref = _fp64(x, w, b, res, ct, act)
-    exact = _run(ops, False, x, w, b, res, ct, act)
-    split = _run(ops, True, x, w, b, res, ct, act)
+    exact = _run(ops, "exact", x, w, b, res, ct, act)
+    split = _run(ops, scheme, x, w, b, res, ct, act)
     for name, s, e, r in zip(("y", "gx", "gw", "gb"), split, exact, ref):
         es, ee = _err(s, r), _err(e, r)
         assert es <= 1.25 * ee + 1e-7, (name, es, ee)
@@ -76,7 +83,8 @@ def test_split_not_less_accurate_than_exact_f32(ops, B, Ci, Co, H, W, act):
 
 def test_split_exactness_on_bf16_representable_inputs(ops):
     """Inputs that are exactly bf16 numbers with small integer values make every partial product and
-    every partial sum exact in fp32: both paths must then agree bit for bit with integer arithmetic."""
+    every partial sum exact in fp32 (f16x2: the power-of-two scaling is exact too): all three paths must
+    then agree bit for bit with integer arithmetic."""
     g = torch.Generator().manual_seed(7)
     B, Ci, Co, H, W = 2, 64, 48, 8, 16
     x = torch.randint(-8, 9, (B, Ci, H, W), generator=g).float()
@@ -85,14 +93,14 @@ def test_split_exactness_on_bf16_representable_inputs(ops):
     res = torch.zeros(B, Co, H, W)
     ct = torch.randint(-4, 5, (B, Co, H, W), generator=g).float()
     ref = _fp64(x, w, b, res, ct, None)
-    for mode in (True, False):
+    for mode in ("f16x2", "bf16x3", "exact"):
         got = _run(ops, mode, x, w, b, res, ct, None)
         for name, a, r in zip(("y", "gx", "gw"), got, ref):
             assert torch.equal(a.double(), r), (mode, name)
 
 
 def test_split_handles_wide_dynamic_range(ops):
-    """Operands spanning 12 decades: the h/m/l terms keep fp32's exponent range (bf16 has the same
+    """bf16x3, operands spanning 12 decades: the h/m/l terms keep fp32's exponent range (bf16 has the same
     8 exponent bits), so nothing under- or overflows in the split."""
     g = torch.Generator().manual_seed(11)
     B, Ci, Co, H, W = 1, 96, 64, 8, 16
@@ -103,8 +111,8 @@ def test_split_handles_wide_dynamic_range(ops):
     res = torch.zeros(B, Co, H, W)
     ct = torch.randn(B, Co, H, W, generator=g)
     ref = _fp64(x, w, b, res, ct, None)
-    exact = _run(ops, False, x, w, b, res, ct, None)
-    split = _run(ops, True, x, w, b, res, ct, None)
+    exact = _run(ops, "exact", x, w, b, res, ct, None)
+    split = _run(ops, "bf16x3", x, w, b, res, ct, None)
     for name, s, e, r in zip(("y", "gx", "gw"), split, exact, ref):
         # element-wise relative to the fp64 magnitude scale of each output row/column is too strict
         # for cancelling sums; compare the two paths on the same max-normalised figure
@@ -112,7 +120,75 @@ def test_split_handles_wide_dynamic_range(ops):
         assert es <= 1.25 * ee + 1e-7, (name, es, ee)
 
 
-def test_split_random_ragged_shapes(ops):
+def test_f16x2_error_model(ops):
+    """What the two-term scheme promises (include/paradis_hip.h): every operand element is represented
+    to 2^-22 of itself or 2^-39 of its tensor's largest magnitude, whichever is larger.
+      * tensors of any overall magnitude (1e-30 .. 1e+30): fp32-level result (the scale is per tensor);
+      * a tensor whose samples differ by 2^12 in magnitude: the small samples' outputs still carry
+        <= 2e-6 relative error (2^12 x 2^12 below the maxima on both operands is inside the 2^39 window);
+      * entries 2^30 below the tensor's maximum: their contribution is right to 2^-39 of the maximum, i.e.
+        the ABSOLUTE error of the output stays at fp32 level although those entries alone are not."""
+    g = torch.Generator().manual_seed(21)
+    B, Ci, Co, H, W = 2, 96, 64, 8, 16
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, generator=g) * Ci ** -0.5
+    z = torch.zeros
+    for sx, sw in ((1e30, 1e-30), (1e-30, 1e30), (1e-20, 1e-10), (1e15, 1e15)):
+        ref = _fp64(x * sx, w * sw, z(Co), z(B, Co, H, W), torch.randn(B, Co, H, W, generator=g), None)
+        got = _run(ops, "f16x2", x * sx, w * sw, z(Co), z(B, Co, H, W), torch.randn(B, Co, H, W, generator=g), None)
+        assert _err(got[0], ref[0]) <= 2e-6, (sx, sw, _err(got[0], ref[0]))
+    xs = x.clone()
+    xs[1] *= 2.0 ** -12                       # second sample 2^12 below the first
+    ct = torch.randn(B, Co, H, W, generator=g)
+    ref = _fp64(xs, w, z(Co), z(B, Co, H, W), ct, None)
+    got = _run(ops, "f16x2", xs, w, z(Co), z(B, Co, H, W), ct, None)
+    assert _err(got[0][1], ref[0][1]) <= 2e-6 and _err(got[0][0], ref[0][0]) <= 2e-6
+    assert _err(got[1][1], ref[1][1]) <= 2e-6       # gx of the small sample
+    xt = x.clone()
+    xt[:, ::2] *= 2.0 ** -30                  # every other channel 2^30 below the rest
+    ref = _fp64(xt, w, z(Co), z(B, Co, H, W), ct, None)
+    got = _run(ops, "f16x2", xt, w, z(Co), z(B, Co, H, W), ct, None)
+    assert _err(got[0], ref[0]) <= 2e-6 and _err(got[2], ref[2]) <= 2e-6
+
+
+def test_f16x2_non_finite_operand_poisons_the_product(ops):
+    """An Inf or NaN anywhere in an operand tensor makes its largest magnitude non-finite: the whole
+    product comes out NaN (loudly wrong), never silently rescaled.  bf16x3 / exact confine it to the
+    outputs it touches (test_split_extreme_magnitudes)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 8, 16, generator=g)
+    w = torch.randn(48, 64, generator=g) * 0.1
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        xb = x.clone(); xb[0, 7, 1, 4] = bad
+        assert torch.isnan(_fwd_only(ops, "f16x2", xb, w)).all()
+        wb = w.clone(); wb[5, 9] = bad
+        assert torch.isnan(_fwd_only(ops, "f16x2", x, wb)).all()
+    assert torch.isfinite(_fwd_only(ops, "f16x2", x, w)).all()
+    # all-zero operands: zero result, no NaN from the scale
+    assert (_fwd_only(ops, "f16x2", torch.zeros_like(x), w) == 0).all()
+    assert (_fwd_only(ops, "f16x2", x, torch.zeros_like(w)) == 0).all()
+
+
+def test_amax_partials(ops):
+    """The reduction feeding the f16x2 scale: maximum of the words = max |x|, on contiguous tensors,
+    channel-sliced views, sizes that are not multiples of four, and with a NaN inside."""
+    g = torch.Generator().manual_seed(9)
+    for shape in ((2, 5, 7, 9), (3, 64, 32, 64), (1, 1, 1, 1)):
+        x = torch.randn(*shape, generator=g).cuda()
+        p = ops._amax_partials(x)
+        assert p.shape == (ops.AMAX_PARTIALS,) and p.dtype == torch.int32
+        got = p.max().view(1).view(torch.float32)
+        assert float(got) == float(x.abs().max())
+    base = torch.randn(2, 12, 8, 16, generator=g).cuda()
+    base[:, 8:] *= 100.0
+    view = base[:, 2:8]                       # channel slice: batch stride != C H W
+    assert float(ops._amax_partials(view).max().view(1).view(torch.float32)) == float(view.abs().max())
+    base[1, 3, 2, 2] = float("nan")
+    assert torch.isnan(ops._amax_partials(view).max().view(1).view(torch.float32)).all()
+
+
+@pytest.mark.parametrize("scheme", SPLIT_SCHEMES)
+def test_split_random_ragged_shapes(ops, scheme):
     """30 random small shapes (every combination of ragged M / K / N tiles, K < 8, N < 32, N % 16 != 0 for
     which the weight gradient takes the exact kernel): all four results within 2e-6 of fp64."""
     g = torch.Generator().manual_seed(2024)
@@ -128,7 +204,7 @@ def test_split_random_ragged_shapes(ops):
         res = torch.randn(B, Co, H, W, generator=g)
         ct = torch.randn(B, Co, H, W, generator=g)
         ref = _fp64(x, w, b, res, ct, "SiLU")
-        got = _run(ops, True, x, w, b, res, ct, "SiLU")
+        got = _run(ops, scheme, x, w, b, res, ct, "SiLU")
         for name, a, r in zip(("y", "gx", "gw", "gb"), got, ref):
             assert torch.isfinite(a).all(), (case, name)
             assert _err(a, r) <= 2e-6, (case, (B, Ci, Co, H, W), name, _err(a, r))
@@ -145,7 +221,7 @@ def test_batched_gemm_split_vs_exact():
         errs = {}
         for split in (False, True):
             C = torch.empty(T, M, N, device="cuda")
-            ws = torch.empty(T * lib.paradis_pw_gemm_split_bytes(M, K), dtype=torch.uint8, device="cuda") if split else None
+            ws = torch.empty(T * lib.paradis_pw_gemm_split_bytes(M, K, 3), dtype=torch.uint8, device="cuda") if split else None
             rc = lib.paradis_bgemm(dptr(A), None, dptr(Bm), dptr(C), T, M, K, N, M * K, 0, K * N, M * N,
                                    dptr(ws), stream_ptr())
             assert rc == 0
@@ -154,18 +230,20 @@ def test_batched_gemm_split_vs_exact():
         assert errs[True] <= 1.25 * errs[False] + 1e-7 and errs[True] <= 2e-6, ((T, M, K, N), errs)
 
 
-def _fwd_only(ops, split, x, w):
-    keep = ops.GEMM_SPLIT
-    ops.GEMM_SPLIT = split
+def _fwd_only(ops, scheme, x, w):
+    if isinstance(scheme, bool):
+        scheme = "bf16x3" if scheme else "exact"
+    keep = ops.GEMM_SCHEME
+    ops.GEMM_SCHEME = ops._SCHEMES[scheme]
     try:
         with torch.no_grad():
             return ops.pointwise(x.cuda(), w.cuda()).cpu()
     finally:
-        ops.GEMM_SPLIT = keep
+        ops.GEMM_SCHEME = keep
 
 
 def test_split_extreme_magnitudes(ops):
-    """Edge semantics of the h/m/l split next to the exact f32 kernel (documented in DESIGN.md 4.1b):
+    """Edge semantics of the bf16 h/m/l split next to the exact f32 kernel (documented in DESIGN.md 4.1b):
       * operands of magnitude 1e+-30 whose products are O(1): fp32-level result (bf16 has fp32's exponent
         range, nothing over- or underflows in the split);
       * operands below ~1e-33: the m / l terms (2^-8, 2^-16 of the operand) fall below fp32's smallest

@@ -20,13 +20,13 @@ def _build(cfg, lg, og, state=None):
 
 @pytest.mark.parametrize("variant,fuse_projection", [("a", False), ("b", False), ("c", False), ("a", True),
                                                      ("c", True)])
-@pytest.mark.parametrize("split_gemm", [True, False])
-def test_reduced_model_vs_reference_golden(variant, fuse_projection, split_gemm, monkeypatch):
-    """Same tolerances for both GEMM arithmetics (bf16-split on the bf16 MFMA = default, exact f32 MFMA)."""
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "exact"])
+def test_reduced_model_vs_reference_golden(variant, fuse_projection, gemm, monkeypatch):
+    """Same tolerances for the three GEMM arithmetics (f16x2 = default, bf16x3, exact f32 MFMA)."""
     from paradis_model_amd import ops
     from paradis_model_amd.loss import build_loss
     from paradis_model_amd.model import blocks
-    monkeypatch.setattr(ops, "GEMM_SPLIT", split_gemm)
+    monkeypatch.setattr(ops, "GEMM_SCHEME", ops._SCHEMES[gemm])
     # the large-plane path (GlobalBias projection inside the GEMM) must give the same model
     monkeypatch.setattr(blocks, "FUSE_BIAS_PROJECTION_MIN_POINTS", 0 if fuse_projection else 1 << 40)
     rec = load_golden(f"g4_model_{variant}.pt")

@@ -62,7 +62,7 @@ def test_abi_validation_without_gpu():
 def test_hip_step_vs_oracle(cls_name, nesterov, split, monkeypatch):
     """Both arithmetics of the Newton-Schulz products (bf16-split / exact f32 MFMA) against the oracle."""
     from paradis_model_amd import ops, optim
-    monkeypatch.setattr(ops, "GEMM_SPLIT", split)
+    monkeypatch.setattr(ops, "GEMM_SCHEME", ops.GEMM_BF16X3 if split else ops.GEMM_EXACT)
     torch.manual_seed(1)
     # two matrices share a shape (stacked in one launch); wide, tall, conv, depthwise, ragged
     shapes = [(64, 48), (48, 64), (64, 48), (32, 16, 1, 1), (40, 1, 3, 3), (20, 8), (130, 258)]

@@ -64,14 +64,14 @@ def main():
             use_t = cfg[2] >= 2
             wsp = wtsp = None
             if cfg[3]:
-                wsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Co, Ci), dtype=torch.uint8, device="cuda")
-                wtsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Ci, Co), dtype=torch.uint8, device="cuda")
-                lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, dptr(wsp), st)
-                lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 1, dptr(wtsp), st)
+                wsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Co, Ci, 3), dtype=torch.uint8, device="cuda")
+                wtsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Ci, Co, 3), dtype=torch.uint8, device="cuda")
+                lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, 3, dptr(wsp), st)
+                lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 1, 3, dptr(wtsp), st)
             t = {}
-            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(wsp), dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
-            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(wtsp), dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
-            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, cfg[3], dptr(ws), st))
+            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(wsp), 3 if wsp is not None else 0, None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
+            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(wtsp), 3 if wtsp is not None else 0, None, dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
+            t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, 3 if cfg[3] else 0, None, None, dptr(ws), st))
             if ACCURACY:   # max error / max |exact| against fp64 on two samples
                 if ref is None:
                     xd, dyd, wd = x[:2].double(), dy[:2].double(), w.double()

@@ -18,7 +18,7 @@ sp = lambda s: ctypes.c_void_p(s.cuda_stream)
 
 def gemm(s, n=4):
     for _ in range(n):
-        lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, 0, dptr(ws), sp(s))
+        lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, 0, None, None, dptr(ws), sp(s))
 def mem(s, n=8):
     for _ in range(n):
         lib.paradis_channel_norm_bwd(dptr(ga), dptr(a), None, dptr(w), dptr(mean), dptr(rstd), dptr(gx), None, dptr(gw),

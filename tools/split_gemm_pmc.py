@@ -14,10 +14,10 @@ B, P, Co, Ci = 32, 2048, 1024, 1024
 w = torch.randn(Co, Ci, device="cuda") / 32
 x = torch.randn(B, Ci, P, device="cuda")
 y = torch.empty(B, Co, P, device="cuda")
-wsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Co, Ci), dtype=torch.uint8, device="cuda")
+wsp = torch.empty(lib.paradis_pw_gemm_split_bytes(Co, Ci, 3), dtype=torch.uint8, device="cuda")
 st = stream_ptr()
-lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, dptr(wsp), st)
+lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, 3, dptr(wsp), st)
 for _ in range(20):
-    assert lib.paradis_pw_gemm_fwd(dptr(w), None, dptr(wsp), dptr(x), None, None, None, None, 0, None, dptr(y),
+    assert lib.paradis_pw_gemm_fwd(dptr(w), None, dptr(wsp), 3, None, dptr(x), None, None, None, None, 0, None, dptr(y),
                                    None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st) == 0
 torch.cuda.synchronize()
