@@ -809,16 +809,19 @@ __device__ __forceinline__ void split_unscale(f32x16 (&acc)[2][2], float inv_a, 
 //   (sched_group_barrier: the VALU work issues in the shadow of the MFMAs of the same wave)  ->
 //   ds_write of t+1  ->  s_waitcnt vmcnt(8): the DMA has landed, the loads of t+2 stay in flight.
 //
-#ifndef SPLIT_ASTAGES
-#define SPLIT_ASTAGES 2   // weight-image ring depth (2: DMA one tile ahead, 48 KiB, 3 WGs/CU; 4: three ahead, 72 KiB, 2 WGs/CU)
+// weight-image ring depth per scheme (stages; the DMA runs stages - 1 tiles ahead).  bf16x3: 2 (48 KiB,
+// 3 WGs/CU; 4 stages = 72 KiB, 2 WGs/CU measured -2 %).  f16x2: its 8 KiB stages make a deeper ring free.
+#ifndef SPLIT_ASTAGES_F16
+#define SPLIT_ASTAGES_F16 2
 #endif
+constexpr int split_astages(int np) { return np == 2 ? SPLIT_ASTAGES_F16 : 2; }
 template <int NP>
-__global__ void __launch_bounds__(256, SPLIT_ASTAGES == 2 ? 3 : 2)
+__global__ void __launch_bounds__(256, 3)
 pw_gemm_split_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int SIMG = simg(NP);                     // (shadows the bf16 constant)
-  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 activation stages][SIMG] | [SPLIT_ASTAGES weight stages][SIMG]
-  constexpr int SA = SPLIT_ASTAGES, DA = SA - 1;     // weight ring depth, DMA distance in tiles
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 activation stages][SIMG] | [SA weight stages][SIMG]
+  constexpr int SA = split_astages(NP), DA = SA - 1;     // weight ring depth, DMA distance in tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -1154,7 +1157,7 @@ int launch_gemm(const GemmArgs& g, int grid, hipStream_t st) {
                     : launch_gemm_bk<A_KC, B_KC, 16>(g, grid, st);
 }
 
-constexpr size_t split_lds(int np) { return (size_t)(2 + SPLIT_ASTAGES) * simg(np) * 16; }
+constexpr size_t split_lds(int np) { return (size_t)(2 + split_astages(np)) * simg(np) * 16; }
 constexpr size_t split_lds_wgrad(int np) { return (size_t)2 * 2 * simgp(np) * 16; }
 constexpr int AMAX_WORDS = PARADIS_AMAX_PARTIALS;
 // f16x2 weight image: the planes, then 16 bytes ([0] = bits of max |W|), then the amax partials of W
