@@ -66,7 +66,9 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
                           const float* sin_lat, const float* cos_lat, const float* lon,
                           int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs, int64_t o_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
-                          int mode, int flags, void* workspace, void* stream);
+                          int mode, int flags, void* workspace,
+                          uint32_t* out_amax /* optional amax side output, see "amax side outputs" */,
+                          void* stream);
 /* gfield [B,K,H,W] (batch stride gf_bs), gu/gv with batch stride guv_bs.
  * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes. */
 size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
@@ -82,7 +84,7 @@ int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
  * encoder's GeoCyclicPadding(3)+Conv2d(groups=C) (reference model/paradis.py:189-190):
  * k x k per-channel stencil on the virtual geocyclic halo. w [C,k,k]; bias [C] or NULL; k odd, 1..11. */
 int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
-                           int B, int C, int H, int W, int k, void* stream);
+                           int B, int C, int H, int W, int k, uint32_t* y_amax /* optional */, void* stream);
 int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx,
                              int B, int C, int H, int W, int k, void* stream);
 size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k);
@@ -121,6 +123,11 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  * contiguous floats (block stride bs); the tensor's maximum is the (unsigned) maximum of the words, a NaN
  * anywhere makes it a NaN pattern.  One read pass, no atomics, no pre-zeroing. */
 int paradis_amax_partials(const float* x, int B, int64_t inner, int64_t bs, uint32_t* partials, void* stream);
+/* amax side outputs: the kernels that produce most GEMM operands (pw_gemm_fwd / dgrad epilogues, channel_norm_fwd,
+ * dwconv_geo_fwd, act_bwd, sl_advect_fwd) take an optional uint32_t[PARADIS_AMAX_PARTIALS] that the CALLER HAS
+ * ZEROED and add the partial maxima of what they store into it (one atomic per wave): the same words
+ * paradis_amax_partials would produce, or an upper bound (sl_advect_fwd: pole rows before their mean), without
+ * the extra read pass.  NULL = no side output. */
 size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme);   /* bytes of the split image of an [M,K] A operand */
 /* split image of A = W[M,K] (transpose 0; out: split_bytes(M,K,scheme)) or of A = W^T (transpose 1; out:
  * split_bytes(K,M,scheme)) from row-major W[M,K]; scheme = PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 */
@@ -134,14 +141,15 @@ int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy
                          *   with projection, reference model/blocks.py:190-196), M % 4 == 0, or NULL/NULL/0 */
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
-                        int act, void* stream);
+                        int act, uint32_t* y_amax /* optional amax side output of Y */, void* stream);
 /* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend);
  * WTsplit: split image of W^T (paradis_pw_gemm_split_weights(..., transpose=1)), NULL for PARADIS_GEMM_EXACT */
 int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme,
                           const uint32_t* dy_amax /* amax partials of dY: PARADIS_GEMM_F16X2 only */,
                           const float* dY, const float* zpre,
                           const float* addend, float* dX, int B, int M, int K, int N, int64_t dy_bs,
-                          int64_t z_bs, int64_t add_bs, int64_t dx_bs, int act, void* stream);
+                          int64_t z_bs, int64_t add_bs, int64_t dx_bs, int act,
+                          uint32_t* dx_amax /* optional amax side output of dX */, void* stream);
 /* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; gbias[M] = sum_{b,n} dY (optional, NULL to skip; fused
  * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes;
  * a split scheme is used when N % 16 == 0 and the rows are 16-B aligned (the exact kernels run otherwise) */
@@ -156,7 +164,7 @@ int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbi
 int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w, const float* b,
                              float* y, float* mean, float* rstd,
                              int B, int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs,
-                             float eps, void* stream);
+                             float eps, uint32_t* y_amax /* optional */, void* stream);
 size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P);
 /* gx1/gx2 receive the slices of the input gradient (gx2 may be NULL); gw,gb [C].
  * addend1 (optional, [B,C1,P] with batch stride add1_bs) is added to gx1: the gradient that reaches
@@ -189,7 +197,8 @@ int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, const float
 
 /* ---- elementwise / reductions used by the blocks */
 int paradis_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
-int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act, void* stream);
+int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act,
+                    uint32_t* gx_amax /* optional */, void* stream);
 /* out = h + sigmoid(alpha[c]) * (adv - h)          (reference model/paradis.py:239,243) */
 int paradis_gated_blend_fwd(const float* h, const float* adv, const float* alpha, float* out,
                             int B, int C, int P, void* stream);

@@ -518,7 +518,7 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
                                             const float* __restrict__ v, VelCursor& vc, float (&qu)[ADV_PF],
                                             float (&qv)[ADV_PF], const float* __restrict__ sin_lat,
                                             const float* __restrict__ cos_lat, float lonc, const AdvGeom& g,
-                                            int wave, unsigned lane, bool fill_halo) {
+                                            int wave, unsigned lane, bool fill_halo, float& am) {
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;
   const int H = g.H, Hp = H + 2 * p, tid = threadIdx.x;
   // halo columns (p left, p + XR right) and the p mirrored rows beyond each pole are copies of interior
@@ -557,6 +557,7 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
       float acc = XR ? sample_wide<MODE>(cur, ix, iy, WS, WSf) : sample_whole<MODE>(cur, ix, iy, Hp, WS, Hpf, WSf);
       if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
       ADV_ST(acc, &srow(O + y * W)[lane]);
+      am = amax_acc(am, acc);
     }
   };
   // Two register sets that swap roles (qu/qv -> ru/rv -> qu/qv): a load never targets a register whose old
@@ -576,7 +577,7 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
                     const float* __restrict__ v, float* __restrict__ out,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lon, int K, AdvGeom g, int64_t f_bs, int64_t uv_bs,
-                    int64_t o_bs, int planes, int chunk) {
+                    int64_t o_bs, int planes, int chunk, uint32_t* __restrict__ out_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;   // WS: window row stride
   const int H = g.H, P = H * W, Hp = H + 2 * p;
@@ -597,6 +598,7 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
   const float lonc = lon_cells(lon[lane], g);
   float* cur = smem;
   float* nxt = smem + Hp * WS;
+  float am = 0.f;
   {   // the first plane of the chunk is staged through registers, halo included
     Window w{0, 0, Hp, WS};
     stage_window(cur, field + (int64_t)b * f_bs + (int64_t)k * P, w, H, W, p, false, 0.f, 0.f, 256);
@@ -613,10 +615,11 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
     const bool has_next = plane + 1 < last;
     const int64_t next_off = has_next ? (int64_t)nb * f_bs + (int64_t)nk * P : 0;
     row64_plane<MODE, XR>(cur, nxt, field, next_off, has_next, out + (int64_t)b * o_bs + (int64_t)k * P, u, v, vc,
-                          qu, qv, sin_lat, cos_lat, lonc, g, wave, lane, plane != first);
+                          qu, qv, sin_lat, cos_lat, lonc, g, wave, lane, plane != first, am);
     float* t = cur; cur = nxt; nxt = t;
     b = nb; k = nk;
   }
+  if (out_amax) amax_flush(am, out_amax);
 }
 
 template <int MODE, bool WHOLE, int NTH>
@@ -626,11 +629,12 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
                      const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                      const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x,
-                     int tiles, int vec4) {
+                     int tiles, int vec4, uint32_t* __restrict__ out_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
   const int tid = threadIdx.x, wave = tid >> 6;
+  float am = 0.f;   // (pole rows: the values before the row mean - an upper bound of what is stored)
   const int plane = WHOLE ? blockIdx.x : blockIdx.x / tiles;
   const int tile = WHOLE ? 0 : blockIdx.x - plane * tiles;
   const int b = plane / K, k = plane - b * K;
@@ -728,6 +732,7 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
         if (i < npts) {
           if (i < W || i >= lastrow0) pole_out[i < W ? i : W + i - lastrow0] = acc;
           else O[i] = acc;
+          am = amax_acc(am, acc);
         }
       }
     }
@@ -754,9 +759,12 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
         const int nidx = (ty0 + it.yl) * W + tx0 + it.xl;
         nu = U[nidx]; nv = V[nidx]; nsa = sin_lat[nidx]; nca = cos_lat[nidx]; nlo = lon[nidx];
       }
-      O[idx] = point_tiled(cu, cv, csa, cca, clo);
+      const float acc = point_tiled(cu, cv, csa, cca, clo);
+      O[idx] = acc;
+      am = amax_acc(am, acc);
     }
   }
+  if (out_amax) amax_flush(am, out_amax);
 }
 
 
@@ -808,7 +816,8 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
                       const float* __restrict__ v, float* __restrict__ out,
                       const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                       const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
-                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x, int tiles) {
+                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x, int tiles,
+                      uint32_t* __restrict__ out_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT, NTH = TILED_THREADS_FWD;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -880,6 +889,7 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
     }
     return acc;
   };
+  float am = 0.f;
   for (int yl0 = tl.rs; yl0 < th; yl0 += tl.rstep * ADV_PF) {
 #pragma unroll
     for (int d = 0; d < ADV_PF; ++d) {
@@ -913,10 +923,14 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
         } else {
           acc = slow_point(ix, iy);
         }
-        if (tl.active) srow(O + y * W + tl.cbase)[tl.lx] = acc;
+        if (tl.active) {
+          srow(O + y * W + tl.cbase)[tl.lx] = acc;
+          am = amax_acc(am, acc);
+        }
       }
     }
   }
+  if (out_amax) amax_flush(am, out_amax);
 }
 
 // ======================================================================================
@@ -1598,7 +1612,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
                                      int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs,
                                      int64_t o_bs, float dt, float min_lat, float min_lon,
                                      float d_lat, float d_lon, int mode, int flags, void* workspace,
-                                     void* stream) {
+                                     uint32_t* out_amax, void* stream) {
   if (int e = check_adv("sl_advect_fwd", B, K, H, W, mode)) return e;
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
@@ -1624,13 +1638,13 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
       const int chunk = ROW64_CHUNK, groups = (planes + chunk - 1) / chunk;
 #define ROW64_FWD(MODE_, XR_)                                                                              \
       hipLaunchKernelGGL((sl_advect_fwd_row64<MODE_, XR_>), dim3(groups), dim3(256), lds, st, field, u, v, out, \
-                         sin_lat, cos_lat, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk)
+                         sin_lat, cos_lat, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk, out_amax)
       if (mode == PARADIS_INTERP_BICUBIC) { if (wide) ROW64_FWD(PARADIS_INTERP_BICUBIC, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BICUBIC, 0); }
       else { if (wide) ROW64_FWD(PARADIS_INTERP_BILINEAR, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BILINEAR, 0); }
 #undef ROW64_FWD
     } else
       ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
-                 (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
+                 (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4, out_amax);
     PD_CHECK_LAUNCH("sl_advect_fwd");
     return 0;
   }
@@ -1659,14 +1673,14 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
     if (mode == PARADIS_INTERP_BICUBIC)
       hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
                          dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
+                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, out_amax);
     else
       hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
                          dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
+                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, out_amax);
   } else {
     ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
-               cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
+               cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4, out_amax);
   }
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, out, planes, K, H, W, o_bs);
   PD_CHECK_LAUNCH("sl_advect_fwd(tiled)");

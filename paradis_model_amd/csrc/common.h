@@ -101,6 +101,18 @@ __device__ __forceinline__ void geo_for_each_alias(int y, int x, int H, int W, i
   }
 }
 
+// ---- amax side output of producer kernels (feeds the f16x2 GEMM scheme): a thread keeps the running
+// maximum of |v| over what it stores (one v_max_f32 with the |.| modifier per value; a NaN is skipped - it
+// poisons the consumer's products by itself - an Inf is kept); amax_flush (EVERY lane of the wave) folds the
+// wave and adds the bit pattern with one atomic into one of the PARADIS_AMAX_PARTIALS words the caller has
+// zeroed (bit patterns of non-negative floats order like unsigned integers).
+__device__ __forceinline__ float amax_acc(float m, float v) { return fmaxf(m, fabsf(v)); }
+__device__ __forceinline__ void amax_flush(float m, uint32_t* __restrict__ partials) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(partials + (blockIdx.x & (PARADIS_AMAX_PARTIALS - 1)), __float_as_uint(m));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -140,7 +140,8 @@ gbias_finish_kernel(const float* __restrict__ T1, const float* __restrict__ T2,
 template <bool BWD>
 __global__ void __launch_bounds__(256)
 act_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ out,
-           int64_t n, int act, bool vec) {
+           int64_t n, int act, bool vec, uint32_t* __restrict__ out_amax) {
+  float am = 0.f;
   if (vec) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -154,11 +155,16 @@ act_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __r
         o = make_float4(act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act));
       }
       reinterpret_cast<float4*>(out)[i] = o;
+      am = amax_acc(amax_acc(amax_acc(amax_acc(am, o.x), o.y), o.z), o.w);
     }
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-      out[i] = BWD ? gy[i] * act_grad(x[i], act) : act_apply(x[i], act);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const float o = BWD ? gy[i] * act_grad(x[i], act) : act_apply(x[i], act);
+      out[i] = o;
+      am = amax_acc(am, o);
+    }
   }
+  if (out_amax) amax_flush(am, out_amax);
 }
 
 __global__ void __launch_bounds__(256)
@@ -337,18 +343,18 @@ extern "C" int paradis_act_fwd(const float* x, float* y, int64_t n, int act, voi
   if (n == 0) return 0;
   const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(y);
   hipLaunchKernelGGL(act_kernel<false>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
-                     (hipStream_t)stream, nullptr, x, y, n, act, vec);
+                     (hipStream_t)stream, nullptr, x, y, n, act, vec, (uint32_t*)nullptr);
   PD_CHECK_LAUNCH("act_fwd");
   return 0;
 }
 
 extern "C" int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act,
-                               void* stream) {
+                               uint32_t* gx_amax, void* stream) {
   PD_REQUIRE(n >= 0 && act >= 0 && act <= 2, "act_bwd: bad arguments");
   if (n == 0) return 0;
   const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
   hipLaunchKernelGGL(act_kernel<true>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
-                     (hipStream_t)stream, gy, x, gx, n, act, vec);
+                     (hipStream_t)stream, gy, x, gx, n, act, vec, gx_amax);
   PD_CHECK_LAUNCH("act_bwd");
   return 0;
 }

@@ -29,7 +29,7 @@ template <int MAXV, int NPXF>
 __global__ void __launch_bounds__(1024)
 channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
                         float* __restrict__ y, float* __restrict__ mean_out,
-                        float* __restrict__ rstd_out, int P, int tiles, float eps) {
+                        float* __restrict__ rstd_out, int P, int tiles, float eps, uint32_t* __restrict__ y_amax) {
   constexpr int G = 1024 / NPXF;
   __shared__ float red[G][NPXF];
   __shared__ float stat[2][NPXF];
@@ -92,18 +92,28 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   }
   __syncthreads();
   const float rstd = stat[1][lane];
-  if (!live) return;
-  float* yb = y + (int64_t)b * C * P + p;
-  if (MAXV > 0) {
+  float am = 0.f;
+  if (live) {
+    float* yb = y + (int64_t)b * C * P + p;
+    if (MAXV > 0) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = grp + G * i;
-      if (c < C) yb[(int64_t)c * P] = (vals[i] - mean) * rstd * w[c] + bias[c];
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = grp + G * i;
+        if (c < C) {
+          const float v = (vals[i] - mean) * rstd * w[c] + bias[c];
+          yb[(int64_t)c * P] = v;
+          am = amax_acc(am, v);
+        }
+      }
+    } else {
+      for (int c = grp; c < C; c += G) {
+        const float v = (s.row(b, c, P)[p] - mean) * rstd * w[c] + bias[c];
+        yb[(int64_t)c * P] = v;
+        am = amax_acc(am, v);
+      }
     }
-  } else {
-    for (int c = grp; c < C; c += G)
-      yb[(int64_t)c * P] = (s.row(b, c, P)[p] - mean) * rstd * w[c] + bias[c];
   }
+  if (y_amax) amax_flush(am, y_amax);
 }
 
 // gx = rstd * ( g*w - mean_c(g*w) - xhat * sum_c(g*w*xhat)/(C-1) )
@@ -422,7 +432,7 @@ extern "C" void paradis_debug_set_norm_bwd_reread(int on) { g_norm_bwd_reread = 
 extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
                                         const float* b, float* y, float* mean, float* rstd, int B,
                                         int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps,
-                                        void* stream) {
+                                        uint32_t* y_amax, void* stream) {
   if (int e = check_norm("channel_norm_fwd", B, C1, C2, P)) return e;
   PD_REQUIRE(C2 == 0 || x2 != nullptr, "channel_norm_fwd: x2 missing");
   if (B == 0) return 0;
@@ -434,18 +444,18 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
     const int tiles = (P + 31) / 32;
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 32 * 4)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
     else
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
   } else {
     const int tiles = (P + NPX - 1) / NPX;
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 16 * 8)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
     else if (C <= 16 * 72)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
     else
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
   }
   PD_CHECK_LAUNCH("channel_norm_fwd");
   return 0;

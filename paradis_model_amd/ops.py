@@ -192,6 +192,42 @@ def _bstride_view(t: Tensor, K: int, H: int, W: int) -> Tuple[Tensor, int]:
     return t.contiguous(), K * H * W
 
 
+# ---------------------------------------------------------------------------
+# amax side outputs (f16x2 GEMM scheme): the kernels that produce most GEMM operands also leave the
+# partial maxima of what they store in a small tensor attached to their output, so the consuming GEMM
+# needs no read pass of its own (ops.amax_partials is the fallback for every other producer).
+# ---------------------------------------------------------------------------
+AMAX_SIDE_OUTPUTS = os.environ.get("PARADIS_AMAX_SIDE", "1") != "0"   # 0: every operand gets its own read pass
+_AMAX_POOL = None      # [rows, AMAX_PARTIALS] zeroed words, handed out row by row (one fill per 256 producers)
+_AMAX_NEXT = 0
+
+
+def _amax_new(device):
+    """Zeroed words for a producer's side output; None when the GEMM scheme does not need them or
+    while tracing (fake tensors carry no side channel)."""
+    global _AMAX_POOL, _AMAX_NEXT
+    if GEMM_SCHEME != GEMM_F16X2 or torch.compiler.is_compiling() or not AMAX_SIDE_OUTPUTS:
+        return None
+    if _AMAX_POOL is None or _AMAX_NEXT == _AMAX_POOL.shape[0] or _AMAX_POOL.device != device:
+        _AMAX_POOL = torch.zeros(256, AMAX_PARTIALS, dtype=torch.int32, device=device)
+        _AMAX_NEXT = 0
+    row = _AMAX_POOL[_AMAX_NEXT]
+    _AMAX_NEXT += 1
+    return row
+
+
+def _amax_attach(t, am):
+    """Remember ``am`` as the amax partials of ``t`` (valid while ``t`` is not modified in place)."""
+    if am is not None:
+        t._paradis_amax = (t._version, am)
+    return t
+
+
+def _amax_lookup(t):
+    ent = getattr(t, "_paradis_amax", None) if t is not None else None
+    return ent[1] if ent is not None and ent[0] == t._version else None
+
+
 @_define(f"sl_advect(Tensor field, Tensor u, Tensor v, Tensor sin_lat, Tensor cos_lat, Tensor lon, {_ADV_GEOM}) -> Tensor")
 def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     _f32(field, u, v)
@@ -204,10 +240,11 @@ def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode
         u_bs = K * H * W
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+    am = _amax_new(field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
               dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
-              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), stream_ptr())
-    return out
+              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), dptr(am), stream_ptr())
+    return _amax_attach(out, am)
 
 
 @_fake("sl_advect")
@@ -268,10 +305,11 @@ def _sl_advect_vel(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, m
     P = K * H * W
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+    am = _amax_new(field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(vel[:, :K]), dptr(vel[:, K:]), dptr(out),
               dptr(sl), dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), stream_ptr())
-    return out
+              flags, dptr(ws), dptr(am), stream_ptr())
+    return _amax_attach(out, am)
 
 
 @_fake("sl_advect_vel")
@@ -366,9 +404,10 @@ def _dwconv_geo(x, weight, bias):
     assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
     w = weight.contiguous()
     y = torch.empty_like(x)
-    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, stream_ptr()),
+    am = _amax_new(x.device)
+    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, dptr(am), stream_ptr()),
           "dwconv_geo_fwd")
-    return y
+    return _amax_attach(y, am)
 
 
 @_fake("dwconv_geo")
@@ -566,9 +605,11 @@ def _channel_norm(x1, x2, weight, bias, eps):
     y = torch.empty(B, C1 + C2, H, W, dtype=x1.dtype, device=x1.device)
     mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
     rstd = torch.empty_like(mean)
+    am = _amax_new(x1.device)
     check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y), dptr(mean),
-                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, stream_ptr()), "channel_norm_fwd")
-    return y, mean, rstd
+                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, dptr(am), stream_ptr()),
+          "channel_norm_fwd")
+    return _amax_attach(y, am), mean, rstd
 
 
 @_fake("channel_norm")
@@ -878,8 +919,12 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool) -> Tensor:
 @_define("amax_partials(Tensor x) -> Tensor")
 def _amax_partials(x):
     """int32[AMAX_PARTIALS]: bit patterns of partial maxima of |x| ([B,C,H,W], channel-sliced views allowed);
-    the f16x2 GEMMs take the maximum of the words as the tensor's largest magnitude.  One read pass."""
+    the f16x2 GEMMs take the maximum of the words as the tensor's largest magnitude.  One read pass -
+    or none, when the kernel that produced ``x`` left the words behind (amax side outputs)."""
     _f32(x)
+    have = _amax_lookup(x)
+    if have is not None:       # left behind by the kernel that produced x
+        return have
     x, x_bs = _plane_view(x)
     B, C, H, W = x.shape
     out = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
@@ -912,6 +957,7 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         ``x`` already is the producer's d(pre-activation).
     """
     _f32(x, weight, bias, bmap, residual, m8, pw)
+    x_side = _amax_lookup(x)
     x, x_bs = _plane_view(x)
     B, Ci, H, W = x.shape
     Co = weight.shape[0]
@@ -936,8 +982,12 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
     if GEMM_SCHEME != GEMM_EXACT:
         wsp = _split_image(weight, Co, Ci, False)   # split planes in tile order
         if GEMM_SCHEME == GEMM_F16X2:
-            x_amax = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
-            check(lib.paradis_amax_partials(dptr(x), B, Ci * P, x_bs, dptr(x_amax), stream_ptr()), "amax_partials")
+            if x_side is not None:
+                x_amax = x_side
+            else:
+                x_amax = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
+                check(lib.paradis_amax_partials(dptr(x), B, Ci * P, x_bs, dptr(x_amax), stream_ptr()),
+                      "amax_partials")
     else:
         w2 = weight.reshape(Co, Ci).contiguous()
         if Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
@@ -948,11 +998,12 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         w2 = weight.reshape(Co, Ci)
         if not w2.is_contiguous():
             w2 = w2.contiguous()
+    y_am = _amax_new(x.device) if defer_act_grad else None   # y feeds the next GEMM directly in a deferred chain
     _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), GEMM_SCHEME,
               dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
               dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
-              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
-    return y, z, x_amax
+              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, dptr(y_am), stream_ptr())
+    return _amax_attach(y, y_am), z, x_amax
 
 
 @_fake("pointwise")
@@ -968,8 +1019,9 @@ def _act_backward(gy, z, act):
     _f32(gy, z)
     gy, z = gy.contiguous(), z.contiguous()
     dz = torch.empty_like(gy)
-    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, stream_ptr()), "act_bwd")
-    return dz
+    am = _amax_new(gy.device)
+    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, dptr(am), stream_ptr()), "act_bwd")
+    return _amax_attach(dz, am)
 
 
 @_fake("act_backward")
@@ -995,11 +1047,12 @@ def _pw_gemm_dgrad(dz, weight, zmul, x_act, dz_amax):
         dz_amax = _amax_partials(dz)
     if zmul is not None:
         zmul = zmul.contiguous()
+    gx_am = _amax_new(dz.device) if x_act != 0 else None   # deferred chain: gx is the previous layer's dz
     _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), GEMM_SCHEME,
               dptr(dz_amax) if GEMM_SCHEME == GEMM_F16X2 else None, dptr(dz),
               dptr(zmul) if x_act != 0 else None, None, dptr(gx), B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P,
-              x_act, stream_ptr())
-    return gx
+              x_act, dptr(gx_am), stream_ptr())
+    return _amax_attach(gx, gx_am)
 
 
 @_fake("pw_gemm_dgrad")

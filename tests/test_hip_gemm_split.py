@@ -296,3 +296,59 @@ def test_split_extreme_magnitudes(ops):
         ys, ye = _fwd_only(ops, True, base_x, w), _fwd_only(ops, False, base_x, w)
         assert torch.equal(torch.isfinite(ys), torch.isfinite(ye)), bad
         assert not torch.isfinite(ys[0, 5]).any() and torch.isfinite(ys[0, :5]).all()
+
+
+def test_amax_side_outputs(ops):
+    """Producer kernels leave the partial maxima of what they store attached to their output (f16x2
+    scheme): equal to a read pass (an upper bound for the advection's pole rows), picked up by
+    ops.amax_partials without a launch, and dropped when the tensor is modified in place."""
+    from tests._util import make_grid
+    keep = ops.GEMM_SCHEME
+    ops.GEMM_SCHEME = ops.GEMM_F16X2
+    try:
+        g = torch.Generator().manual_seed(31)
+        B, C, H, W = 2, 64, 32, 64
+
+        def amax_of(words):
+            return float(words.max().view(1).view(torch.float32))
+
+        def check(t, exact=True):
+            words = ops._amax_lookup(t)
+            assert words is not None, "no side output attached"
+            got, want = amax_of(words), float(t.detach().abs().max())
+            assert got == want if exact else (want <= got <= 4 * want), (got, want)
+            assert ops._amax_partials(t) is words      # no read pass
+            return words
+
+        x = torch.randn(B, C, H, W, generator=g).cuda()
+        w = (torch.randn(C, generator=g) + 1).cuda()
+        b = torch.randn(C, generator=g).cuda()
+        check(ops.channel_norm(x, w, b, 1e-5))
+        dw = torch.randn(C, 1, 5, 5, generator=g).cuda()
+        check(ops.dwconv_geo(x, dw, b))
+        pw = (torch.randn(48, C, generator=g) * 0.1).cuda().requires_grad_(True)
+        xin = x.clone().requires_grad_(True)
+        y, zpre = ops.pointwise(xin, pw, None, None, None, "SiLU", defer_act_grad=True)   # chained CLinear layers
+        check(y)
+        assert ops._amax_lookup(ops.pointwise(xin, pw, None, None, None, "SiLU")) is None   # (only then)
+        _, lg, og = make_grid(H, W, False)
+        geom = ops.AdvectGeometry(lg, og)
+        vel = (torch.randn(B, 2 * C, H, W, generator=g) * 0.3).cuda()
+        check(ops.sl_advect_vel(x, vel, geom, 0.05, "bicubic"), exact=False)
+        # backward producers: act_backward (dz of the GEMM above) and the dgrad epilogue
+        gy = torch.randn(B, 48, H, W, generator=g).cuda()
+        dz = ops._act_backward(gy, y.detach(), 1)
+        check(dz)
+        gx = ops._pw_gemm_dgrad(dz, pw.detach(), x, 1, None)     # deferred chain: gx = W^T dz * act'(x_pre)
+        check(gx)
+        # an in-place update invalidates the attachment
+        gx.mul_(2.0)
+        assert ops._amax_lookup(gx) is None
+        assert amax_of(ops._amax_partials(gx)) == float(gx.abs().max())
+        # ragged GEMM tiles (guarded epilogue path) and a shape smaller than one tile
+        for (Co, Ci, h, wd) in ((97, 186, 9, 20), (7, 10, 4, 8)):
+            xs = torch.randn(1, Ci, h, wd, generator=g).cuda()
+            ws = torch.randn(Co, Ci, generator=g).cuda()
+            check(ops.pointwise(xs, ws, None, None, None, "SiLU", defer_act_grad=True)[0])
+    finally:
+        ops.GEMM_SCHEME = keep

@@ -1,3 +1,5 @@
+"""Diagnostic: 200 launches of the forward advection kernel at 32x64, B=32, K=768 after a clock warm-up
+(for rocprofv3 --kernel-trace / --pmc: tools/adv_trace.sh).  argv[1] = velocity scale (default 0.05)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paradis_model_amd import ops
