@@ -78,7 +78,11 @@ int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
                           int B, int K, int H, int W, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                           int64_t gf_bs, int64_t guv_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
-                          int mode, int flags, void* workspace, void* stream);
+                          int mode, int flags, void* workspace,
+                          uint32_t* gf_amax, uint32_t* guv_amax /* optional amax side outputs of gfield and of
+                          (gu, gv) together; whole-plane schedules only: paradis_sl_advect_bwd_has_amax */,
+                          void* stream);
+int paradis_sl_advect_bwd_has_amax(int H, int W, int mode, int flags);
 
 /* ---- a7 (depthwise half of SepConv, reference model/blocks.py:101-113) and the static
  * encoder's GeoCyclicPadding(3)+Conv2d(groups=C) (reference model/paradis.py:189-190):
@@ -124,7 +128,8 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  * anywhere makes it a NaN pattern.  One read pass, no atomics, no pre-zeroing. */
 int paradis_amax_partials(const float* x, int B, int64_t inner, int64_t bs, uint32_t* partials, void* stream);
 /* amax side outputs: the kernels that produce most GEMM operands (pw_gemm_fwd / dgrad epilogues, channel_norm_fwd,
- * dwconv_geo_fwd, act_bwd, sl_advect_fwd) take an optional uint32_t[PARADIS_AMAX_PARTIALS] that the CALLER HAS
+ * dwconv_geo_fwd, act_bwd, sl_advect_fwd, sl_advect_bwd [gfield; gu and gv], channel_norm_bwd [gx1],
+ * gated_blend_bwd [gadv]) take an optional uint32_t[PARADIS_AMAX_PARTIALS] that the CALLER HAS
  * ZEROED and add the partial maxima of what they store into it (one atomic per wave): the same words
  * paradis_amax_partials would produce, or an upper bound (sl_advect_fwd: pole rows before their mean), without
  * the extra read pass.  NULL = no side output. */
@@ -174,7 +179,8 @@ int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2, 
                              const float* mean, const float* rstd, float* gx1, float* gx2,
                              float* gw, float* gb, int B, int C1, int C2, int P,
                              int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs, int64_t gx2_bs,
-                             const float* addend1, int64_t add1_bs, void* workspace, void* stream);
+                             const float* addend1, int64_t add1_bs, void* workspace,
+                             uint32_t* gx1_amax /* optional amax side output of gx1 */, void* stream);
 
 /* ---- a9: GlobalBias map (reference model/blocks.py:188-196).
  * m8[Cin,H,W] = sum_r A[c,r] U[r,h] V[r,w];  map[Co,H,W] = Pw[Co,Cin] m8 (or map = m8 if Pw NULL). */
@@ -205,7 +211,7 @@ int paradis_gated_blend_fwd(const float* h, const float* adv, const float* alpha
 size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P);
 int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv, const float* alpha,
                             float* gh, float* gadv, float* galpha, int B, int C, int P,
-                            void* workspace, void* stream);
+                            void* workspace, uint32_t* gadv_amax /* optional amax side output of gadv */, void* stream);
 /* gmap[C,P] = sum_b dz[b,C,P] (NULL to skip), gbias[C] = sum_{b,p} dz (NULL to skip) */
 int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
                        int64_t dz_bs, void* stream);

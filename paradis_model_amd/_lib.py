@@ -35,7 +35,8 @@ SIGNATURES = {
     "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, I, P, P, P]),
     "paradis_sl_advect_ws_bytes": (S, [I, I, I, I]),
     "paradis_sl_advect_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L,
-                                  F, F, F, F, F, I, I, P, P]),
+                                  F, F, F, F, F, I, I, P, P, P, P]),
+    "paradis_sl_advect_bwd_has_amax": (I, [I, I, I, I]),
     "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_dwconv_geo_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_wgrad_ws_bytes": (S, [I, I, I, I, I]),
@@ -60,7 +61,7 @@ SIGNATURES = {
     "paradis_pw_gemm_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, I, P, P, P, P]),
     "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P, P]),
     "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),
-    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P]),
+    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P, P]),
     "paradis_global_bias_map_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "paradis_global_bias_map_bwd_ws_bytes": (S, [I, I, I, I, I]),
     "paradis_global_bias_map_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
@@ -68,7 +69,7 @@ SIGNATURES = {
     "paradis_act_bwd": (I, [P, P, P, L, I, P, P]),
     "paradis_gated_blend_fwd": (I, [P, P, P, P, I, I, I, P]),
     "paradis_gated_blend_bwd_ws_bytes": (S, [I, I, I]),
-    "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
+    "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
     "paradis_bias_grads": (I, [P, P, P, I, I, I, L, P]),
     "paradis_add": (I, [P, P, P, L, P]),
     "paradis_add_bcast": (I, [P, P, P, L, I, P]),

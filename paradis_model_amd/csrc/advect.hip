@@ -1039,8 +1039,10 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
                     float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lon, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
-                    int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int vec4) {
+                    int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int vec4, uint32_t* __restrict__ gf_amax,
+                    uint32_t* __restrict__ guv_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float amv = 0.f, amf = 0.f;   // amax side outputs of (gu, gv) and of gfield
   constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0, W = 64;
   const int H = g.H, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
   const int tid = threadIdx.x;
@@ -1128,9 +1130,11 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
         departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
         srow(GU + y * W)[lane] = guv;
         srow(GV + y * W)[lane] = gvv;
+        amv = amax_acc(amax_acc(amv, guv), gvv);
       }
     }
   }
+  if (guv_amax) amax_flush(amv, guv_amax);
   __syncthreads();
   // fold the halo back: every source cell sums its aliases (adjoint of the a1 map: its own cell, the
   // lon-wrap copies of the p edge columns, and for rows next to a pole the mirrored row shifted by
@@ -1156,7 +1160,9 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
     float val = (float)((double)s * inv);
     if (y == 0 || y == H - 1) val = wave_sum(val) * (1.0f / 64.0f);
     srow(GF + y * W)[lane] = val;
+    amf = amax_acc(amf, val);
   }
+  if (gf_amax) amax_flush(amf, gf_amax);
 }
 
 template <int MODE, bool WHOLE, int NTH>
@@ -1168,8 +1174,9 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
                      const float* __restrict__ lon, const float* __restrict__ fmeans,
                      const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles,
-                     int vec4) {
+                     int vec4, uint32_t* __restrict__ gf_amax, uint32_t* __restrict__ guv_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float amv = 0.f;   // amax side output of (gu, gv): whole-plane schedule only
   constexpr int NT = Interp<MODE>::NT;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -1291,7 +1298,9 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
     GU[idx] = guv;
     GV[idx] = gvv;
+    amv = amax_acc(amax_acc(amv, guv), gvv);
   }
+  if (WHOLE && guv_amax) amax_flush(amv, guv_amax);
   __syncthreads();
   const double inv = (double)inv_scale;
   if (WHOLE) {
@@ -1310,7 +1319,12 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
       for (int x = tid & 63; x < W; x += 64) row[x] = m;
     }
     __syncthreads();
-    for (int i = tid; i < P; i += NTH) GF[i] = win[i];
+    float amf = 0.f;
+    for (int i = tid; i < P; i += NTH) {
+      GF[i] = win[i];
+      amf = amax_acc(amf, win[i]);
+    }
+    if (gf_amax) amax_flush(amf, gf_amax);
   } else {
     // flush the window once: one global float atomic per touched cell instead of 16 per point
     // (consecutive lanes -> consecutive cells: the 16 atomics per 64-byte line of one wave-instruction
@@ -1556,6 +1570,7 @@ int reserve_lds(K kernel, const char* what) {
 
 // `flags` of the C ABI (include/paradis_hip.h, PARADIS_ADVECT_*): schedule choice and window halo are
 // per-call arguments, the library keeps no mutable state
+size_t bwd_whole_lds(size_t cells) { return (3 * ((cells + 1) & ~(size_t)1) + 24) * sizeof(float); }   // 64-bit accumulators + field
 bool use_tiled(size_t whole_bytes, int flags) {
   if (flags & PARADIS_ADVECT_TILED) return true;
   return whole_bytes > WHOLE_LDS_LIMIT;
@@ -1687,31 +1702,41 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   return 0;
 }
 
+// 1 when sl_advect_bwd can fill its amax side outputs for this grid (whole-plane schedules: the tiled ones finish
+// gfield with global atomics across workgroups)
+extern "C" int paradis_sl_advect_bwd_has_amax(int H, int W, int mode, int flags) {
+  const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1;
+  return H >= 1 && W >= 1 && !use_tiled(bwd_whole_lds((size_t)(H + 2 * p) * (W + 2 * p)), flags);
+}
+
 extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
                                      const float* v, float* gfield, float* gu, float* gv,
                                      const float* sin_lat, const float* cos_lat, const float* lon,
                                      int B, int K, int H, int W, int64_t go_bs, int64_t f_bs,
                                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, float dt,
                                      float min_lat, float min_lon, float d_lat, float d_lon, int mode,
-                                     int flags, void* workspace, void* stream) {
+                                     int flags, void* workspace, uint32_t* gf_amax, uint32_t* guv_amax,
+                                     void* stream) {
   if (int e = check_adv("sl_advect_bwd", B, K, H, W, mode)) return e;
+  PD_REQUIRE((gf_amax == nullptr && guv_amax == nullptr) || paradis_sl_advect_bwd_has_amax(H, W, mode, flags),
+             "sl_advect_bwd: amax side outputs exist for the whole-plane schedules only (paradis_sl_advect_bwd_has_amax)");
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
   AdvGeom g = make_geom(H, W, p, dt, min_lat, min_lon, d_lat, d_lon);
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * K, P = H * W;
-  auto lds_of = [](size_t cells) { return (3 * ((cells + 1) & ~(size_t)1) + 24) * sizeof(float); };
+  auto lds_of = [](size_t cells) { return bwd_whole_lds(cells); };
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && (p % 2 == 0) &&
                    (reinterpret_cast<uintptr_t>(field) & 15) == 0;
   const size_t whole = lds_of((size_t)(H + 2 * p) * (W + 2 * p));
   if (!use_tiled(whole, flags)) {
     if (use_row64(W, flags))
       ADV_LAUNCH_ROW64(sl_advect_bwd_row64, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
-                       K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, vec4);
+                       K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, vec4, gf_amax, guv_amax);
     else
       ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
                  cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
-                 gf_bs, guv_bs, 0, 1, 1, vec4);
+                 gf_bs, guv_bs, 0, 1, 1, vec4, gf_amax, guv_amax);
     PD_CHECK_LAUNCH("sl_advect_bwd");
     return 0;
   }
@@ -1757,7 +1782,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   } else {
     ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
                gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-               f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4);
+               f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4, (uint32_t*)nullptr, (uint32_t*)nullptr);
   }
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");

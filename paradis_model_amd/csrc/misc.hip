@@ -221,18 +221,20 @@ __global__ void __launch_bounds__(256)
 gated_blend_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ h,
                        const float* __restrict__ adv, const float* __restrict__ alpha,
                        float* __restrict__ gh, float* __restrict__ gadv, float* __restrict__ partial,
-                       int C, int P) {
+                       int C, int P, uint32_t* __restrict__ gadv_amax) {
   __shared__ float red[4];
   const int c = blockIdx.x % C;
   const float g = 1.0f / (1.0f + expf(-alpha[c]));
   const int64_t base = (int64_t)blockIdx.x * P;
-  float acc = 0.f;
+  float acc = 0.f, am = 0.f;
   for (int p = threadIdx.x; p < P; p += 256) {
     const float go = gout[base + p];
     gh[base + p] = (1.0f - g) * go;
     gadv[base + p] = g * go;
+    am = amax_acc(am, g * go);
     acc += go * (adv[base + p] - h[base + p]);
   }
+  if (gadv_amax) amax_flush(am, gadv_amax);
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -386,14 +388,14 @@ extern "C" size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P) {
 
 extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv,
                                        const float* alpha, float* gh, float* gadv, float* galpha, int B,
-                                       int C, int P, void* workspace, void* stream) {
+                                       int C, int P, void* workspace, uint32_t* gadv_amax, void* stream) {
   PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "gated_blend_bwd: bad shape");
   PD_REQUIRE(workspace != nullptr, "gated_blend_bwd: workspace required");
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   if (B > 0)
     hipLaunchKernelGGL(gated_blend_bwd_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0, st, gout, h,
-                       adv, alpha, gh, gadv, partial, C, P);
+                       adv, alpha, gh, gadv, partial, C, P, gadv_amax);
   hipLaunchKernelGGL(gated_blend_finish, dim3((C + 255) / 256), dim3(256), 0, st, partial, alpha, galpha, B, C);
   PD_CHECK_LAUNCH("gated_blend_bwd");
   return 0;

@@ -121,8 +121,10 @@ __global__ void __launch_bounds__(1024)
 channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                            float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                           int64_t gbs2, const float* __restrict__ add1, int64_t abs1, int P, int tiles) {
+                           int64_t gbs2, const float* __restrict__ add1, int64_t abs1, int P, int tiles,
+                           uint32_t* __restrict__ gx1_amax) {
   __shared__ float red[2][16][NPX];
+  float am = 0.f;
   __shared__ float stat[2][NPX];
   const int C = s.C1 + s.C2;
   const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPX;
@@ -151,15 +153,20 @@ channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* 
     stat[grp][lane] = t;
   }
   __syncthreads();
-  if (!live) return;
-  const float m1 = stat[0][lane] / (float)C, m2 = stat[1][lane] / (float)(C - 1);
-  for (int c = grp; c < C; c += 16) {
-    const float gh = gyb[(int64_t)c * P] * w[c];
-    const float xh = (s.row(b, c, P)[p] - mean) * rstd;
-    const float v = rstd * (gh - m1 - xh * m2);
-    if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
-    else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
+  if (live) {
+    const float m1 = stat[0][lane] / (float)C, m2 = stat[1][lane] / (float)(C - 1);
+    for (int c = grp; c < C; c += 16) {
+      const float gh = gyb[(int64_t)c * P] * w[c];
+      const float xh = (s.row(b, c, P)[p] - mean) * rstd;
+      const float v = rstd * (gh - m1 - xh * m2);
+      if (c < s.C1) {
+        const float o = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
+        gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = o;
+        am = amax_acc(am, o);
+      } else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
+    }
   }
+  if (gx1_amax) amax_flush(am, gx1_amax);
 }
 
 // gw[c] = sum_{b,p} gy * xhat ; gb[c] = sum_{b,p} gy.  grid (C, chunks): partial[c][chunk][2]
@@ -215,8 +222,10 @@ __global__ void __launch_bounds__(NPB * 32)
 channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                              int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles) {
+                              int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles,
+                              uint32_t* __restrict__ gx1_amax) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][32][NPB] reduce + [C][NPB] xhat
+  float am = 0.f;
   float (*red)[32][NPB] = reinterpret_cast<float (*)[32][NPB]>(lds);
   float* xs = lds + 2 * 32 * NPB;
   const int C = s.C1 + s.C2;
@@ -275,8 +284,11 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
       const float xh = xs[c * NPB + px];
       if (live) {
         const float v = rstd * (g[i] * w[c] - m1 - xh * m2);
-        if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
-        else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
+        if (c < s.C1) {
+          const float o = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
+          gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = o;
+          am = amax_acc(am, o);
+        } else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
       }
       float a = g[i] * xh, d = g[i];       // dead pixels hold zeros
 #pragma unroll
@@ -287,6 +299,7 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
       if (px == 0) { pw[c] = a; pw[C + c] = d; }
     }
   }
+  if (gx1_amax) amax_flush(am, gx1_amax);
 }
 
 // Same work with nothing parked between the two phases: gy and x are streamed twice, the second time
@@ -299,8 +312,10 @@ __global__ void __launch_bounds__(512)
 channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                               int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles) {
+                               int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles,
+                               uint32_t* __restrict__ gx1_amax) {
   constexpr int NPB = 32, G = 16;
+  float am = 0.f;
   __shared__ float red[2][G][NPB];
   const int C = s.C1 + s.C2;
   const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPB;
@@ -358,8 +373,10 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
         const float xh = (xv[j] - mean) * rstd;
         if (live) {
           const float v = rstd * (g * wv[j] - m1 - xh * m2);
-          if (c < s.C1) gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + av[j];
-          else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
+          if (c < s.C1) {
+            gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + av[j];
+            am = amax_acc(am, v + av[j]);
+          } else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
         }
         float a = g * xh, d = g;
 #pragma unroll
@@ -371,6 +388,7 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
       }
     }
   }
+  if (gx1_amax) amax_flush(am, gx1_amax);
 }
 
 // Two-stage reduction of the per-block partial sums in a fixed order (no atomics: bit-reproducible):
@@ -473,7 +491,7 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
                                         float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
                                         int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
                                         int64_t gx2_bs, const float* addend1, int64_t add1_bs,
-                                        void* workspace, void* stream) {
+                                        void* workspace, uint32_t* gx1_amax, void* stream) {
   if (int e = check_norm("channel_norm_bwd", B, C1, C2, P)) return e;
   PD_REQUIRE(workspace != nullptr, "channel_norm_bwd: workspace required");
   const int C = C1 + C2;
@@ -509,16 +527,16 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     }
     if (g_norm_bwd_reread == 1 && addend1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<true>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
-                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
     else if (g_norm_bwd_reread == 1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<false>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
-                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
     else if (C <= 32 * 4)
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
-                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
+                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
     else
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<36, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
-                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
+                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
     const int rows = 64, chunks = (nblk + rows - 1) / rows;
     float* chunk = partial + (size_t)nblk * 2 * C;
     hipLaunchKernelGGL(channel_norm_bwd_fused_finish, dim3((C + 255) / 256, chunks), dim3(256), 0, st, partial,
@@ -530,7 +548,7 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   }
   const int tiles = (P + NPX - 1) / NPX;
   hipLaunchKernelGGL(channel_norm_bwd_dx_kernel, dim3((unsigned)((int64_t)B * tiles)), dim3(1024), 0, st,
-                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, P, tiles);
+                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, P, tiles, gx1_amax);
   const int chunks = dw_chunks(B, C, P);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(channel_norm_bwd_dw_kernel, dim3(C * chunks), dim3(256), 0, st, gy, s, mean, rstd,

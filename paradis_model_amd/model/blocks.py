@@ -77,9 +77,9 @@ class CLinear(nn.Module):
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
     def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, x_pre=None,
-                x_act=None, defer_act_grad=False, bias_proj=None):
+                x_act=None, defer_act_grad=False, bias_proj=None, feeds_gemm=False):
         return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act, x_pre, x_act,
-                             defer_act_grad, bias_proj)
+                             defer_act_grad, bias_proj, feeds_gemm)
 
 
 class SepConv(nn.Module):
@@ -274,7 +274,8 @@ class GMBlock(nn.Sequential):
                             and isinstance(m, CLinear) and torch.is_grad_enabled())
                 if isinstance(m, CLinear):
                     out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
-                            defer_act_grad=hand_off, bias_proj=bias_proj)
+                            defer_act_grad=hand_off, bias_proj=bias_proj,
+                            feeds_gemm=res is None and j < n and isinstance(mods[j], CLinear))
                 else:
                     out = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj)
                 if hand_off:

@@ -271,7 +271,7 @@ def _sl_advect_backward(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_l
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
               dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
               dptr(cl), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), stream_ptr())
+              flags, dptr(ws), None, None, stream_ptr())
     return gfield, gu, gv
 
 
@@ -329,11 +329,15 @@ def _sl_advect_vel_backward(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, 
     gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
     gvel = torch.empty_like(vel)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+    # gfield and gvel are the cotangents of the down-projection and of the velocity network's last GEMM
+    side = bool(lib.paradis_sl_advect_bwd_has_amax(H, W, mode, flags))
+    am_f = _amax_new(gout.device) if side else None
+    am_v = _amax_new(gout.device) if side else None
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
               dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
               dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), stream_ptr())
-    return gfield, gvel
+              flags, dptr(ws), dptr(am_f), dptr(am_v), stream_ptr())
+    return _amax_attach(gfield, am_f), _amax_attach(gvel, am_v)
 
 
 @_fake("sl_advect_vel_backward")
@@ -641,11 +645,12 @@ def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
     gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
     gb = torch.empty_like(gw)
     ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
+    am = _amax_new(gy.device)      # gx1 is the cotangent of the GEMM that produced the block's input
     check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight), dptr(mean),
                                        dptr(rstd), dptr(gx1), dptr(gx2) if C2 else None, dptr(gw), dptr(gb), B,
                                        C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add), add_bs, dptr(ws),
-                                       stream_ptr()), "channel_norm_bwd")
-    return gx1, gx2, gw, gb
+                                       dptr(am), stream_ptr()), "channel_norm_bwd")
+    return _amax_attach(gx1, am), gx2, gw, gb
 
 
 @_fake("channel_norm_backward")
@@ -943,9 +948,9 @@ def _amax_for_gemm(x):
 
 
 @_define("pointwise(Tensor x, Tensor weight, Tensor? bias, Tensor? bmap, Tensor? residual, int act, "
-         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z) "
+         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z, bool y_feeds_gemm) "
          "-> (Tensor, Tensor, Tensor)")
-def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z):
+def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, y_feeds_gemm):
     """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z);
     third = amax partials of x (f16x2 scheme; empty otherwise), kept for the weight gradient.
 
@@ -998,7 +1003,7 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         w2 = weight.reshape(Co, Ci)
         if not w2.is_contiguous():
             w2 = w2.contiguous()
-    y_am = _amax_new(x.device) if defer_act_grad else None   # y feeds the next GEMM directly in a deferred chain
+    y_am = _amax_new(x.device) if (defer_act_grad or y_feeds_gemm) else None   # y is the next GEMM's operand as it is
     _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), GEMM_SCHEME,
               dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
               dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
@@ -1007,7 +1012,7 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
 
 
 @_fake("pointwise")
-def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z):
+def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, y_feeds_gemm):
     B, _, H, W = x.shape
     y = x.new_empty(B, weight.shape[0], H, W)
     return (y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0)),
@@ -1127,7 +1132,7 @@ def _(gmap, m8, pw):
 
 
 def _pw_setup(ctx, inputs, output):
-    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z = inputs
+    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, _feeds = inputs
     y, z, x_amax = output
     ctx.save_for_backward(x, weight, z, x_pre, m8, pw, x_amax)
     ctx.meta = (act, bias is not None, bmap is not None, residual is not None,
@@ -1142,7 +1147,7 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     act, has_bias, has_map, has_res, x_act, deferred = ctx.meta
     need = ctx.needs_input_grad
     if gy is None:
-        return (None,) * 12
+        return (None,) * 13
     has_proj = pw is not None
     gres = gy if has_res else None
     if act != 0 and not deferred:
@@ -1172,18 +1177,20 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
         gpw, gm8 = _global_bias_proj_backward(gmap, m8, pw)
         gmap = None
-    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None
+    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None, None
 
 
 _autograd("pointwise", _pw_setup, _pw_backward)
 
 
 def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
-              defer_act_grad=False, bias_proj=None):
+              defer_act_grad=False, bias_proj=None, feeds_gemm=False):
     """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1].
 
     ``bias_proj=(m8[Cin,H,W], Pw[Co,Cin])`` adds the projected low-rank GlobalBias map inside the GEMM
     epilogue instead of a materialised ``bias_map``.
+    ``feeds_gemm=True``: ``y`` is the operand of another ``pointwise`` as it is (the f16x2 scheme then takes the
+    operand's largest magnitude from this GEMM's epilogue instead of a read pass).
     ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
     called with ``x_pre=z, x_act=act`` (see the op docstring); only valid when ``y`` has no other use."""
     if defer_act_grad and (act is None or residual is not None):
@@ -1195,7 +1202,7 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
     y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad),
-                         m8, pw, save_z)
+                         m8, pw, save_z, bool(feeds_gemm))
     return (y, z) if defer_act_grad else y
 
 
@@ -1258,9 +1265,10 @@ def _gated_blend_backward(gout, h, adv, alpha):
     B, C, H, W = h.shape
     gh, gadv, galpha = torch.empty_like(h), torch.empty_like(h), torch.empty_like(alpha)
     ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
+    am = _amax_new(h.device)       # gadv is the cotangent of the advection's up-projection GEMM
     check(lib.paradis_gated_blend_bwd(dptr(gout), dptr(h), dptr(adv), dptr(alpha), dptr(gh), dptr(gadv),
-                                      dptr(galpha), B, C, H * W, dptr(ws), stream_ptr()), "gated_blend_bwd")
-    return gh, gadv, galpha
+                                      dptr(galpha), B, C, H * W, dptr(ws), dptr(am), stream_ptr()), "gated_blend_bwd")
+    return gh, _amax_attach(gadv, am), galpha
 
 
 @_fake("gated_blend_backward")

@@ -119,9 +119,9 @@ def test_fake_kernels_of_backward_ops_give_the_right_shapes():
         assert gw.shape == (5, C) and gb.shape == (5,)
         gb, gmap = O.bias_grads(e(B, 5, H, W), False, True)
         assert gb.numel() == 0 and gmap.shape == (5, H, W)
-        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, True)
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, True, False)
         assert y.shape == z.shape == (B, 5, H, W)
-        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, False)
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, False, False)
         assert z.numel() == 0
         assert O.concat_channels([e(B, 3, H, W), e(B, 4, H, W)]).shape == (B, 7, H, W)
         assert O.slice_channels(e(B, 7, H, W), 3, 4).shape == (B, 4, H, W)

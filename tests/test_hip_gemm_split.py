@@ -341,6 +341,15 @@ def test_amax_side_outputs(ops):
         check(dz)
         gx = ops._pw_gemm_dgrad(dz, pw.detach(), x, 1, None)     # deferred chain: gx = W^T dz * act'(x_pre)
         check(gx)
+        # cotangent producers: ChannelNorm backward (gx1), gated blend backward (gadv), advection backward
+        mean = torch.zeros(B, H * W).cuda(); rstd = torch.ones(B, H * W).cuda()
+        gx1 = ops._channel_norm_backward(x, x, None, w, mean, rstd, None)[0]
+        check(gx1)
+        alpha = torch.randn(C, generator=g).cuda()
+        check(ops._gated_blend_backward(x, x, x * 0.5, alpha)[1])
+        gf, gvel = ops._sl_advect_vel_backward(x, x, vel, *ops._geom_args(geom, x.device, 0.05, "bicubic", None))
+        check(gf)
+        check(gvel)
         # an in-place update invalidates the attachment
         gx.mul_(2.0)
         assert ops._amax_lookup(gx) is None
