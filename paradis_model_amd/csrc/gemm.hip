@@ -965,6 +965,136 @@ pw_gemm_split_kernel(GemmArgs g) {
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
+// f16x2 forward / dgrad with a 128 x 256 workgroup tile: 8 waves = two 128-column halves (sub 0 / 1 = n-tiles
+// 2 nt2, 2 nt2 + 1, each staging its own activation tile exactly like pw_gemm_split_kernel<2>) that share ONE
+// weight tile and its DMA ring.  The k-loop of this GEMM is bound by the bytes it pulls out of L2 (DESIGN.md
+// 4.1c): 24 KiB per two 128 x 128 x 16 tiles here instead of 32.  48 KiB of LDS, <= 128 VGPRs: two workgroups =
+// 16 waves per CU.  An odd last n-tile leaves sub 1 without work: it runs along on the clamped last tile and
+// skips the epilogue.
+__global__ void __launch_bounds__(512, 4)      // (second argument: waves per SIMD)
+pw_gemm_split_wide_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NP = 2, SIMG = simg(NP), SA = 2, DA = SA - 1;
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 subs][2 activation stages][SIMG] | [SA weight stages][SIMG]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = __builtin_amdgcn_readfirstlane(wave >> 2), lw = wave & 3, ltid = tid & 255;
+  const int wm = lw >> 1, wn = lw & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN, NT2 = (NT + 1) >> 1;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt2 = (L / MT) % NT2, bz = L / (MT * NT2);
+  const bool live = 2 * nt2 + sub < NT;              // wave-uniform
+  const int nt = min(2 * nt2 + sub, NT - 1);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T = (g.K + SBK - 1) / SBK;
+
+  // one 16-byte chunk of the 512-chunk weight tile per thread
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
+  const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
+  const float* Bb;
+  {
+    const uint64_t a = reinterpret_cast<uint64_t>(g.B + (int64_t)bz * g.b_bs);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    Bb = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  }
+  const int bn = min(n0 + (ltid & 127), g.N - 1);
+
+  float sc_b, inv_a, inv_b;
+  {
+    float sc_a;
+    __shared__ uint32_t red[8];
+    const uint32_t* pp = g.b_amax;
+    uint32_t m = max(pp[tid], pp[tid + 512]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = max(max(max(red[0], red[1]), max(red[2], red[3])), max(max(red[4], red[5]), max(red[6], red[7])));
+    scale_from_amax(m, sc_b, inv_b);
+    scale_from_amax(g.a_amax[0], sc_a, inv_a);
+  }
+
+  float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
+  auto issueA = [&](int t) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * SIMG), (lds_ptr_t)(img + (4 + t % SA) * SIMG + wave * 64), 16, 0, 0);
+  };
+  auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
+    u32x4 h, l;
+    split8_f16(x, sc_b, h, l);
+    o[0] = h; o[2 * SCH] = l;
+  };
+  // inline-asm loads with hand-counted waits: see pw_gemm_split_kernel
+  const uint32_t boff = (uint32_t)bn * 4u;
+  auto fetchB = [&](int t, float (&x)[8]) __attribute__((always_inline)) {
+    const int k0 = t * SBK + bh * 8;
+    const float* p = Bb + (int64_t)min(k0, g.K - 1) * g.ldb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("global_load_dword %0, %1, %2" : "=&v"(x[j]) : "v"(boff), "s"(p) : "memory");
+      p += (k0 + j + 1 < g.K) ? g.ldb : 0;
+    }
+  };
+#define USE_X(x, N) do { asm volatile("s_waitcnt vmcnt(" #N ")" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), \
+                                      "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]) : "memory");                  \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
+  u32x4* const Bst = img + sub * 2 * SIMG + bh * SCH + (ltid & 127);   // this thread's chunk in its sub's stage 0
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int u = 0; u < DA && u < T; ++u) issueA(u);
+  fetchB(0, xb[0]);
+  USE_X(xb[0], 0);
+  if (T > 1) fetchB(1, xb[1]);
+  split_store(xb[0], Bst);
+  if (T > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
+    const u32x4* As = img + (4 + t % SA) * SIMG + lh * SCH + wm * 64 + li;
+    const u32x4* Bs = img + (sub * 2 + cur) * SIMG + lh * SCH + wn * 64 + li;
+    const bool dmaA = t + DA < T, ldB = t + 2 < T;
+    if (dmaA) issueA(t + DA);
+    if (ldB) fetchB(t + 2, xload);
+    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's DMA and 8 loads
+    if (dmaA && ldB) USE_X(xsplit, 9);
+    else if (ldB) USE_X(xsplit, 8);
+    else USE_X(xsplit, 0);
+    SplitFrags<NP> f;
+    split_tile_read<NP, 2 * SCH, 2 * SCH>(As, Bs, f);
+    split_tile_mfma<NP>(f, acc);
+    split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+    // weight tile t+1 landed (8 loads of this step are younger), own ds_writes done, the loads of t+2 in flight
+    if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, 0, xb[0], xb[1]);
+    if (t + 1 < T) step(t + 1, 1, xb[1], xb[0]);
+  }
+#undef USE_X
+  if (live) {
+    split_unscale(acc, inv_a, inv_b);
+    gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+  }
+}
+
 // wgrad: dW[M,N'] = sum over (sample, p) A[m][p] B[n][p], both operands p-contiguous fp32, both split
 // in registers.  Thread t stages 8 consecutive p of row t>>1 (k-half t&1) of each operand.
 // Needs K % 16 == 0 and 16-B aligned rows (host-checked; otherwise the f32 kernels run).
@@ -1200,9 +1330,15 @@ int launch_split_np(const GemmArgs& d, hipStream_t st) {
   hipLaunchKernelGGL(pw_gemm_split_kernel<NP>, dim3(grid), dim3(256), split_lds(NP), st, d);
   return 0;
 }
+constexpr size_t SPLIT_WIDE_LDS = (size_t)(2 * 2 + 2) * simg(2) * 16;   // 48 KiB
 // scheme: PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 (the latter with d.a_amax / d.b_amax set)
 int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
-  return scheme == PARADIS_GEMM_F16X2 ? launch_split_np<2>(d, st) : launch_split_np<3>(d, st);
+  if (scheme != PARADIS_GEMM_F16X2) return launch_split_np<3>(d, st);
+  const int NT = (d.N + BN - 1) / BN;
+  if (NT < 2) return launch_split_np<2>(d, st);
+  const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;     // 128 x 256 tiles
+  hipLaunchKernelGGL(pw_gemm_split_wide_kernel, dim3(grid), dim3(512), SPLIT_WIDE_LDS, st, d);
+  return 0;
 }
 
 int check_gemm(const char* name, int B, int M, int K, int N) {
