@@ -971,17 +971,18 @@ pw_gemm_split_kernel(GemmArgs g) {
 // 4.1c): 24 KiB per two 128 x 128 x 16 tiles here instead of 32.  48 KiB of LDS, <= 128 VGPRs: two workgroups =
 // 16 waves per CU.  An odd last n-tile leaves sub 1 without work: it runs along on the clamped last tile and
 // skips the epilogue.
-__global__ void __launch_bounds__(512, 4)      // (second argument: waves per SIMD)
+template <int NSUB>
+__global__ void __launch_bounds__(256 * NSUB, 4)      // (second argument: waves per SIMD)
 pw_gemm_split_wide_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NP = 2, SIMG = simg(NP), SA = 2, DA = SA - 1;
-  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 subs][2 activation stages][SIMG] | [SA weight stages][SIMG]
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [NSUB][2 activation stages][SIMG] | [SA weight stages][SIMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = __builtin_amdgcn_readfirstlane(wave >> 2), lw = wave & 3, ltid = tid & 255;
   const int wm = lw >> 1, wn = lw & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN, NT2 = (NT + 1) >> 1;
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN, NT2 = (NT + NSUB - 1) / NSUB;
   int L;
   {
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -989,13 +990,14 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
   const int mt = L % MT, nt2 = (L / MT) % NT2, bz = L / (MT * NT2);
-  const bool live = 2 * nt2 + sub < NT;              // wave-uniform
-  const int nt = min(2 * nt2 + sub, NT - 1);
+  const bool live = NSUB * nt2 + sub < NT;           // wave-uniform
+  const int nt = min(NSUB * nt2 + sub, NT - 1);
   const int m0 = mt * BM, n0 = nt * BN;
   const int T = (g.K + SBK - 1) / SBK;
 
-  // one 16-byte chunk of the 512-chunk weight tile per thread
-  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
+  // one 16-byte chunk of the 512-chunk weight tile per thread (of the first 512)
+  const bool doA = NSUB == 2 || wave < 8;            // wave-uniform
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + (tid & 511);
   const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
   const float* Bb;
   {
@@ -1008,21 +1010,24 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   float sc_b, inv_a, inv_b;
   {
     float sc_a;
-    __shared__ uint32_t red[8];
+    __shared__ uint32_t red[4 * NSUB];
     const uint32_t* pp = g.b_amax;
-    uint32_t m = max(pp[tid], pp[tid + 512]);
+    uint32_t m = NSUB == 2 ? max(pp[tid], pp[tid + 512]) : pp[tid];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = max(max(max(red[0], red[1]), max(red[2], red[3])), max(max(red[4], red[5]), max(red[6], red[7])));
+    m = red[0];
+#pragma unroll
+    for (int i = 1; i < 4 * NSUB; ++i) m = max(m, red[i]);
     scale_from_amax(m, sc_b, inv_b);
     scale_from_amax(g.a_amax[0], sc_a, inv_a);
   }
 
   float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
   auto issueA = [&](int t) __attribute__((always_inline)) {
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * SIMG), (lds_ptr_t)(img + (4 + t % SA) * SIMG + wave * 64), 16, 0, 0);
+    if (doA)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * SIMG), (lds_ptr_t)(img + (2 * NSUB + t % SA) * SIMG + wave * 64), 16, 0, 0);
   };
   auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
     u32x4 h, l;
@@ -1061,13 +1066,13 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   if (T > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   auto step = [&](int t, int cur, float (&xload)[8], float (&xsplit)[8]) __attribute__((always_inline)) {
-    const u32x4* As = img + (4 + t % SA) * SIMG + lh * SCH + wm * 64 + li;
+    const u32x4* As = img + (2 * NSUB + t % SA) * SIMG + lh * SCH + wm * 64 + li;
     const u32x4* Bs = img + (sub * 2 + cur) * SIMG + lh * SCH + wn * 64 + li;
     const bool dmaA = t + DA < T, ldB = t + 2 < T;
     if (dmaA) issueA(t + DA);
     if (ldB) fetchB(t + 2, xload);
     // xsplit (tile t+1) was loaded a step ago; younger operations: this step's DMA and 8 loads
-    if (dmaA && ldB) USE_X(xsplit, 9);
+    if (dmaA && ldB && doA) USE_X(xsplit, 9);
     else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
     SplitFrags<NP> f;
@@ -1330,14 +1335,26 @@ int launch_split_np(const GemmArgs& d, hipStream_t st) {
   hipLaunchKernelGGL(pw_gemm_split_kernel<NP>, dim3(grid), dim3(256), split_lds(NP), st, d);
   return 0;
 }
-constexpr size_t SPLIT_WIDE_LDS = (size_t)(2 * 2 + 2) * simg(2) * 16;   // 48 KiB
+constexpr size_t split_wide_lds(int nsub) { return (size_t)(2 * nsub + 2) * simg(2) * 16; }   // 48 / 80 KiB
+// n-tiles per workgroup: 2 (two 8-wave workgroups per CU).  4 - one 16-wave workgroup per CU, another 17 % fewer
+// bytes - measured 2.5 % SLOWER: a single workgroup's waves all stop at the same barriers.
+constexpr int SPLIT_WIDE_NSUB = 2;
 // scheme: PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 (the latter with d.a_amax / d.b_amax set)
 int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
   if (scheme != PARADIS_GEMM_F16X2) return launch_split_np<3>(d, st);
   const int NT = (d.N + BN - 1) / BN;
   if (NT < 2) return launch_split_np<2>(d, st);
-  const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;     // 128 x 256 tiles
-  hipLaunchKernelGGL(pw_gemm_split_wide_kernel, dim3(grid), dim3(512), SPLIT_WIDE_LDS, st, d);
+  constexpr int NSUB = SPLIT_WIDE_NSUB;
+  static PerDeviceOnce once;
+  if (split_wide_lds(NSUB) > 64 * 1024 && once.first()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_wide_kernel<NSUB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_wide_lds(NSUB)) != hipSuccess) {
+      paradis_set_error("pw_gemm(split): cannot reserve LDS");
+      return 2;
+    }
+  }
+  const int grid = ((d.M + BM - 1) / BM) * ((NT + NSUB - 1) / NSUB) * d.nbatch;     // 128 x (128 NSUB) tiles
+  hipLaunchKernelGGL(pw_gemm_split_wide_kernel<NSUB>, dim3(grid), dim3(256 * NSUB), split_wide_lds(NSUB), st, d);
   return 0;
 }
 
