@@ -19,6 +19,7 @@ check arguments and call ``torch.ops.paradis.*``.  Reference call sites are cite
 """
 from __future__ import annotations
 
+import functools
 import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
@@ -51,8 +52,22 @@ def _define(schema: str, autocast: bool = True):
     return deco
 
 
+TRACED = False     # set once any paradis:: op has been traced with fake tensors (torch.compile, export, opcheck)
+
+
 def _fake(name: str):
-    return torch.library.register_fake(f"paradis::{name}")
+    """Register the fake (shape) kernel of an op.  Every fake kernel also records that tracing has happened
+    in this process: compiled graphs may update a custom op's output in place through generated kernels that
+    do not bump its version counter, so the amax side channel (below) is an eager-mode optimisation and
+    switches itself off for good the first time one of the ops is traced."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            global TRACED
+            TRACED = True
+            return fn(*args, **kwargs)
+        return torch.library.register_fake(f"paradis::{name}")(wrapper)
+    return deco
 
 
 def _autograd(name: str, setup, backward) -> None:
@@ -198,22 +213,23 @@ def _bstride_view(t: Tensor, K: int, H: int, W: int) -> Tuple[Tensor, int]:
 # needs no read pass of its own (ops.amax_partials is the fallback for every other producer).
 # ---------------------------------------------------------------------------
 AMAX_SIDE_OUTPUTS = os.environ.get("PARADIS_AMAX_SIDE", "1") != "0"   # 0: every operand gets its own read pass
-_AMAX_POOL = None      # [rows, AMAX_PARTIALS] zeroed words, handed out row by row (one fill per 256 producers)
-_AMAX_NEXT = 0
+_AMAX_POOL = []        # zeroed int32[AMAX_PARTIALS] tensors, handed out one by one
+_AMAX_DEVICE = None
 
 
 def _amax_new(device):
-    """Zeroed words for a producer's side output; None when the GEMM scheme does not need them or
-    while tracing (fake tensors carry no side channel)."""
-    global _AMAX_POOL, _AMAX_NEXT
-    if GEMM_SCHEME != GEMM_F16X2 or torch.compiler.is_compiling() or not AMAX_SIDE_OUTPUTS:
+    """Zeroed words for a producer's side output; None when the GEMM scheme does not need them or once
+    the ops have been traced (see ``_fake``).  Every hand-out is a tensor with its own storage
+    (custom-op outputs must not be views: inductor rebuilds graph outputs from the fake kernel's metadata,
+    storage offset 0); 256 of them are zeroed by one multi-tensor fill."""
+    global _AMAX_POOL, _AMAX_DEVICE
+    if GEMM_SCHEME != GEMM_F16X2 or TRACED or not AMAX_SIDE_OUTPUTS:
         return None
-    if _AMAX_POOL is None or _AMAX_NEXT == _AMAX_POOL.shape[0] or _AMAX_POOL.device != device:
-        _AMAX_POOL = torch.zeros(256, AMAX_PARTIALS, dtype=torch.int32, device=device)
-        _AMAX_NEXT = 0
-    row = _AMAX_POOL[_AMAX_NEXT]
-    _AMAX_NEXT += 1
-    return row
+    if not _AMAX_POOL or _AMAX_DEVICE != device:
+        _AMAX_POOL = [torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=device) for _ in range(256)]
+        torch._foreach_zero_(_AMAX_POOL)
+        _AMAX_DEVICE = device
+    return _AMAX_POOL.pop()
 
 
 def _amax_attach(t, am):
@@ -224,6 +240,8 @@ def _amax_attach(t, am):
 
 
 def _amax_lookup(t):
+    if TRACED:
+        return None
     ent = getattr(t, "_paradis_amax", None) if t is not None else None
     return ent[1] if ent is not None and ent[0] == t._version else None
 

@@ -303,8 +303,9 @@ def test_amax_side_outputs(ops):
     scheme): equal to a read pass (an upper bound for the advection's pole rows), picked up by
     ops.amax_partials without a launch, and dropped when the tensor is modified in place."""
     from tests._util import make_grid
-    keep = ops.GEMM_SCHEME
+    keep, keep_traced = ops.GEMM_SCHEME, ops.TRACED
     ops.GEMM_SCHEME = ops.GEMM_F16X2
+    ops.TRACED = False          # (tracing any op - torch.compile, opcheck in other tests - switches the channel off)
     try:
         g = torch.Generator().manual_seed(31)
         B, C, H, W = 2, 64, 32, 64
@@ -359,5 +360,38 @@ def test_amax_side_outputs(ops):
             xs = torch.randn(1, Ci, h, wd, generator=g).cuda()
             ws = torch.randn(Co, Ci, generator=g).cuda()
             check(ops.pointwise(xs, ws, None, None, None, "SiLU", defer_act_grad=True)[0])
+        # once an op has been traced with fake tensors the channel stays off: a compiled graph may update a
+        # custom op's output in place without touching its version counter
+        ops.TRACED = True
+        assert ops._amax_lookup(ops.dwconv_geo(x, dw, b)) is None
     finally:
-        ops.GEMM_SCHEME = keep
+        ops.GEMM_SCHEME, ops.TRACED = keep, keep_traced
+
+
+def test_model_gradients_do_not_depend_on_the_amax_side_channel(ops):
+    """A training step of the reduced model with the producers' amax side outputs and with one read pass per
+    GEMM operand: same loss and gradients (the scales are powers of two; only the advection's upper bound can
+    move one by a binade)."""
+    from paradis_model_amd.config import reduced_config, stub_datamodule
+    from paradis_model_amd.model import Paradis
+    from tests._util import make_grid, max_rel
+    keep = (ops.GEMM_SCHEME, ops.TRACED, ops.AMAX_SIDE_OUTPUTS)
+    ops.GEMM_SCHEME, ops.TRACED = ops.GEMM_F16X2, False
+    try:
+        cfg = reduced_config()
+        _, lg, og = make_grid(32, 64, False)
+        torch.manual_seed(42)
+        model = Paradis(stub_datamodule(cfg), cfg, lg, og).cuda()
+        x = seeded(3, 2, 186, 32, 64).cuda()
+        res = []
+        for side in (True, False):
+            ops.AMAX_SIDE_OUTPUTS = side
+            model.zero_grad(set_to_none=True)
+            xd = x.clone().requires_grad_(True)
+            y = model(xd)
+            y.square().mean().backward()
+            res.append((y.detach(), xd.grad, torch.cat([p.grad.flatten() for p in model.parameters()])))
+        for a, b in zip(res[0], res[1]):
+            assert max_rel(a, b) <= 1e-5
+    finally:
+        ops.GEMM_SCHEME, ops.TRACED, ops.AMAX_SIDE_OUTPUTS = keep
