@@ -321,7 +321,7 @@ def main():
                          "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
                 peak = MFMA_BF16_PEAK_TFLOPS / products
             elif args.gemm == "f16x2":
-                kname = ("pw_gemm_split_kernel<2>/pw_gemm_wgrad_split_kernel<2> (fwd+dgrad+wgrad; fp32 operands as "
+                kname = ("pw_gemm_split_wide_kernel<2>/pw_gemm_wgrad_split_kernel<2> (fwd+dgrad+wgrad; fp32 operands as "
                          "2 f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)")
                 peak = MFMA_BF16_PEAK_TFLOPS / products
             else:
