@@ -161,3 +161,28 @@ def test_synthetic_batch_shapes_and_rollout_glue():
     assert nxt.shape == (3, 166, 32, 64)
     assert torch.equal(nxt[:, :83], mi[:, 83:166]) and torch.equal(nxt[:, 83:], out[:, :83])
     assert torch.equal(next_input(mi, out, 83, 1), out[:, :83])
+
+
+def test_gemm_scheme_selection_and_amax_side_channel_bookkeeping(monkeypatch):
+    """Host logic of the GEMM arithmetic switch (PARADIS_GEMM) and of the amax side channel: words attached
+    to a tensor are returned while its version counter is unchanged and tracing has not happened."""
+    import torch
+    from paradis_model_amd import ops
+    for name, code in (("f16x2", 2), ("bf16x3", 3), ("split", 3), ("exact", 0)):
+        monkeypatch.setenv("PARADIS_GEMM", name)
+        assert ops._scheme_from_env() == code
+    monkeypatch.setenv("PARADIS_GEMM", "fp8")
+    with pytest.raises(ValueError):
+        ops._scheme_from_env()
+    monkeypatch.delenv("PARADIS_GEMM")
+    assert ops._scheme_from_env() == ops.GEMM_F16X2                       # the default
+    monkeypatch.setattr(ops, "TRACED", False)
+    t, words = torch.zeros(4), torch.zeros(ops.AMAX_PARTIALS, dtype=torch.int32)
+    assert ops._amax_lookup(t) is None and ops._amax_lookup(None) is None
+    assert ops._amax_attach(t, words) is t and ops._amax_lookup(t) is words
+    assert ops._amax_attach(t, None) is t                                 # no side output produced: nothing changes
+    t.add_(1.0)                                                           # in-place update: version counter moves
+    assert ops._amax_lookup(t) is None
+    ops._amax_attach(t, words)
+    monkeypatch.setattr(ops, "TRACED", True)                              # an op was traced (torch.compile): channel off
+    assert ops._amax_lookup(t) is None and ops._amax_new(torch.device("cpu")) is None
