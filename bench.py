@@ -261,7 +261,7 @@ def main():
     elapsed = max_over_ranks(elapsed, dev)
 
     # The same K steps with the exact f32-MFMA GEMMs, timed the same way and reported beside the headline
-    # (`value` is the default arithmetic: fp32 through the bf16 split).
+    # (`value` is the default arithmetic: fp32 through two f16 terms per operand).
     exact = None
     if args.gemm != "exact" and not args.no_exact_leg:
         ops.GEMM_SCHEME = ops.GEMM_EXACT
