@@ -108,9 +108,15 @@ __device__ __forceinline__ void geo_for_each_alias(int y, int x, int H, int W, i
 // zeroed (bit patterns of non-negative floats order like unsigned integers).
 __device__ __forceinline__ float amax_acc(float m, float v) { return fmaxf(m, fabsf(v)); }
 __device__ __forceinline__ void amax_flush(float m, uint32_t* __restrict__ partials) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(partials + (blockIdx.x & (PARADIS_AMAX_PARTIALS - 1)), __float_as_uint(m));
+  // wave maximum by DPP (no LDS-pipe shuffles, no waits): row_shr 1/2/4/8 leave each 16-lane row's maximum in
+  // its last lane, row_bcast 15 / 31 carry it on; lane 63 ends up with the maximum of the wave.  Lanes a shift
+  // has no source for read 0 (bound_ctrl) - neutral for bit patterns of non-negative floats.
+  uint32_t v = __float_as_uint(m);
+#define PD_DPP_MAX(ctrl, rows) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, true))
+  PD_DPP_MAX(0x111, 0xf); PD_DPP_MAX(0x112, 0xf); PD_DPP_MAX(0x114, 0xf); PD_DPP_MAX(0x118, 0xf);
+  PD_DPP_MAX(0x142, 0xa); PD_DPP_MAX(0x143, 0xc);
+#undef PD_DPP_MAX
+  if ((threadIdx.x & 63) == 63) atomicMax(partials + (blockIdx.x & (PARADIS_AMAX_PARTIALS - 1)), v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
