@@ -107,15 +107,18 @@ __device__ __forceinline__ void geo_for_each_alias(int y, int x, int H, int W, i
 // wave and adds the bit pattern with one atomic into one of the PARADIS_AMAX_PARTIALS words the caller has
 // zeroed (bit patterns of non-negative floats order like unsigned integers).
 __device__ __forceinline__ float amax_acc(float m, float v) { return fmaxf(m, fabsf(v)); }
-__device__ __forceinline__ void amax_flush(float m, uint32_t* __restrict__ partials) {
-  // wave maximum by DPP (no LDS-pipe shuffles, no waits): row_shr 1/2/4/8 leave each 16-lane row's maximum in
-  // its last lane, row_bcast 15 / 31 carry it on; lane 63 ends up with the maximum of the wave.  Lanes a shift
-  // has no source for read 0 (bound_ctrl) - neutral for bit patterns of non-negative floats.
-  uint32_t v = __float_as_uint(m);
+// unsigned maximum over the wave by DPP (no LDS-pipe shuffles, no waits): row_shr 1/2/4/8 leave each 16-lane
+// row's maximum in its last lane, row_bcast 15 / 31 carry it on; LANE 63 ends up with the maximum of the wave.
+// Lanes a shift has no source for read 0 (bound_ctrl): neutral for an unsigned maximum.
+__device__ __forceinline__ uint32_t wave_umax_lane63(uint32_t v) {
 #define PD_DPP_MAX(ctrl, rows) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, true))
   PD_DPP_MAX(0x111, 0xf); PD_DPP_MAX(0x112, 0xf); PD_DPP_MAX(0x114, 0xf); PD_DPP_MAX(0x118, 0xf);
   PD_DPP_MAX(0x142, 0xa); PD_DPP_MAX(0x143, 0xc);
 #undef PD_DPP_MAX
+  return v;
+}
+__device__ __forceinline__ void amax_flush(float m, uint32_t* __restrict__ partials) {
+  const uint32_t v = wave_umax_lane63(__float_as_uint(m));
   if ((threadIdx.x & 63) == 63) atomicMax(partials + (blockIdx.x & (PARADIS_AMAX_PARTIALS - 1)), v);
 }
 

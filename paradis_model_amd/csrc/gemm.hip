@@ -622,9 +622,8 @@ __device__ __forceinline__ uint32_t reduce_amax_partials(const uint32_t* __restr
   __shared__ uint32_t red[4];
   const int tid = threadIdx.x;
   uint32_t m = max(max(p[tid], p[tid + 256]), max(p[tid + 512], p[tid + 768]));
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = m;
+  m = wave_umax_lane63(m);
+  if ((tid & 63) == 63) red[tid >> 6] = m;
   __syncthreads();
   m = max(max(red[0], red[1]), max(red[2], red[3]));
   __syncthreads();
@@ -691,10 +690,9 @@ amax_partials_kernel(const float* __restrict__ x, int B, int64_t inner, int64_t 
       m = max(m, __float_as_uint(x[b * bs + j]) & 0x7fffffffu);
     }
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  m = wave_umax_lane63(m);
   __shared__ uint32_t red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
@@ -1013,9 +1011,8 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
     __shared__ uint32_t red[4 * NSUB];
     const uint32_t* pp = g.b_amax;
     uint32_t m = NSUB == 2 ? max(pp[tid], pp[tid + 512]) : pp[tid];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if (lane == 0) red[wave] = m;
+    m = wave_umax_lane63(m);
+    if (lane == 63) red[wave] = m;
     __syncthreads();
     m = red[0];
 #pragma unroll
