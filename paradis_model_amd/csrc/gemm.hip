@@ -1229,8 +1229,31 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
+// out[i] = slabs[0][i] + slabs[1][i] + ... in that order; vec: n % 4 == 0 and 16-byte aligned pointers (four
+// elements per thread, four slabs' loads in flight)
 __global__ void __launch_bounds__(256)
-slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S) {
+slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S, int vec) {
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    const float4* sl = reinterpret_cast<const float4*>(slabs);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int k = 0;
+      for (; k + 4 <= S; k += 4) {
+        float4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = sl[(int64_t)(k + j) * n4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s.x += q[j].x; s.y += q[j].y; s.z += q[j].z; s.w += q[j].w; }
+      }
+      for (; k < S; ++k) {
+        const float4 q = sl[(int64_t)k * n4 + i];
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      }
+      reinterpret_cast<float4*>(out)[i] = s;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
@@ -1612,12 +1635,13 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   } else if (int e = launch_gemm<true, true>(g, grid, st)) return e;
   if (S > 1) {
     const int64_t n = (int64_t)M * K;
-    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, S);
+    const int vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dW)) & 15) == 0;
+    const int blocks = (int)std::min<int64_t>(((vec ? n / 4 : n) + 255) / 256, 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, S, vec);
   }
   if (g.rowsum)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)rowsum_ws,
-                       gbias, (int64_t)M, S);
+                       gbias, (int64_t)M, S, 0);
   PD_CHECK_LAUNCH("pw_gemm_wgrad");
   return 0;
 }
