@@ -6,10 +6,14 @@ One "step" = forward (S=1 rollout step) + ParadisLoss + backward + AdamW on one 
 ERA5-shaped batch of 32 samples per GPU (configs[1]: 32x64 grid, default 60 M-parameter model,
 fp32).  N>1: one process per GPU (torchrun), batch-sharded DDP over RCCL, weak scaling.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the pointwise GEMMs: fp32 in /
-fp32 accumulate / fp32 out, by default as two f16 terms of the per-tensor scaled operands on the f16
-matrix pipe (--gemm bf16x3: exact 3-way bf16 splits; --gemm exact: f32 MFMA); timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the
-reference path, timed on the host cores on a bounded sample).
+Prints ONE JSON line on rank 0.  `value` / `ms_per_step` / `roofline` are measured with the default,
+reference-width GEMM arithmetic: fp32 in / fp32 accumulate / fp32 out through the exact three-term bf16
+decomposition of every operand value (bf16x3: 24 significand bits, fp32's exponent range per element, six
+products on the bf16 MFMA; `--gemm exact` = the f32 MFMA chain).  `roofline` = the pointwise GEMMs (dominant
+kernels), timed live with HIP events on the launch stream.  Two more timed legs of the same K steps are
+reported beside the headline and never as the headline: `exact_f32_gemm` (v_mfma_f32_32x32x2_f32) and
+`f16x2_emulated` (opt-in block-exponent format, NOT reference-width arithmetic).  `cpu_baseline` = the CPU
+oracle (port of the reference path), timed on the host cores on a bounded sample.
 """
 import argparse
 import json
@@ -178,13 +182,14 @@ def main():
     ap.add_argument("--checkpoint", action="store_true", help="per-layer activation checkpointing")
     ap.add_argument("--optimizer", default="adamw", choices=["adamw", "muon", "normuon"],
                     help="adamw = the measured configuration (SURVEY 8d); normuon = the reference's shipped default")
-    ap.add_argument("--gemm", default=os.environ.get("PARADIS_GEMM", "f16x2"),
-                    choices=["f16x2", "bf16x3", "split", "exact"],
-                    help="pointwise GEMM arithmetic (all fp32 in/accumulate/out): f16x2 = two f16 terms of the per-tensor "
-                         "scaled operands, 3 products on the f16 MFMA (default); bf16x3 (= split) = exact three bf16 "
-                         "terms, 6 products on the bf16 MFMA; exact = f32 MFMA")
-    ap.add_argument("--no-exact-leg", action="store_true",
-                    help="skip the second timed loop with the exact f32-MFMA GEMMs (reported as exact_f32_gemm)")
+    ap.add_argument("--gemm", default=os.environ.get("PARADIS_GEMM", "bf16x3"),
+                    choices=["bf16x3", "split", "exact", "f16x2"],
+                    help="pointwise GEMM arithmetic of the HEADLINE leg (all fp32 in/accumulate/out): bf16x3 (= split, "
+                         "default) = exact three bf16 terms per value, 6 products on the bf16 MFMA; exact = f32 MFMA; "
+                         "f16x2 = opt-in block-exponent emulation (two f16 terms of the per-tensor scaled operands) - "
+                         "not reference-width arithmetic, labelled as such in the output")
+    ap.add_argument("--no-extra-legs", "--no-exact-leg", dest="no_extra_legs", action="store_true",
+                    help="skip the extra timed loops (exact_f32_gemm, f16x2_emulated)")
     ap.add_argument("--bucket-mb", type=int, default=32, help="DDP gradient bucket size (N>1)")
     ap.add_argument("--static-graph", action="store_true", help="DDP static_graph=True (N>1)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -260,12 +265,11 @@ def main():
     _lib.PROFILER = None
     elapsed = max_over_ranks(elapsed, dev)
 
-    # The same K steps with the exact f32-MFMA GEMMs, timed the same way and reported beside the headline
-    # (`value` is the default arithmetic: fp32 through two f16 terms per operand).
-    exact = None
-    if args.gemm != "exact" and not args.no_exact_leg:
-        ops.GEMM_SCHEME = ops.GEMM_EXACT
-        for _ in range(min(args.warmup, 2)):
+    # The same K steps in the other two arithmetics, timed the same way (>= 5 warm-up steps each) and reported
+    # beside the headline under their own names.
+    def extra_leg(scheme_name, label):
+        ops.GEMM_SCHEME = ops._SCHEMES[scheme_name]
+        for _ in range(max(args.warmup, 5)):
             step(batch)
         barrier()
         torch.cuda.synchronize()
@@ -274,10 +278,19 @@ def main():
             step(batch)
         torch.cuda.synchronize()
         barrier()
-        e_exact = max_over_ranks(time.perf_counter() - t1, dev)
+        e = max_over_ranks(time.perf_counter() - t1, dev)
         ops.GEMM_SCHEME = ops._SCHEMES[args.gemm]
-        exact = {"value": world * B * args.steps / e_exact, "unit": "samples/s",
-                 "ms_per_step": 1e3 * e_exact / args.steps, "gemm_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+        return {"value": world * B * args.steps / e, "unit": "samples/s", "ms_per_step": 1e3 * e / args.steps,
+                "warmup": max(args.warmup, 5), "gemm_arithmetic": label}
+
+    legs = {}
+    if not args.no_extra_legs:
+        if args.gemm != "exact":
+            legs["exact_f32_gemm"] = extra_leg("exact", "fp32 MFMA (v_mfma_f32_32x32x2_f32)")
+        if args.gemm != "f16x2":
+            legs["f16x2_emulated"] = extra_leg(
+                "f16x2", "NOT reference-width: block-exponent emulation, two f16 terms of the per-tensor scaled "
+                         "operands (22 significand bits relative to each tensor's maximum), 3 products on f16 MFMA")
 
     metric = "training samples/sec (whole node) on 5.625deg ERA5 grid, 1/2/4/8 MI355X"
     try:   # use BASELINE.json's exact wording when the file travels with the repo
@@ -292,16 +305,19 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.gemm != "f16x2" else "f32 storage, f16x2 block-exponent GEMM emulation", "data": "synthetic",
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
                    "optimizer": args.optimizer, "parallelism": f"dp{world}",
                    "ddp": ({"bucket_cap_mb": args.bucket_mb, "static_graph": bool(args.static_graph),
                             "backend": torch.distributed.get_backend()} if world > 1 else None),
-                   "gemm_arithmetic": {"f16x2": "fp32 via two f16 terms of the per-tensor scaled operands (22 significand "
-                                                "bits), 3 products on f16 MFMA, fp32 accumulate",
-                                       "bf16x3": "fp32 via exact 3-way bf16 split on bf16 MFMA, fp32 accumulate",
-                                       "exact": "fp32 MFMA"}[args.gemm],
+                   "gemm_arithmetic": args.gemm,
+                   "gemm_arithmetic_detail": {
+                       "f16x2": "NOT reference-width: two f16 terms of the per-tensor scaled operands (22 significand "
+                                "bits relative to the tensor maximum), 3 products on f16 MFMA, fp32 accumulate",
+                       "bf16x3": "fp32 operands as the exact 3-term bf16 decomposition (24 significand bits, fp32 exponent "
+                                 "range per element), 6 products on bf16 MFMA, fp32 accumulate",
+                       "exact": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}[args.gemm],
                    "mode": "forward-only" if args.forward_only else "train",
                    "activation_checkpointing": bool(args.checkpoint),
                    "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
@@ -317,8 +333,9 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS}.get(args.gemm)
             if args.gemm == "bf16x3":
-                kname = ("pw_gemm_split_kernel<3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
-                         "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
+                kname = ("pw_gemm_split_wide_kernel<3>/pw_gemm_split_kernel<3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+"
+                         "wgrad; fp32 operands as 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 "
+                         "accumulate)")
                 peak = MFMA_BF16_PEAK_TFLOPS / products
             elif args.gemm == "f16x2":
                 kname = ("pw_gemm_split_wide_kernel<2>/pw_gemm_wgrad_split_kernel<2> (fwd+dgrad+wgrad; fp32 operands as "
@@ -348,8 +365,7 @@ def main():
                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
                              "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
                              "bytes_per_launch": r["work"] / r["launches"]}
-    if exact is not None:
-        out["exact_f32_gemm"] = exact
+    out.update(legs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=8)
     if rank == 0:

@@ -488,8 +488,12 @@ def coarse_geometry(lat_grid: Tensor, lon_grid: Tensor, stride: int) -> GridGeom
 
 
 def paradis_forward(params: Dict[str, Tensor], spec: ModelSpec, fields: Tensor,
-                    lat_grid: Tensor, lon_grid: Tensor, interp_impl: str = "taps") -> Tensor:
-    """fields [B, in_dim, H, W] -> [B, out_dim, H, W]  (paradis.py:256-269)."""
+                    lat_grid: Tensor, lon_grid: Tensor, interp_impl: str = "taps",
+                    checkpoint_layers: bool = False) -> Tensor:
+    """fields [B, in_dim, H, W] -> [B, out_dim, H, W]  (paradis.py:256-269).
+    ``checkpoint_layers``: recompute each ADR layer in the backward pass (the reference's
+    ``compute.gradient_checkpointing``, paradis.py:222-226, non-reentrant): same values, one layer's
+    intermediates alive at a time - what lets the fp64 oracle of a 128x256 plane fit the host."""
     geo = coarse_geometry(lat_grid.to(fields.dtype), lon_grid.to(fields.dtype), spec.stride)
     hidden = run_block(params, "input_proj", spec.plans["input_proj"], fields)
     hs = static_encoder(params, fields[:, -spec.n_static:])
@@ -497,7 +501,12 @@ def paradis_forward(params: Dict[str, Tensor], spec: ModelSpec, fields: Tensor,
     hidden = avgpool_geo(hidden, spec.stride)
     hs = avgpool_geo(hs, spec.stride)
     for i in range(spec.num_layers):
-        hidden = layer_step(params, spec, i, hidden, hs, geo, interp_impl)
+        if checkpoint_layers and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            hidden = checkpoint(lambda h, s_, i=i: layer_step(params, spec, i, h, s_, geo, interp_impl),
+                                hidden, hs, use_reentrant=False)
+        else:
+            hidden = layer_step(params, spec, i, hidden, hs, geo, interp_impl)
     hidden = upsample_lon_periodic(hidden, spec.nlat, spec.nlon) + skip
     return run_block(params, "output_proj", spec.plans["output_proj"], hidden)
 

@@ -165,7 +165,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
-def wrap_ddp(model, *, bucket_cap_mb: int = 32, device_ids: Optional[Sequence[int]] = None,
+def wrap_ddp(model, *, bucket_cap_mb: float = 32, device_ids: Optional[Sequence[int]] = None,
              static_graph: bool = False):
     """Batch-sharded data parallelism (the reference's only strategy, ``train.py:49``): full replica
     per GPU, bucketed gradient all-reduce (RCCL over xGMI) overlapped with backward.  Geometry

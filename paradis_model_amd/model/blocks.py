@@ -77,9 +77,9 @@ class CLinear(nn.Module):
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
     def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, x_pre=None,
-                x_act=None, defer_act_grad=False, bias_proj=None, feeds_gemm=False):
+                x_act=None, defer_act_grad=False, bias_proj=None):
         return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act, x_pre, x_act,
-                             defer_act_grad, bias_proj, feeds_gemm)
+                             defer_act_grad, bias_proj)
 
 
 class SepConv(nn.Module):
@@ -187,23 +187,27 @@ class GMBlock(nn.Sequential):
                  hidden_dim: Union[Sequence, int] = 0, activation_fn: Type[nn.Module] = nn.SiLU,
                  bias_channels: int = 0, activation: Union[Sequence, bool] = False,
                  pre_normalize: bool = False):
-        num_layers = len(layers)
-        if num_layers == 0:
+        depth = len(layers)
+        if depth == 0:
             raise ValueError("GMBlock: must specify at least one layer")
-        if isinstance(activation, Sequence):
-            assert len(activation) == num_layers
-        else:
-            activation = (True,) * (num_layers - 1) + (activation,)
-        if isinstance(hidden_dim, Sequence):
-            assert len(hidden_dim) == num_layers - 1
-        else:
-            if hidden_dim <= 0:
-                hidden_dim = max(input_dim, output_dim)
-            hidden_dim = (hidden_dim,) * (num_layers - 1)
-        if isinstance(kernel_size, int):
-            kernel_size = (kernel_size,) * num_layers
-        else:
-            assert len(kernel_size) == num_layers
+
+        def per_layer(value, count, what):
+            """scalar -> one entry per slot; a sequence must already have one entry per slot"""
+            if isinstance(value, Sequence) and not isinstance(value, str):
+                if len(value) != count:
+                    raise AssertionError(f"GMBlock: {what} needs {count} entries, got {len(value)}")
+                return tuple(value)
+            return (value,) * count
+
+        # an activation follows every layer but the last; `activation` (bool) decides the last one
+        activation = (per_layer(activation, depth, "activation") if isinstance(activation, Sequence)
+                      else (True,) * (depth - 1) + (bool(activation),))
+        # widths between layers: `hidden_dim` <= 0 means "as wide as the wider end of the block"
+        if not isinstance(hidden_dim, Sequence) and hidden_dim <= 0:
+            hidden_dim = max(input_dim, output_dim)
+        hidden_dim = per_layer(hidden_dim, depth - 1, "hidden_dim")
+        kernel_size = per_layer(kernel_size, depth, "kernel_size")
+        num_layers = depth
 
         children = []
         if pre_normalize:
@@ -274,8 +278,7 @@ class GMBlock(nn.Sequential):
                             and isinstance(m, CLinear) and torch.is_grad_enabled())
                 if isinstance(m, CLinear):
                     out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
-                            defer_act_grad=hand_off, bias_proj=bias_proj,
-                            feeds_gemm=res is None and j < n and isinstance(mods[j], CLinear))
+                            defer_act_grad=hand_off, bias_proj=bias_proj)
                 else:
                     out = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj)
                 if hand_off:

@@ -19,7 +19,6 @@ check arguments and call ``torch.ops.paradis.*``.  Reference call sites are cite
 """
 from __future__ import annotations
 
-import functools
 import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
@@ -52,22 +51,9 @@ def _define(schema: str, autocast: bool = True):
     return deco
 
 
-TRACED = False     # set once any paradis:: op has been traced with fake tensors (torch.compile, export, opcheck)
-
-
 def _fake(name: str):
-    """Register the fake (shape) kernel of an op.  Every fake kernel also records that tracing has happened
-    in this process: compiled graphs may update a custom op's output in place through generated kernels that
-    do not bump its version counter, so the amax side channel (below) is an eager-mode optimisation and
-    switches itself off for good the first time one of the ops is traced."""
-    def deco(fn):
-        @functools.wraps(fn)
-        def wrapper(*args, **kwargs):
-            global TRACED
-            TRACED = True
-            return fn(*args, **kwargs)
-        return torch.library.register_fake(f"paradis::{name}")(wrapper)
-    return deco
+    """Register the fake (shape) kernel of an op."""
+    return torch.library.register_fake(f"paradis::{name}")
 
 
 def _autograd(name: str, setup, backward) -> None:
@@ -207,45 +193,6 @@ def _bstride_view(t: Tensor, K: int, H: int, W: int) -> Tuple[Tensor, int]:
     return t.contiguous(), K * H * W
 
 
-# ---------------------------------------------------------------------------
-# amax side outputs (f16x2 GEMM scheme): the kernels that produce most GEMM operands also leave the
-# partial maxima of what they store in a small tensor attached to their output, so the consuming GEMM
-# needs no read pass of its own (ops.amax_partials is the fallback for every other producer).
-# ---------------------------------------------------------------------------
-AMAX_SIDE_OUTPUTS = os.environ.get("PARADIS_AMAX_SIDE", "1") != "0"   # 0: every operand gets its own read pass
-_AMAX_POOL = []        # zeroed int32[AMAX_PARTIALS] tensors, handed out one by one
-_AMAX_DEVICE = None
-
-
-def _amax_new(device):
-    """Zeroed words for a producer's side output; None when the GEMM scheme does not need them or once
-    the ops have been traced (see ``_fake``).  Every hand-out is a tensor with its own storage
-    (custom-op outputs must not be views: inductor rebuilds graph outputs from the fake kernel's metadata,
-    storage offset 0); 256 of them are zeroed by one multi-tensor fill."""
-    global _AMAX_POOL, _AMAX_DEVICE
-    if GEMM_SCHEME != GEMM_F16X2 or TRACED or not AMAX_SIDE_OUTPUTS:
-        return None
-    if not _AMAX_POOL or _AMAX_DEVICE != device:
-        _AMAX_POOL = [torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=device) for _ in range(256)]
-        torch._foreach_zero_(_AMAX_POOL)
-        _AMAX_DEVICE = device
-    return _AMAX_POOL.pop()
-
-
-def _amax_attach(t, am):
-    """Remember ``am`` as the amax partials of ``t`` (valid while ``t`` is not modified in place)."""
-    if am is not None:
-        t._paradis_amax = (t._version, am)
-    return t
-
-
-def _amax_lookup(t):
-    if TRACED:
-        return None
-    ent = getattr(t, "_paradis_amax", None) if t is not None else None
-    return ent[1] if ent is not None and ent[0] == t._version else None
-
-
 @_define(f"sl_advect(Tensor field, Tensor u, Tensor v, Tensor sin_lat, Tensor cos_lat, Tensor lon, {_ADV_GEOM}) -> Tensor")
 def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     _f32(field, u, v)
@@ -258,11 +205,10 @@ def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode
         u_bs = K * H * W
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
-    am = _amax_new(field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
               dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
-              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), dptr(am), stream_ptr())
-    return _amax_attach(out, am)
+              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), None, stream_ptr())
+    return out
 
 
 @_fake("sl_advect")
@@ -323,11 +269,10 @@ def _sl_advect_vel(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, m
     P = K * H * W
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
-    am = _amax_new(field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(vel[:, :K]), dptr(vel[:, K:]), dptr(out),
               dptr(sl), dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), dptr(am), stream_ptr())
-    return _amax_attach(out, am)
+              flags, dptr(ws), None, stream_ptr())
+    return out
 
 
 @_fake("sl_advect_vel")
@@ -347,15 +292,11 @@ def _sl_advect_vel_backward(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, 
     gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
     gvel = torch.empty_like(vel)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
-    # gfield and gvel are the cotangents of the down-projection and of the velocity network's last GEMM
-    side = bool(lib.paradis_sl_advect_bwd_has_amax(H, W, mode, flags))
-    am_f = _amax_new(gout.device) if side else None
-    am_v = _amax_new(gout.device) if side else None
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
               dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
               dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), dptr(am_f), dptr(am_v), stream_ptr())
-    return _amax_attach(gfield, am_f), _amax_attach(gvel, am_v)
+              flags, dptr(ws), None, None, stream_ptr())
+    return gfield, gvel
 
 
 @_fake("sl_advect_vel_backward")
@@ -426,10 +367,9 @@ def _dwconv_geo(x, weight, bias):
     assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
     w = weight.contiguous()
     y = torch.empty_like(x)
-    am = _amax_new(x.device)
-    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, dptr(am), stream_ptr()),
+    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, None, stream_ptr()),
           "dwconv_geo_fwd")
-    return _amax_attach(y, am)
+    return y
 
 
 @_fake("dwconv_geo")
@@ -627,11 +567,10 @@ def _channel_norm(x1, x2, weight, bias, eps):
     y = torch.empty(B, C1 + C2, H, W, dtype=x1.dtype, device=x1.device)
     mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
     rstd = torch.empty_like(mean)
-    am = _amax_new(x1.device)
     check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y), dptr(mean),
-                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, dptr(am), stream_ptr()),
+                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, None, stream_ptr()),
           "channel_norm_fwd")
-    return _amax_attach(y, am), mean, rstd
+    return y, mean, rstd
 
 
 @_fake("channel_norm")
@@ -663,12 +602,11 @@ def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
     gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
     gb = torch.empty_like(gw)
     ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
-    am = _amax_new(gy.device)      # gx1 is the cotangent of the GEMM that produced the block's input
     check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight), dptr(mean),
                                        dptr(rstd), dptr(gx1), dptr(gx2) if C2 else None, dptr(gw), dptr(gb), B,
                                        C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add), add_bs, dptr(ws),
-                                       dptr(am), stream_ptr()), "channel_norm_bwd")
-    return _amax_attach(gx1, am), gx2, gw, gb
+                                       None, stream_ptr()), "channel_norm_bwd")
+    return gx1, gx2, gw, gb
 
 
 @_fake("channel_norm_backward")
@@ -872,24 +810,27 @@ def global_bias_m8(A, U, V):
 # (reference model/blocks.py:86,110 + :196 + activation + the residual adds of paradis.py:246,253)
 # ---------------------------------------------------------------------------
 # Arithmetic of the pointwise GEMMs (include/paradis_hip.h, a6), all fp32 in / accumulate / out:
-#   "f16x2"  (default) two f16 terms of the per-tensor scaled operands, three products on the f16 matrix pipe
-#            (22 significand bits; error vs fp64 that of an fp32 SGEMM: tests/test_hip_gemm_split.py);
-#   "bf16x3" three bf16 terms, six products: exact decomposition, error not above the f32 MFMA path's;
-#   "exact"  the f32 MFMA chain.
-# PARADIS_GEMM selects ("split" = bf16x3, the name of earlier rounds).
+#   "bf16x3" (default) three bf16 terms per operand value (an exact decomposition of the 24-bit significand with
+#            fp32's exponent range per element), six products on the bf16 matrix pipe; error vs fp64 not above the
+#            f32 MFMA chain's (tests/test_hip_gemm_split.py);
+#   "exact"  the f32 MFMA chain (v_mfma_f32_32x32x2_f32);
+#   "f16x2"  OPT-IN, not reference-width arithmetic: two f16 terms of the per-TENSOR scaled operands (a block-exponent
+#            format: 22 significand bits relative to the tensor's largest magnitude), three products on the f16 pipe.
+# PARADIS_GEMM selects ("split" = bf16x3, the name of earlier rounds).  The scheme is an explicit integer argument of
+# the ops below (as it is at the C ABI), so a traced graph pins the arithmetic it was traced with.
 GEMM_EXACT, GEMM_F16X2, GEMM_BF16X3 = 0, 2, 3
 _SCHEMES = {"exact": GEMM_EXACT, "f16x2": GEMM_F16X2, "bf16x3": GEMM_BF16X3, "split": GEMM_BF16X3}
 AMAX_PARTIALS = 1024
 
 
 def _scheme_from_env() -> int:
-    name = os.environ.get("PARADIS_GEMM", "f16x2")
+    name = os.environ.get("PARADIS_GEMM", "bf16x3")
     if name not in _SCHEMES:
         raise ValueError(f"PARADIS_GEMM={name!r}: choose between {'|'.join(_SCHEMES)}")
     return _SCHEMES[name]
 
 
-GEMM_SCHEME = _scheme_from_env()
+GEMM_SCHEME = _scheme_from_env()     # what the Python wrappers pass to the ops when the caller names no scheme
 
 
 def gemm_scheme_name() -> str:
@@ -898,15 +839,28 @@ def gemm_scheme_name() -> str:
 
 # split tile images of the weights (split GEMMs) are rebuilt only when the weights change:
 # keyed on the parameter object, its data pointer, its autograd version (every torch in-place update
-# bumps it) and WEIGHT_EPOCH, which the HIP optimisers bump (their kernels write through raw pointers).
+# bumps it) and WEIGHT_EPOCH, which every optimiser step bumps (the HIP optimisers write through raw
+# pointers, and foreign optimisers / EMA helpers may write through ``.data``: a global optimizer-step
+# post-hook covers both).  Raw writes outside an optimiser step (a user kernel, ``p.data.copy_``) must be
+# followed by ``ops.weights_updated()``.
 WEIGHT_EPOCH = 0
 _IMAGES = {}     # (id(weight), transpose, scheme) -> (weakref, data_ptr, version, epoch, image)
 
 
 def weights_updated() -> None:
-    """Called by optimisers that update parameters through the C ABI (no version-counter bump)."""
+    """Invalidate the cached weight images: call after any parameter write that bypasses autograd's version
+    counter.  Optimiser steps do it by themselves (hook below)."""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
+
+
+def _optimizer_step_hook(optimizer, args, kwargs) -> None:
+    weights_updated()
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_post_hook  # noqa: E402
+
+_register_step_post_hook(_optimizer_step_hook)
 
 
 def _drop_images(wid: int) -> None:
@@ -915,11 +869,16 @@ def _drop_images(wid: int) -> None:
         _IMAGES.pop((wid, True, scheme), None)
 
 
-def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool) -> Tensor:
-    scheme = GEMM_SCHEME
+def _version_of(t: Tensor) -> int:
+    """autograd version counter; inference tensors (created under ``torch.inference_mode()``, the mode Lightning
+    runs validation / predict steps in) do not track one and cannot be updated in place outside that mode: 0."""
+    return 0 if t.is_inference() else t._version
+
+
+def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int) -> Tensor:
     key = (id(weight), transpose, scheme)
     ent = _IMAGES.get(key)
-    ver = weight._version
+    ver = _version_of(weight)
     if ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == ver and \
             ent[3] == WEIGHT_EPOCH:
         return ent[4]
@@ -942,12 +901,8 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool) -> Tensor:
 @_define("amax_partials(Tensor x) -> Tensor")
 def _amax_partials(x):
     """int32[AMAX_PARTIALS]: bit patterns of partial maxima of |x| ([B,C,H,W], channel-sliced views allowed);
-    the f16x2 GEMMs take the maximum of the words as the tensor's largest magnitude.  One read pass -
-    or none, when the kernel that produced ``x`` left the words behind (amax side outputs)."""
+    the opt-in f16x2 GEMMs take the maximum of the words as the tensor's largest magnitude.  One read pass."""
     _f32(x)
-    have = _amax_lookup(x)
-    if have is not None:       # left behind by the kernel that produced x
-        return have
     x, x_bs = _plane_view(x)
     B, C, H, W = x.shape
     out = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
@@ -960,17 +915,13 @@ def _(x):
     return x.new_empty(AMAX_PARTIALS, dtype=torch.int32)
 
 
-def _amax_for_gemm(x):
-    """amax partials of a GEMM operand when the scheme needs them, else None"""
-    return _amax_partials(x) if GEMM_SCHEME == GEMM_F16X2 else None
-
-
 @_define("pointwise(Tensor x, Tensor weight, Tensor? bias, Tensor? bmap, Tensor? residual, int act, "
-         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z, bool y_feeds_gemm) "
+         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z, int scheme) "
          "-> (Tensor, Tensor, Tensor)")
-def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, y_feeds_gemm):
+def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme):
     """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z);
     third = amax partials of x (f16x2 scheme; empty otherwise), kept for the weight gradient.
+    ``scheme``: GEMM arithmetic (GEMM_EXACT / GEMM_BF16X3 / GEMM_F16X2); the backward uses the same.
 
     Activation-gradient hand-off between two chained ops (GMBlock drives it):
       * ``defer_act_grad`` (producer): the op's backward receives d(pre-activation) directly and
@@ -980,7 +931,6 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         ``x`` already is the producer's d(pre-activation).
     """
     _f32(x, weight, bias, bmap, residual, m8, pw)
-    x_side = _amax_lookup(x)
     x, x_bs = _plane_view(x)
     B, Ci, H, W = x.shape
     Co = weight.shape[0]
@@ -1002,15 +952,11 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
     z = torch.empty_like(y) if (save_z and act != 0) else y.new_empty(0)
     w2 = w2t = wsp = None
     x_amax = x.new_empty(0, dtype=torch.int32)
-    if GEMM_SCHEME != GEMM_EXACT:
-        wsp = _split_image(weight, Co, Ci, False)   # split planes in tile order
-        if GEMM_SCHEME == GEMM_F16X2:
-            if x_side is not None:
-                x_amax = x_side
-            else:
-                x_amax = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
-                check(lib.paradis_amax_partials(dptr(x), B, Ci * P, x_bs, dptr(x_amax), stream_ptr()),
-                      "amax_partials")
+    if scheme != GEMM_EXACT:
+        wsp = _split_image(weight, Co, Ci, False, scheme)   # split planes in tile order
+        if scheme == GEMM_F16X2:
+            x_amax = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
+            check(lib.paradis_amax_partials(dptr(x), B, Ci * P, x_bs, dptr(x_amax), stream_ptr()), "amax_partials")
     else:
         w2 = weight.reshape(Co, Ci).contiguous()
         if Ci % 16 == 0 and Co % 4 == 0 and Co * Ci >= 4096:
@@ -1021,20 +967,19 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         w2 = weight.reshape(Co, Ci)
         if not w2.is_contiguous():
             w2 = w2.contiguous()
-    y_am = _amax_new(x.device) if (defer_act_grad or y_feeds_gemm) else None   # y is the next GEMM's operand as it is
-    _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), GEMM_SCHEME,
+    _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), scheme,
               dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
               dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
-              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, dptr(y_am), stream_ptr())
-    return _amax_attach(y, y_am), z, x_amax
+              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, None, stream_ptr())
+    return y, z, x_amax
 
 
 @_fake("pointwise")
-def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, y_feeds_gemm):
+def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme):
     B, _, H, W = x.shape
     y = x.new_empty(B, weight.shape[0], H, W)
     return (y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0)),
-            x.new_empty(AMAX_PARTIALS if GEMM_SCHEME == GEMM_F16X2 else 0, dtype=torch.int32))
+            x.new_empty(AMAX_PARTIALS if scheme == GEMM_F16X2 else 0, dtype=torch.int32))
 
 
 @_define("act_backward(Tensor gy, Tensor z, int act) -> Tensor")
@@ -1042,9 +987,8 @@ def _act_backward(gy, z, act):
     _f32(gy, z)
     gy, z = gy.contiguous(), z.contiguous()
     dz = torch.empty_like(gy)
-    am = _amax_new(gy.device)
-    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, dptr(am), stream_ptr()), "act_bwd")
-    return _amax_attach(dz, am)
+    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, None, stream_ptr()), "act_bwd")
+    return dz
 
 
 @_fake("act_backward")
@@ -1052,8 +996,8 @@ def _(gy, z, act):
     return gy.new_empty(gy.shape)
 
 
-@_define("pw_gemm_dgrad(Tensor dz, Tensor weight, Tensor? zmul, int x_act, Tensor? dz_amax) -> Tensor")
-def _pw_gemm_dgrad(dz, weight, zmul, x_act, dz_amax):
+@_define("pw_gemm_dgrad(Tensor dz, Tensor weight, Tensor? zmul, int x_act, Tensor? dz_amax, int scheme) -> Tensor")
+def _pw_gemm_dgrad(dz, weight, zmul, x_act, dz_amax, scheme):
     """gx = W^T dz (* act'(zmul) when the producing layer deferred its activation gradient).
     dz_amax: amax partials of dz (f16x2 scheme; computed here when missing)."""
     _f32(dz, weight, zmul)
@@ -1065,27 +1009,27 @@ def _pw_gemm_dgrad(dz, weight, zmul, x_act, dz_amax):
     w2 = weight.reshape(Co, Ci)
     if not w2.is_contiguous():
         w2 = w2.contiguous()
-    wtsp = _split_image(weight, Co, Ci, True) if GEMM_SCHEME != GEMM_EXACT else None
-    if GEMM_SCHEME == GEMM_F16X2 and dz_amax is None:
+    wtsp = _split_image(weight, Co, Ci, True, scheme) if scheme != GEMM_EXACT else None
+    if scheme == GEMM_F16X2 and dz_amax is None:
         dz_amax = _amax_partials(dz)
     if zmul is not None:
         zmul = zmul.contiguous()
-    gx_am = _amax_new(dz.device) if x_act != 0 else None   # deferred chain: gx is the previous layer's dz
-    _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), GEMM_SCHEME,
-              dptr(dz_amax) if GEMM_SCHEME == GEMM_F16X2 else None, dptr(dz),
+    _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), scheme,
+              dptr(dz_amax) if scheme == GEMM_F16X2 else None, dptr(dz),
               dptr(zmul) if x_act != 0 else None, None, dptr(gx), B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P,
-              x_act, dptr(gx_am), stream_ptr())
-    return _amax_attach(gx, gx_am)
+              x_act, None, stream_ptr())
+    return gx
 
 
 @_fake("pw_gemm_dgrad")
-def _(dz, weight, zmul, x_act, dz_amax):
+def _(dz, weight, zmul, x_act, dz_amax, scheme):
     B, Co, H, W = dz.shape
     return dz.new_empty(B, weight.numel() // Co, H, W)
 
 
-@_define("pw_gemm_wgrad(Tensor dz, Tensor x, bool want_bias, Tensor? dz_amax, Tensor? x_amax) -> (Tensor, Tensor)")
-def _pw_gemm_wgrad(dz, x, want_bias, dz_amax, x_amax):
+@_define("pw_gemm_wgrad(Tensor dz, Tensor x, bool want_bias, Tensor? dz_amax, Tensor? x_amax, int scheme) "
+         "-> (Tensor, Tensor)")
+def _pw_gemm_wgrad(dz, x, want_bias, dz_amax, x_amax, scheme):
     """gW[Co,Ci] = sum over samples and points of dz x^T; the bias gradient (row sums of dz) falls out
     of the same pass.  dz_amax / x_amax: amax partials (f16x2 scheme; computed here when missing)."""
     _f32(dz, x)
@@ -1096,19 +1040,19 @@ def _pw_gemm_wgrad(dz, x, want_bias, dz_amax, x_amax):
     gw = torch.empty(Co, Ci, dtype=dz.dtype, device=dz.device)
     gb = torch.empty(Co if want_bias else 0, dtype=dz.dtype, device=dz.device)
     ws = _ws(lib.paradis_pw_gemm_wgrad_ws_bytes(B, Co, Ci, P), dz.device)
-    f16 = GEMM_SCHEME == GEMM_F16X2
+    f16 = scheme == GEMM_F16X2
     if f16 and (dz_amax is None or dz_amax.numel() == 0):
         dz_amax = _amax_partials(dz)
     if f16 and (x_amax is None or x_amax.numel() == 0):
         x_amax = _amax_partials(x)
     _lib.call("pw_gemm_wgrad", 2.0 * B * Co * Ci * P, dptr(dz), dptr(x), dptr(gw), dptr(gb) if want_bias else None,
-              B, Co, Ci, P, Co * P, x_bs, GEMM_SCHEME, dptr(dz_amax) if f16 else None,
+              B, Co, Ci, P, Co * P, x_bs, scheme, dptr(dz_amax) if f16 else None,
               dptr(x_amax) if f16 else None, dptr(ws), stream_ptr())
     return gw, gb
 
 
 @_fake("pw_gemm_wgrad")
-def _(dz, x, want_bias, dz_amax, x_amax):
+def _(dz, x, want_bias, dz_amax, x_amax, scheme):
     Co, Ci = dz.shape[1], x.shape[1]
     return dz.new_empty(Co, Ci), dz.new_empty(Co if want_bias else 0)
 
@@ -1150,11 +1094,11 @@ def _(gmap, m8, pw):
 
 
 def _pw_setup(ctx, inputs, output):
-    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, _feeds = inputs
+    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, scheme = inputs
     y, z, x_amax = output
     ctx.save_for_backward(x, weight, z, x_pre, m8, pw, x_amax)
     ctx.meta = (act, bias is not None, bmap is not None, residual is not None,
-                x_act if x_pre is not None else 0, bool(defer))
+                x_act if x_pre is not None else 0, bool(defer), scheme)
     # z carries no gradient; without this autograd would materialise a full-size zero tensor for it
     ctx.mark_non_differentiable(z, x_amax)
     ctx.set_materialize_grads(False)
@@ -1162,7 +1106,7 @@ def _pw_setup(ctx, inputs, output):
 
 def _pw_backward(ctx, gy, gz=None, gamax=None):
     x, weight, z, x_pre, m8, pw, x_amax = ctx.saved_tensors
-    act, has_bias, has_map, has_res, x_act, deferred = ctx.meta
+    act, has_bias, has_map, has_res, x_act, deferred, scheme = ctx.meta
     need = ctx.needs_input_grad
     if gy is None:
         return (None,) * 13
@@ -1173,16 +1117,16 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     else:
         dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
     gx = gw = gb = gmap = gm8 = gpw = None
-    # one pass over dz serves both of its GEMMs
-    dz_amax = _amax_for_gemm(dz) if (need[0] or need[1]) else None
+    # f16x2: one read pass over dz serves both of its GEMMs
+    dz_amax = _amax_partials(dz) if (scheme == GEMM_F16X2 and (need[0] or need[1])) else None
     if need[0]:
-        gx = _pw_gemm_dgrad(dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax)
+        gx = _pw_gemm_dgrad(dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme)
     want_b = has_bias and need[2]
     want_p = has_proj and (need[9] or need[10])
     want_m = (has_map and need[3]) or want_p
     if need[1]:
         fused_b = want_b and not want_m     # bias gradient = row sums of dz: fused into the wgrad GEMM
-        gw, gbf = _pw_gemm_wgrad(dz, x, fused_b, dz_amax, x_amax)
+        gw, gbf = _pw_gemm_wgrad(dz, x, fused_b, dz_amax, x_amax, scheme)
         gw = gw.reshape(weight.shape)
         if fused_b:
             gb, want_b = gbf, False
@@ -1202,13 +1146,12 @@ _autograd("pointwise", _pw_setup, _pw_backward)
 
 
 def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
-              defer_act_grad=False, bias_proj=None, feeds_gemm=False):
+              defer_act_grad=False, bias_proj=None, scheme: Optional[int] = None):
     """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1].
 
     ``bias_proj=(m8[Cin,H,W], Pw[Co,Cin])`` adds the projected low-rank GlobalBias map inside the GEMM
     epilogue instead of a materialised ``bias_map``.
-    ``feeds_gemm=True``: ``y`` is the operand of another ``pointwise`` as it is (the f16x2 scheme then takes the
-    operand's largest magnitude from this GEMM's epilogue instead of a read pass).
+    ``scheme``: GEMM arithmetic, default ``ops.GEMM_SCHEME`` (read when the call is made / traced).
     ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
     called with ``x_pre=z, x_act=act`` (see the op docstring); only valid when ``y`` has no other use."""
     if defer_act_grad and (act is None or residual is not None):
@@ -1220,7 +1163,7 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
     y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad),
-                         m8, pw, save_z, bool(feeds_gemm))
+                         m8, pw, save_z, GEMM_SCHEME if scheme is None else int(scheme))
     return (y, z) if defer_act_grad else y
 
 
@@ -1283,10 +1226,9 @@ def _gated_blend_backward(gout, h, adv, alpha):
     B, C, H, W = h.shape
     gh, gadv, galpha = torch.empty_like(h), torch.empty_like(h), torch.empty_like(alpha)
     ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
-    am = _amax_new(h.device)       # gadv is the cotangent of the advection's up-projection GEMM
     check(lib.paradis_gated_blend_bwd(dptr(gout), dptr(h), dptr(adv), dptr(alpha), dptr(gh), dptr(gadv),
-                                      dptr(galpha), B, C, H * W, dptr(ws), dptr(am), stream_ptr()), "gated_blend_bwd")
-    return gh, _amax_attach(gadv, am), galpha
+                                      dptr(galpha), B, C, H * W, dptr(ws), None, stream_ptr()), "gated_blend_bwd")
+    return gh, gadv, galpha
 
 
 @_fake("gated_blend_backward")

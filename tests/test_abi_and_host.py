@@ -163,10 +163,9 @@ def test_synthetic_batch_shapes_and_rollout_glue():
     assert torch.equal(next_input(mi, out, 83, 1), out[:, :83])
 
 
-def test_gemm_scheme_selection_and_amax_side_channel_bookkeeping(monkeypatch):
-    """Host logic of the GEMM arithmetic switch (PARADIS_GEMM) and of the amax side channel: words attached
-    to a tensor are returned while its version counter is unchanged and tracing has not happened."""
-    import torch
+def test_gemm_scheme_selection(monkeypatch):
+    """Host logic of the GEMM arithmetic switch (PARADIS_GEMM): the default is the reference-width bf16x3
+    decomposition; f16x2 is opt-in; the ops carry the scheme as an explicit integer argument."""
     from paradis_model_amd import ops
     for name, code in (("f16x2", 2), ("bf16x3", 3), ("split", 3), ("exact", 0)):
         monkeypatch.setenv("PARADIS_GEMM", name)
@@ -175,14 +174,30 @@ def test_gemm_scheme_selection_and_amax_side_channel_bookkeeping(monkeypatch):
     with pytest.raises(ValueError):
         ops._scheme_from_env()
     monkeypatch.delenv("PARADIS_GEMM")
-    assert ops._scheme_from_env() == ops.GEMM_F16X2                       # the default
-    monkeypatch.setattr(ops, "TRACED", False)
-    t, words = torch.zeros(4), torch.zeros(ops.AMAX_PARTIALS, dtype=torch.int32)
-    assert ops._amax_lookup(t) is None and ops._amax_lookup(None) is None
-    assert ops._amax_attach(t, words) is t and ops._amax_lookup(t) is words
-    assert ops._amax_attach(t, None) is t                                 # no side output produced: nothing changes
-    t.add_(1.0)                                                           # in-place update: version counter moves
-    assert ops._amax_lookup(t) is None
-    ops._amax_attach(t, words)
-    monkeypatch.setattr(ops, "TRACED", True)                              # an op was traced (torch.compile): channel off
-    assert ops._amax_lookup(t) is None and ops._amax_new(torch.device("cpu")) is None
+    assert ops._scheme_from_env() == ops.GEMM_BF16X3                      # the default
+    for op in ("pointwise", "pw_gemm_dgrad", "pw_gemm_wgrad"):
+        schema = str(ops.OPS[op]._schema)
+        assert "int scheme" in schema, schema
+    assert not hasattr(ops, "TRACED") and not hasattr(ops, "_amax_attach")   # no hidden per-tensor / global state
+
+
+def test_weight_image_cache_invalidation():
+    """Cached split weight images are dropped by any optimiser step (global post-hook), by the version counter
+    and by ``ops.weights_updated()``; inference tensors have no version counter and must not raise."""
+    import torch
+    from paradis_model_amd import ops
+    e0 = ops.WEIGHT_EPOCH
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    torch.optim.SGD([p], lr=0.1).step()                                   # a foreign optimiser
+    assert ops.WEIGHT_EPOCH > e0
+    e1 = ops.WEIGHT_EPOCH
+    ops.weights_updated()
+    assert ops.WEIGHT_EPOCH == e1 + 1
+    with torch.inference_mode():
+        t = torch.ones(2)
+    assert ops._version_of(t) == 0
+    q = torch.ones(2)
+    v = ops._version_of(q)
+    q.add_(1)
+    assert ops._version_of(q) == v + 1

@@ -114,15 +114,15 @@ def test_fake_kernels_of_backward_ops_give_the_right_shapes():
         gx1, gx2, gw, gb = O.channel_norm_backward(e(B, C + 2, H, W), e(B, C, H, W), e(B, 2, H, W), e(C + 2),
                                                    e(B, H * W), e(B, H * W), None)
         assert gx1.shape == (B, C, H, W) and gx2.shape == (B, 2, H, W) and gw.shape == (C + 2,)
-        assert O.pw_gemm_dgrad(e(B, 5, H, W), e(5, C, 1, 1), None, 0, None).shape == (B, C, H, W)
-        gw, gb = O.pw_gemm_wgrad(e(B, 5, H, W), e(B, C, H, W), True, None, None)
+        assert O.pw_gemm_dgrad(e(B, 5, H, W), e(5, C, 1, 1), None, 0, None, 3).shape == (B, C, H, W)
+        gw, gb = O.pw_gemm_wgrad(e(B, 5, H, W), e(B, C, H, W), True, None, None, 3)
         assert gw.shape == (5, C) and gb.shape == (5,)
         gb, gmap = O.bias_grads(e(B, 5, H, W), False, True)
         assert gb.numel() == 0 and gmap.shape == (5, H, W)
-        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, True, False)
-        assert y.shape == z.shape == (B, 5, H, W)
-        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, False, False)
-        assert z.numel() == 0
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, True, 3)
+        assert y.shape == z.shape == (B, 5, H, W) and am.numel() == 0
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, False, 2)
+        assert z.numel() == 0 and am.numel() == 1024     # the f16x2 scheme's amax words are an explicit op output
         assert O.concat_channels([e(B, 3, H, W), e(B, 4, H, W)]).shape == (B, 7, H, W)
         assert O.slice_channels(e(B, 7, H, W), 3, 4).shape == (B, 4, H, W)
         loss, grad = O.paradis_loss(e(B, C, H, W), e(B, C, H, W), e(C), e(H), 1, 1.0, True)

@@ -87,18 +87,21 @@ def test_cfg2_six_step_rollout_default_model_vs_oracle():
                                    num_common=83, n_inputs=2, keep_outputs=True)
     errs = [max_rel(g.cpu(), w) for g, w in zip(outs, want_outs)]
     print("cfg2 per-step forward max-rel", ["%.1e" % e for e in errs])
-    # step 1 is the 1e-5 bar; later steps feed fp32-level differences back through the model, the
-    # oracle's own fp32-vs-fp64 gap grows the same way (measured ~2x per step)
-    assert errs[0] <= 1e-5, errs
-    assert max(errs) <= 1e-4, errs
+    # every one of the six steps at the 1e-5 bar (measured 2.0-2.4e-6 at each step)
+    assert max(errs) <= 1e-5, errs
     assert abs(float(got_total) - float(total)) <= 5e-6 * abs(float(total))
     ga = model.alpha_adv.grad.cpu()
     e_alpha = max_rel(ga, P["alpha_adv"].grad)
     print("cfg2 alpha_adv grad max-rel", e_alpha)
-    assert e_alpha <= 1e-3, e_alpha
+    assert e_alpha <= 1e-4, e_alpha          # measured 2e-6
+    worst = ("", 0.0)
     for n, p in model.named_parameters():
         want = float(P[n].grad.norm())
-        assert abs(float(p.grad.norm()) - want) <= 2e-3 * want + 1e-9, n
+        rel = abs(float(p.grad.norm()) - want) / (want + 1e-30)
+        if rel > worst[1]:
+            worst = (n, rel)
+        assert abs(float(p.grad.norm()) - want) <= 5e-4 * want + 1e-9, (n, rel)
+    print("cfg2 worst parameter-gradient norm deviation", worst)
 
 
 def test_cfg2_full_batch_rollout_properties():
@@ -155,6 +158,90 @@ def test_cfg3_default_model_128x256_forward_vs_oracle():
     e = max_rel(got, want)
     print("cfg3 128x256 default-model forward max-rel", e)
     assert e <= 1e-5, e
+
+
+def _oracle_grads_ckpt(model, spec, x, ct, lg, og, dtype):
+    """oracle forward + every parameter gradient with one ADR layer's intermediates alive at a time"""
+    ps = {k: v.detach().cpu().to(dtype).requires_grad_(True) if v.dtype.is_floating_point else v.detach().cpu()
+          for k, v in model.state_dict().items()}
+    y = O.paradis_forward(ps, spec, x.to(dtype), lg.to(dtype), og.to(dtype),
+                          interp_impl="aten_ref" if dtype == torch.float32 else "taps", checkpoint_layers=True)
+    (y * ct.to(dtype)).sum().backward()
+    return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
+
+
+def test_cfg3_default_model_128x256_gradients_fp64_protocol():
+    """configs[3]'s per-sample work inside the 60 M-parameter model: forward AND every parameter gradient at
+    128x256, B=1 - the tile-row advection scatter with its window flush, the GlobalBias projection adjoint
+    behind the GEMM epilogue, split-k weight gradients over 32,768 points - by the fp64 protocol of SURVEY 8c(iii):
+    the HIP gradient's distance to the fp64 oracle against the CPU-fp32 oracle's own distance."""
+    from tests.test_hip_model import _check_grads_by_fp64_protocol
+    cfg = default_config()
+    H, W = 128, 256
+    _, lg, og = make_grid(H, W, False)
+    model = _build(cfg, lg, og)
+    spec = _spec(cfg, H, W)
+    x = seeded(23, 1, 186, H, W)
+    x[:, -2], x[:, -1] = lg, og
+    ct = seeded(24, 1, 97, H, W)
+    y32, g32 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float32)
+    y64, g64 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float64)
+    got = model(x.cuda())
+    (got * ct.cuda()).sum().backward()
+    e, e_cpu = max_rel(got.detach().cpu(), y32), max_rel(y32, y64)
+    print("cfg3 128x256 default model: forward max-rel vs cpu32 %.2e (cpu32 vs fp64 %.2e)" % (e, e_cpu))
+    assert e <= 1e-5, e
+    worst = _check_grads_by_fp64_protocol(model, g32, g64)
+    print("cfg3 128x256 default model: worst grad error vs fp64 (gpu, cpu32)", worst)
+
+
+def test_cfg3_train_step_b8_properties():
+    """configs[3] per GPU: one training step (forward + ParadisLoss + backward + AdamW) of the default model at
+    128x256 with the per-GPU batch of 8.  Too large for the CPU oracle, so size-independent properties:
+    everything finite, the batch loss equals the mean of the eight per-sample losses (samples never interact:
+    reference trainer.py:508-576), the batch gradient equals the mean of per-sample gradients on a probe
+    parameter set, the step fits one MI355X and every parameter moves."""
+    from paradis_model_amd.harness import TrainStep, rollout_loss
+    from paradis_model_amd.loss import build_loss
+    cfg = default_config()
+    H, W, B = 128, 256, 8
+    lat_deg, lg, og = make_grid(H, W, False)
+    model = _build(cfg, lg, og)
+    loss_fn = build_loss(cfg, lat_deg).cuda()
+    batch = tuple(t.cuda() for t in _batch(B, 1, H, W, lg, og, seed0=300))
+    probes = [n for n, _ in model.named_parameters()
+              if n in ("alpha_adv", "velocity_nets.3.1-SepConv.pointwise.weight", "advection.5.up_projection.0-CLinear.conv.bias",
+                       "reaction.7.0-ChannelNorm.weight", "diffusion.0.0-GlobalBias.U", "output_proj.2-CLinear.conv.weight")]
+    assert len(probes) == 6, probes
+    named = dict(model.named_parameters())
+    # per-sample losses and gradients of the probes
+    per_loss, per_grad = [], {n: 0.0 for n in probes}
+    for b in range(B):
+        model.zero_grad(set_to_none=True)
+        one = tuple(t[b:b + 1] for t in batch)
+        lb, _ = rollout_loss(model, loss_fn, one, num_common=83, n_inputs=2)
+        per_loss.append(float(lb))
+        for n in probes:
+            per_grad[n] = per_grad[n] + named[n].grad.detach().double() / B
+    before = {n: p.detach().clone() for n, p in named.items()}
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    step = TrainStep(model, loss_fn, cfg, num_common=83, n_inputs=2)
+    total = step(batch)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated()
+    print("cfg3 B=8 128x256 train step: peak HBM %.1f GB, loss %.6f" % (peak / 1e9, float(total)))
+    assert peak < 288e9 and torch.isfinite(total)
+    mean = sum(per_loss) / B
+    assert abs(mean - float(total)) <= 2e-6 * abs(mean), (mean, float(total))
+    for n in probes:
+        e = max_rel(named[n].grad.double(), per_grad[n])
+        assert e <= 2e-5, (n, e)           # fp32 sums in a different order (8 samples at once vs one by one)
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in named.items())
+    assert moved == len(named), (moved, len(named))
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    del model, batch, loss_fn, step
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -298,100 +298,57 @@ def test_split_extreme_magnitudes(ops):
         assert not torch.isfinite(ys[0, 5]).any() and torch.isfinite(ys[0, :5]).all()
 
 
-def test_amax_side_outputs(ops):
-    """Producer kernels leave the partial maxima of what they store attached to their output (f16x2
-    scheme): equal to a read pass (an upper bound for the advection's pole rows), picked up by
-    ops.amax_partials without a launch, and dropped when the tensor is modified in place."""
-    from tests._util import make_grid
-    keep, keep_traced = ops.GEMM_SCHEME, ops.TRACED
-    ops.GEMM_SCHEME = ops.GEMM_F16X2
-    ops.TRACED = False          # (tracing any op - torch.compile, opcheck in other tests - switches the channel off)
-    try:
-        g = torch.Generator().manual_seed(31)
-        B, C, H, W = 2, 64, 32, 64
+def test_amax_side_outputs_c_abi(ops):
+    """C-ABI feature kept for the opt-in f16x2 scheme: producer kernels take an optional zeroed
+    ``uint32[PARADIS_AMAX_PARTIALS]`` and add the partial maxima of what they store (include/paradis_hip.h).
+    The Python ops no longer use it (every f16x2 operand gets its read pass: no hidden state next to a tensor);
+    here the words are compared with a read pass through the ABI directly."""
+    from paradis_model_amd._lib import check, dptr, lib, stream_ptr
+    g = torch.Generator().manual_seed(31)
+    B, C, H, W = 2, 64, 32, 64
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.randn(C, generator=g) + 1).cuda()
+    b = torch.randn(C, generator=g).cuda()
 
-        def amax_of(words):
-            return float(words.max().view(1).view(torch.float32))
+    def amax_of(words):
+        return float(words.max().view(1).view(torch.float32))
 
-        def check(t, exact=True):
-            words = ops._amax_lookup(t)
-            assert words is not None, "no side output attached"
-            got, want = amax_of(words), float(t.detach().abs().max())
-            assert got == want if exact else (want <= got <= 4 * want), (got, want)
-            assert ops._amax_partials(t) is words      # no read pass
-            return words
-
-        x = torch.randn(B, C, H, W, generator=g).cuda()
-        w = (torch.randn(C, generator=g) + 1).cuda()
-        b = torch.randn(C, generator=g).cuda()
-        check(ops.channel_norm(x, w, b, 1e-5))
-        dw = torch.randn(C, 1, 5, 5, generator=g).cuda()
-        check(ops.dwconv_geo(x, dw, b))
-        pw = (torch.randn(48, C, generator=g) * 0.1).cuda().requires_grad_(True)
-        xin = x.clone().requires_grad_(True)
-        y, zpre = ops.pointwise(xin, pw, None, None, None, "SiLU", defer_act_grad=True)   # chained CLinear layers
-        check(y)
-        assert ops._amax_lookup(ops.pointwise(xin, pw, None, None, None, "SiLU")) is None   # (only then)
-        _, lg, og = make_grid(H, W, False)
-        geom = ops.AdvectGeometry(lg, og)
-        vel = (torch.randn(B, 2 * C, H, W, generator=g) * 0.3).cuda()
-        check(ops.sl_advect_vel(x, vel, geom, 0.05, "bicubic"), exact=False)
-        # backward producers: act_backward (dz of the GEMM above) and the dgrad epilogue
-        gy = torch.randn(B, 48, H, W, generator=g).cuda()
-        dz = ops._act_backward(gy, y.detach(), 1)
-        check(dz)
-        gx = ops._pw_gemm_dgrad(dz, pw.detach(), x, 1, None)     # deferred chain: gx = W^T dz * act'(x_pre)
-        check(gx)
-        # cotangent producers: ChannelNorm backward (gx1), gated blend backward (gadv), advection backward
-        mean = torch.zeros(B, H * W).cuda(); rstd = torch.ones(B, H * W).cuda()
-        gx1 = ops._channel_norm_backward(x, x, None, w, mean, rstd, None)[0]
-        check(gx1)
-        alpha = torch.randn(C, generator=g).cuda()
-        check(ops._gated_blend_backward(x, x, x * 0.5, alpha)[1])
-        gf, gvel = ops._sl_advect_vel_backward(x, x, vel, *ops._geom_args(geom, x.device, 0.05, "bicubic", None))
-        check(gf)
-        check(gvel)
-        # an in-place update invalidates the attachment
-        gx.mul_(2.0)
-        assert ops._amax_lookup(gx) is None
-        assert amax_of(ops._amax_partials(gx)) == float(gx.abs().max())
-        # ragged GEMM tiles (guarded epilogue path) and a shape smaller than one tile
-        for (Co, Ci, h, wd) in ((97, 186, 9, 20), (7, 10, 4, 8)):
-            xs = torch.randn(1, Ci, h, wd, generator=g).cuda()
-            ws = torch.randn(Co, Ci, generator=g).cuda()
-            check(ops.pointwise(xs, ws, None, None, None, "SiLU", defer_act_grad=True)[0])
-        # once an op has been traced with fake tensors the channel stays off: a compiled graph may update a
-        # custom op's output in place without touching its version counter
-        ops.TRACED = True
-        assert ops._amax_lookup(ops.dwconv_geo(x, dw, b)) is None
-    finally:
-        ops.GEMM_SCHEME, ops.TRACED = keep, keep_traced
+    words = torch.zeros(ops.AMAX_PARTIALS, dtype=torch.int32, device="cuda")
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(B, H * W, device="cuda"), torch.empty(B, H * W, device="cuda")
+    check(lib.paradis_channel_norm_fwd(dptr(x), None, dptr(w), dptr(b), dptr(y), dptr(mean), dptr(rstd), B, C, 0,
+                                       H * W, C * H * W, 0, 1e-5, dptr(words), stream_ptr()), "channel_norm_fwd")
+    assert amax_of(words) == float(y.abs().max()) == amax_of(ops._amax_partials(y))
+    words.zero_()
+    dw = torch.randn(C, 1, 5, 5, generator=g).cuda()
+    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(dw), dptr(b), dptr(y), B, C, H, W, 5, dptr(words), stream_ptr()),
+          "dwconv_geo_fwd")
+    assert amax_of(words) == float(y.abs().max())
+    words.zero_()
+    check(lib.paradis_act_bwd(dptr(x), dptr(y), dptr(mean.new_empty(x.shape)), x.numel(), 1, dptr(words),
+                              stream_ptr()), "act_bwd")
+    assert amax_of(words) == float(ops._act_backward(x, y, 1).abs().max())
 
 
-def test_model_gradients_do_not_depend_on_the_amax_side_channel(ops):
-    """A training step of the reduced model with the producers' amax side outputs and with one read pass per
-    GEMM operand: same loss and gradients (the scales are powers of two; only the advection's upper bound can
-    move one by a binade)."""
-    from paradis_model_amd.config import reduced_config, stub_datamodule
-    from paradis_model_amd.model import Paradis
-    from tests._util import make_grid, max_rel
-    keep = (ops.GEMM_SCHEME, ops.TRACED, ops.AMAX_SIDE_OUTPUTS)
-    ops.GEMM_SCHEME, ops.TRACED = ops.GEMM_F16X2, False
-    try:
-        cfg = reduced_config()
-        _, lg, og = make_grid(32, 64, False)
-        torch.manual_seed(42)
-        model = Paradis(stub_datamodule(cfg), cfg, lg, og).cuda()
-        x = seeded(3, 2, 186, 32, 64).cuda()
-        res = []
-        for side in (True, False):
-            ops.AMAX_SIDE_OUTPUTS = side
-            model.zero_grad(set_to_none=True)
-            xd = x.clone().requires_grad_(True)
-            y = model(xd)
-            y.square().mean().backward()
-            res.append((y.detach(), xd.grad, torch.cat([p.grad.flatten() for p in model.parameters()])))
-        for a, b in zip(res[0], res[1]):
-            assert max_rel(a, b) <= 1e-5
-    finally:
-        ops.GEMM_SCHEME, ops.TRACED, ops.AMAX_SIDE_OUTPUTS = keep
+def test_f16x2_is_opt_in_and_traceable(ops):
+    """The default arithmetic is bf16x3; f16x2 is chosen per call (``scheme=``) or through ``ops.GEMM_SCHEME`` and
+    is an explicit integer argument of the ops, so its amax words are ordinary op outputs / inputs (no tensor
+    attributes): forward under ``torch.inference_mode()`` works, and a gradient step with it equals one whose
+    operands were scaled by read passes anyway (there is no other path any more)."""
+    assert ops._scheme_from_env.__defaults__ is None
+    import os
+    if "PARADIS_GEMM" not in os.environ:
+        assert ops.GEMM_SCHEME == ops.GEMM_BF16X3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 16, 32, generator=g).cuda()
+    w = (torch.randn(48, 64, generator=g) * 0.1).cuda()
+    want = torch.einsum("oc,bchw->bohw", w.double(), x.double())
+    with torch.inference_mode():
+        for scheme in (ops.GEMM_F16X2, ops.GEMM_BF16X3, ops.GEMM_EXACT):
+            y = ops.pointwise(x, w, scheme=scheme)
+            assert _err(y.cpu(), want.cpu()) <= 2e-6
+    wr, xr = w.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ops.pointwise(xr, wr, act="SiLU", scheme=ops.GEMM_F16X2).square().sum().backward()
+    wd, xd = w.double().requires_grad_(True), x.double().requires_grad_(True)
+    torch.nn.functional.silu(torch.einsum("oc,bchw->bohw", wd, xd)).square().sum().backward()
+    assert _err(wr.grad.cpu(), wd.grad.cpu()) <= 2e-6 and _err(xr.grad.cpu(), xd.grad.cpu()) <= 2e-6

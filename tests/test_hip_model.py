@@ -121,7 +121,7 @@ def _oracle_grads(model, spec, x, ct, lg, og, dtype):
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
 
-def _check_grads_by_fp64_protocol(model, g32, g64, factor=6.0, floor=2e-5):
+def _check_grads_by_fp64_protocol(model, g32, g64, factor=4.0, floor=2e-5):
     """the HIP gradient's distance to the fp64 oracle against the CPU fp32 oracle's own
     distance (the velocity path amplifies fp32 coordinate rounding; a few ill-conditioned points
     near the poles decide the maximum of a weight gradient).  Measured on the default model
@@ -131,15 +131,18 @@ def _check_grads_by_fp64_protocol(model, g32, g64, factor=6.0, floor=2e-5):
     products of a dot product one after the other (512 updates for K = 1024), the CPU's vector units
     keep 16 partial sums per accumulator - sqrt(512/64) = 2.8."""
     worst = ("", 0.0, 0.0)
+    bad = []
     for n, p in model.named_parameters():
         ref = g64.get(n)
         if ref is None or float(ref.abs().max()) == 0:
             continue
         e_gpu = max_rel(p.grad.cpu().double(), ref)
         e_cpu = max_rel(g32[n].double(), ref)
-        assert e_gpu <= factor * e_cpu + floor, (n, e_gpu, e_cpu)
+        if not e_gpu <= factor * e_cpu + floor:
+            bad.append((n, e_gpu, e_cpu))
         if e_gpu > worst[1]:
             worst = (n, e_gpu, e_cpu)
+    assert not bad, bad
     return worst
 
 
@@ -194,7 +197,9 @@ def test_reduced_model_on_large_grids_vs_oracle(nlat, nlon, poles):
     _, g64 = _oracle_grads(model, spec, x, ct, lg, og, torch.float64)
     got = model(x.cuda())
     (got * ct.cuda()).sum().backward()
-    assert max_rel(got.detach().cpu(), y32) <= 2e-5
+    e_fwd = max_rel(got.detach().cpu(), y32)
+    print("large-grid reduced model forward max-rel", nlat, nlon, e_fwd)
+    assert e_fwd <= 1e-5, e_fwd
     worst = _check_grads_by_fp64_protocol(model, g32, g64)
     print("large-grid worst grad error vs fp64 (gpu, cpu32)", nlat, nlon, worst)
 
@@ -210,3 +215,25 @@ def test_gradient_checkpointing_matches():
         m(x).square().mean().backward()
         grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu())
     assert max_rel(grads[1], grads[0]) <= 1e-5
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16x2", "exact"])
+def test_forward_under_inference_mode(gemm, monkeypatch):
+    """Lightning runs validation / sanity-check / predict steps under ``torch.inference_mode()`` (reference
+    train.py:44, forecast.py:99 leave ``inference_mode`` at its default): parameters moved or created there and
+    every op output are inference tensors, which have no version counter.  Same values as under ``no_grad``."""
+    from paradis_model_amd import ops
+    monkeypatch.setattr(ops, "GEMM_SCHEME", ops._SCHEMES[gemm])
+    cfg = reduced_config()
+    _, lg, og = make_grid(16, 32, False)
+    model = _build(cfg, lg, og)
+    x = seeded(3, 2, 186, 16, 32).cuda()
+    with torch.no_grad():
+        want = model(x)
+    with torch.inference_mode():
+        got = model(x)
+        got2 = model(x.clone())          # an inference-tensor input as well
+        w = model.input_proj[0].conv.weight.clone()      # an inference-tensor weight: no version counter
+        y = ops.pointwise(x, w)
+    assert torch.equal(got, want) and torch.equal(got2, want)
+    assert y.shape == (2, w.shape[0], 16, 32) and bool(torch.isfinite(y).all())
