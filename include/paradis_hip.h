@@ -50,7 +50,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 4: GEMM `scheme` arguments, paradis_amax_partials (3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 5: no amax side outputs (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -66,9 +66,7 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
                           const float* sin_lat, const float* cos_lat, const float* lon,
                           int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs, int64_t o_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
-                          int mode, int flags, void* workspace,
-                          uint32_t* out_amax /* optional amax side output, see "amax side outputs" */,
-                          void* stream);
+                          int mode, int flags, void* workspace, void* stream);
 /* gfield [B,K,H,W] (batch stride gf_bs), gu/gv with batch stride guv_bs.
  * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes. */
 size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
@@ -78,17 +76,13 @@ int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
                           int B, int K, int H, int W, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                           int64_t gf_bs, int64_t guv_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
-                          int mode, int flags, void* workspace,
-                          uint32_t* gf_amax, uint32_t* guv_amax /* optional amax side outputs of gfield and of
-                          (gu, gv) together; whole-plane schedules only: paradis_sl_advect_bwd_has_amax */,
-                          void* stream);
-int paradis_sl_advect_bwd_has_amax(int H, int W, int mode, int flags);
+                          int mode, int flags, void* workspace, void* stream);
 
 /* ---- a7 (depthwise half of SepConv, reference model/blocks.py:101-113) and the static
  * encoder's GeoCyclicPadding(3)+Conv2d(groups=C) (reference model/paradis.py:189-190):
  * k x k per-channel stencil on the virtual geocyclic halo. w [C,k,k]; bias [C] or NULL; k odd, 1..11. */
 int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
-                           int B, int C, int H, int W, int k, uint32_t* y_amax /* optional */, void* stream);
+                           int B, int C, int H, int W, int k, void* stream);
 int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx,
                              int B, int C, int H, int W, int k, void* stream);
 size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k);
@@ -112,7 +106,8 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  *   - PARADIS_GEMM_BF16X3: each fp32 operand is decomposed exactly into three bf16 terms and the product is
  *     accumulated from the six partial products >= 2^-16 on v_mfma_f32_32x32x16_bf16 (relative
  *     truncation 2^-23 per product, fewer accumulation roundings: error vs fp64 not above the exact path's);
- *   - PARADIS_GEMM_F16X2:  each operand TENSOR is scaled by a power of two that puts its largest magnitude
+ *   - PARADIS_GEMM_F16X2 (opt-in; a block-exponent format, NOT the reference's per-element fp32 arithmetic):
+ *     each operand TENSOR is scaled by a power of two that puts its largest magnitude
  *     into [2^14, 2^15) and every value is written as two f16 terms (22 significand bits; values more than
  *     ~2^17 below the tensor's maximum keep an absolute accuracy of 2^-39 max|x|); three partial products on
  *     v_mfma_f32_32x32x16_f16, result unscaled in the epilogue.  Error vs fp64 of a K = 1024 product: that of
@@ -127,12 +122,6 @@ int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t planes, int Hc
  * contiguous floats (block stride bs); the tensor's maximum is the (unsigned) maximum of the words, a NaN
  * anywhere makes it a NaN pattern.  One read pass, no atomics, no pre-zeroing. */
 int paradis_amax_partials(const float* x, int B, int64_t inner, int64_t bs, uint32_t* partials, void* stream);
-/* amax side outputs: the kernels that produce most GEMM operands (pw_gemm_fwd / dgrad epilogues, channel_norm_fwd,
- * dwconv_geo_fwd, act_bwd, sl_advect_fwd, sl_advect_bwd [gfield; gu and gv], channel_norm_bwd [gx1],
- * gated_blend_bwd [gadv]) take an optional uint32_t[PARADIS_AMAX_PARTIALS] that the CALLER HAS
- * ZEROED and add the partial maxima of what they store into it (one atomic per wave): the same words
- * paradis_amax_partials would produce, or an upper bound (sl_advect_fwd: pole rows before their mean), without
- * the extra read pass.  NULL = no side output. */
 size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme);   /* bytes of the split image of an [M,K] A operand */
 /* split image of A = W[M,K] (transpose 0; out: split_bytes(M,K,scheme)) or of A = W^T (transpose 1; out:
  * split_bytes(K,M,scheme)) from row-major W[M,K]; scheme = PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 */
@@ -146,15 +135,14 @@ int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy
                          *   with projection, reference model/blocks.py:190-196), M % 4 == 0, or NULL/NULL/0 */
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
-                        int act, uint32_t* y_amax /* optional amax side output of Y */, void* stream);
+                        int act, void* stream);
 /* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend);
  * WTsplit: split image of W^T (paradis_pw_gemm_split_weights(..., transpose=1)), NULL for PARADIS_GEMM_EXACT */
 int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme,
                           const uint32_t* dy_amax /* amax partials of dY: PARADIS_GEMM_F16X2 only */,
                           const float* dY, const float* zpre,
                           const float* addend, float* dX, int B, int M, int K, int N, int64_t dy_bs,
-                          int64_t z_bs, int64_t add_bs, int64_t dx_bs, int act,
-                          uint32_t* dx_amax /* optional amax side output of dX */, void* stream);
+                          int64_t z_bs, int64_t add_bs, int64_t dx_bs, int act, void* stream);
 /* dW[M,K] = sum_b dY[b][M,N] * X[b][K,N]^T ; gbias[M] = sum_{b,n} dY (optional, NULL to skip; fused
  * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes;
  * a split scheme is used when N % 16 == 0 and the rows are 16-B aligned (the exact kernels run otherwise) */
@@ -169,7 +157,7 @@ int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbi
 int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w, const float* b,
                              float* y, float* mean, float* rstd,
                              int B, int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs,
-                             float eps, uint32_t* y_amax /* optional */, void* stream);
+                             float eps, void* stream);
 size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P);
 /* gx1/gx2 receive the slices of the input gradient (gx2 may be NULL); gw,gb [C].
  * addend1 (optional, [B,C1,P] with batch stride add1_bs) is added to gx1: the gradient that reaches
@@ -179,8 +167,7 @@ int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2, 
                              const float* mean, const float* rstd, float* gx1, float* gx2,
                              float* gw, float* gb, int B, int C1, int C2, int P,
                              int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs, int64_t gx2_bs,
-                             const float* addend1, int64_t add1_bs, void* workspace,
-                             uint32_t* gx1_amax /* optional amax side output of gx1 */, void* stream);
+                             const float* addend1, int64_t add1_bs, void* workspace, void* stream);
 
 /* ---- a9: GlobalBias map (reference model/blocks.py:188-196).
  * m8[Cin,H,W] = sum_r A[c,r] U[r,h] V[r,w];  map[Co,H,W] = Pw[Co,Cin] m8 (or map = m8 if Pw NULL). */
@@ -203,15 +190,14 @@ int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, const float
 
 /* ---- elementwise / reductions used by the blocks */
 int paradis_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
-int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act,
-                    uint32_t* gx_amax /* optional */, void* stream);
+int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act, void* stream);
 /* out = h + sigmoid(alpha[c]) * (adv - h)          (reference model/paradis.py:239,243) */
 int paradis_gated_blend_fwd(const float* h, const float* adv, const float* alpha, float* out,
                             int B, int C, int P, void* stream);
 size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P);
 int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv, const float* alpha,
                             float* gh, float* gadv, float* galpha, int B, int C, int P,
-                            void* workspace, uint32_t* gadv_amax /* optional amax side output of gadv */, void* stream);
+                            void* workspace, void* stream);
 /* gmap[C,P] = sum_b dz[b,C,P] (NULL to skip), gbias[C] = sum_{b,p} dz (NULL to skip) */
 int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
                        int64_t dz_bs, void* stream);

@@ -32,12 +32,11 @@ SIGNATURES = {
     "paradis_last_error": (c_char_p, []),
     "paradis_geocyclic_pad_fwd": (I, [P, P, L, I, I, I, P]),
     "paradis_geocyclic_pad_bwd": (I, [P, P, L, I, I, I, P]),
-    "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, I, P, P, P]),
+    "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, I, P, P]),
     "paradis_sl_advect_ws_bytes": (S, [I, I, I, I]),
     "paradis_sl_advect_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L,
-                                  F, F, F, F, F, I, I, P, P, P, P]),
-    "paradis_sl_advect_bwd_has_amax": (I, [I, I, I, I]),
-    "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P]),
+                                  F, F, F, F, F, I, I, P, P]),
+    "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_wgrad_ws_bytes": (S, [I, I, I, I, I]),
     "paradis_dwconv_geo_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, P]),
@@ -48,7 +47,7 @@ SIGNATURES = {
     "paradis_amax_partials": (I, [P, I, L, L, P, P]),
     "paradis_pw_gemm_split_bytes": (S, [I, I, I]),
     "paradis_pw_gemm_split_weights": (I, [P, I, I, I, I, P, P]),
-    "paradis_pw_gemm_fwd": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P, P]),
+    "paradis_pw_gemm_fwd": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
     "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I, I]),
     "paradis_forcings": (I, [P, P, P, I, I, I, I, I, I, P, I, ctypes.c_double, ctypes.c_double, P, P, P]),
     "paradis_normalize_features": (I, [P, P, P, P, L, I, ctypes.c_float, I, P]),
@@ -56,20 +55,20 @@ SIGNATURES = {
     "paradis_global_bias_m8_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "paradis_global_bias_proj_bwd": (I, [P, P, P, P, P, I, I, L, P]),
     "paradis_transpose": (I, [P, P, I, I, P]),
-    "paradis_pw_gemm_dgrad": (I, [P, P, I, P, P, P, P, P, I, I, I, I, L, L, L, L, I, P, P]),
+    "paradis_pw_gemm_dgrad": (I, [P, P, I, P, P, P, P, P, I, I, I, I, L, L, L, L, I, P]),
     "paradis_pw_gemm_wgrad_ws_bytes": (S, [I, I, I, I]),
     "paradis_pw_gemm_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, I, P, P, P, P]),
-    "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P, P]),
+    "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
     "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),
-    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P, P]),
+    "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P]),
     "paradis_global_bias_map_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "paradis_global_bias_map_bwd_ws_bytes": (S, [I, I, I, I, I]),
     "paradis_global_bias_map_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_act_fwd": (I, [P, P, L, I, P]),
-    "paradis_act_bwd": (I, [P, P, P, L, I, P, P]),
+    "paradis_act_bwd": (I, [P, P, P, L, I, P]),
     "paradis_gated_blend_fwd": (I, [P, P, P, P, I, I, I, P]),
     "paradis_gated_blend_bwd_ws_bytes": (S, [I, I, I]),
-    "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P, P]),
+    "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
     "paradis_bias_grads": (I, [P, P, P, I, I, I, L, P]),
     "paradis_add": (I, [P, P, P, L, P]),
     "paradis_add_bcast": (I, [P, P, P, L, I, P]),

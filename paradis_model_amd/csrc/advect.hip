@@ -518,7 +518,7 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
                                             const float* __restrict__ v, VelCursor& vc, float (&qu)[ADV_PF],
                                             float (&qv)[ADV_PF], const float* __restrict__ sin_lat,
                                             const float* __restrict__ cos_lat, float lonc, const AdvGeom& g,
-                                            int wave, unsigned lane, bool fill_halo, float& am) {
+                                            int wave, unsigned lane, bool fill_halo) {
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;
   const int H = g.H, Hp = H + 2 * p, tid = threadIdx.x;
   // halo columns (p left, p + XR right) and the p mirrored rows beyond each pole are copies of interior
@@ -557,7 +557,6 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
       float acc = XR ? sample_wide<MODE>(cur, ix, iy, WS, WSf) : sample_whole<MODE>(cur, ix, iy, Hp, WS, Hpf, WSf);
       if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
       ADV_ST(acc, &srow(O + y * W)[lane]);
-      am = amax_acc(am, acc);
     }
   };
   // Two register sets that swap roles (qu/qv -> ru/rv -> qu/qv): a load never targets a register whose old
@@ -577,7 +576,7 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
                     const float* __restrict__ v, float* __restrict__ out,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lon, int K, AdvGeom g, int64_t f_bs, int64_t uv_bs,
-                    int64_t o_bs, int planes, int chunk, uint32_t* __restrict__ out_amax) {
+                    int64_t o_bs, int planes, int chunk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;   // WS: window row stride
   const int H = g.H, P = H * W, Hp = H + 2 * p;
@@ -598,7 +597,6 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
   const float lonc = lon_cells(lon[lane], g);
   float* cur = smem;
   float* nxt = smem + Hp * WS;
-  float am = 0.f;
   {   // the first plane of the chunk is staged through registers, halo included
     Window w{0, 0, Hp, WS};
     stage_window(cur, field + (int64_t)b * f_bs + (int64_t)k * P, w, H, W, p, false, 0.f, 0.f, 256);
@@ -615,11 +613,10 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
     const bool has_next = plane + 1 < last;
     const int64_t next_off = has_next ? (int64_t)nb * f_bs + (int64_t)nk * P : 0;
     row64_plane<MODE, XR>(cur, nxt, field, next_off, has_next, out + (int64_t)b * o_bs + (int64_t)k * P, u, v, vc,
-                          qu, qv, sin_lat, cos_lat, lonc, g, wave, lane, plane != first, am);
+                          qu, qv, sin_lat, cos_lat, lonc, g, wave, lane, plane != first);
     float* t = cur; cur = nxt; nxt = t;
     b = nb; k = nk;
   }
-  if (out_amax) amax_flush(am, out_amax);
 }
 
 template <int MODE, bool WHOLE, int NTH>
@@ -629,12 +626,11 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
                      const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                      const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x,
-                     int tiles, int vec4, uint32_t* __restrict__ out_amax) {
+                     int tiles, int vec4) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
   const int tid = threadIdx.x, wave = tid >> 6;
-  float am = 0.f;   // (pole rows: the values before the row mean - an upper bound of what is stored)
   const int plane = WHOLE ? blockIdx.x : blockIdx.x / tiles;
   const int tile = WHOLE ? 0 : blockIdx.x - plane * tiles;
   const int b = plane / K, k = plane - b * K;
@@ -732,7 +728,6 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
         if (i < npts) {
           if (i < W || i >= lastrow0) pole_out[i < W ? i : W + i - lastrow0] = acc;
           else O[i] = acc;
-          am = amax_acc(am, acc);
         }
       }
     }
@@ -761,10 +756,8 @@ sl_advect_fwd_kernel(const float* __restrict__ field, const float* __restrict__ 
       }
       const float acc = point_tiled(cu, cv, csa, cca, clo);
       O[idx] = acc;
-      am = amax_acc(am, acc);
     }
   }
-  if (out_amax) amax_flush(am, out_amax);
 }
 
 
@@ -816,8 +809,7 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
                       const float* __restrict__ v, float* __restrict__ out,
                       const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                       const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
-                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x, int tiles,
-                      uint32_t* __restrict__ out_amax) {
+                      AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT, NTH = TILED_THREADS_FWD;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -889,7 +881,6 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
     }
     return acc;
   };
-  float am = 0.f;
   for (int yl0 = tl.rs; yl0 < th; yl0 += tl.rstep * ADV_PF) {
 #pragma unroll
     for (int d = 0; d < ADV_PF; ++d) {
@@ -925,12 +916,10 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
         }
         if (tl.active) {
           srow(O + y * W + tl.cbase)[tl.lx] = acc;
-          am = amax_acc(am, acc);
         }
       }
     }
   }
-  if (out_amax) amax_flush(am, out_amax);
 }
 
 // ======================================================================================
@@ -1039,10 +1028,8 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
                     float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lon, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
-                    int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int vec4, uint32_t* __restrict__ gf_amax,
-                    uint32_t* __restrict__ guv_amax) {
+                    int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int vec4) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float amv = 0.f, amf = 0.f;   // amax side outputs of (gu, gv) and of gfield
   constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0, W = 64;
   const int H = g.H, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
   const int tid = threadIdx.x;
@@ -1130,11 +1117,9 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
         departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
         srow(GU + y * W)[lane] = guv;
         srow(GV + y * W)[lane] = gvv;
-        amv = amax_acc(amax_acc(amv, guv), gvv);
       }
     }
   }
-  if (guv_amax) amax_flush(amv, guv_amax);
   __syncthreads();
   // fold the halo back: every source cell sums its aliases (adjoint of the a1 map: its own cell, the
   // lon-wrap copies of the p edge columns, and for rows next to a pole the mirrored row shifted by
@@ -1160,9 +1145,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
     float val = (float)((double)s * inv);
     if (y == 0 || y == H - 1) val = wave_sum(val) * (1.0f / 64.0f);
     srow(GF + y * W)[lane] = val;
-    amf = amax_acc(amf, val);
   }
-  if (gf_amax) amax_flush(amf, gf_amax);
 }
 
 template <int MODE, bool WHOLE, int NTH>
@@ -1174,9 +1157,8 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
                      const float* __restrict__ lon, const float* __restrict__ fmeans,
                      const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles,
-                     int vec4, uint32_t* __restrict__ gf_amax, uint32_t* __restrict__ guv_amax) {
+                     int vec4) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float amv = 0.f;   // amax side output of (gu, gv): whole-plane schedule only
   constexpr int NT = Interp<MODE>::NT;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -1298,9 +1280,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
     GU[idx] = guv;
     GV[idx] = gvv;
-    amv = amax_acc(amax_acc(amv, guv), gvv);
   }
-  if (WHOLE && guv_amax) amax_flush(amv, guv_amax);
   __syncthreads();
   const double inv = (double)inv_scale;
   if (WHOLE) {
@@ -1319,12 +1299,9 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
       for (int x = tid & 63; x < W; x += 64) row[x] = m;
     }
     __syncthreads();
-    float amf = 0.f;
     for (int i = tid; i < P; i += NTH) {
       GF[i] = win[i];
-      amf = amax_acc(amf, win[i]);
     }
-    if (gf_amax) amax_flush(amf, gf_amax);
   } else {
     // flush the window once: one global float atomic per touched cell instead of 16 per point
     // (consecutive lanes -> consecutive cells: the 16 atomics per 64-byte line of one wave-instruction
@@ -1627,7 +1604,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
                                      int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs,
                                      int64_t o_bs, float dt, float min_lat, float min_lon,
                                      float d_lat, float d_lon, int mode, int flags, void* workspace,
-                                     uint32_t* out_amax, void* stream) {
+                                     void* stream) {
   if (int e = check_adv("sl_advect_fwd", B, K, H, W, mode)) return e;
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
@@ -1653,13 +1630,13 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
       const int chunk = ROW64_CHUNK, groups = (planes + chunk - 1) / chunk;
 #define ROW64_FWD(MODE_, XR_)                                                                              \
       hipLaunchKernelGGL((sl_advect_fwd_row64<MODE_, XR_>), dim3(groups), dim3(256), lds, st, field, u, v, out, \
-                         sin_lat, cos_lat, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk, out_amax)
+                         sin_lat, cos_lat, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk)
       if (mode == PARADIS_INTERP_BICUBIC) { if (wide) ROW64_FWD(PARADIS_INTERP_BICUBIC, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BICUBIC, 0); }
       else { if (wide) ROW64_FWD(PARADIS_INTERP_BILINEAR, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BILINEAR, 0); }
 #undef ROW64_FWD
     } else
       ADV_LAUNCH(sl_advect_fwd_kernel, true, 256, planes, whole, field, u, v, out, sin_lat, cos_lat, lon,
-                 (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4, out_amax);
+                 (const float*)nullptr, K, g, f_bs, uv_bs, o_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_fwd");
     return 0;
   }
@@ -1688,25 +1665,18 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
     if (mode == PARADIS_INTERP_BICUBIC)
       hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
                          dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, out_amax);
+                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
     else
       hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
                          dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, out_amax);
+                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
   } else {
     ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
-               cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4, out_amax);
+               cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
   }
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, out, planes, K, H, W, o_bs);
   PD_CHECK_LAUNCH("sl_advect_fwd(tiled)");
   return 0;
-}
-
-// 1 when sl_advect_bwd can fill its amax side outputs for this grid (whole-plane schedules: the tiled ones finish
-// gfield with global atomics across workgroups)
-extern "C" int paradis_sl_advect_bwd_has_amax(int H, int W, int mode, int flags) {
-  const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1;
-  return H >= 1 && W >= 1 && !use_tiled(bwd_whole_lds((size_t)(H + 2 * p) * (W + 2 * p)), flags);
 }
 
 extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
@@ -1715,11 +1685,8 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                                      int B, int K, int H, int W, int64_t go_bs, int64_t f_bs,
                                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, float dt,
                                      float min_lat, float min_lon, float d_lat, float d_lon, int mode,
-                                     int flags, void* workspace, uint32_t* gf_amax, uint32_t* guv_amax,
-                                     void* stream) {
+                                     int flags, void* workspace, void* stream) {
   if (int e = check_adv("sl_advect_bwd", B, K, H, W, mode)) return e;
-  PD_REQUIRE((gf_amax == nullptr && guv_amax == nullptr) || paradis_sl_advect_bwd_has_amax(H, W, mode, flags),
-             "sl_advect_bwd: amax side outputs exist for the whole-plane schedules only (paradis_sl_advect_bwd_has_amax)");
   if (B == 0) return 0;
   const int p = mode == PARADIS_INTERP_BICUBIC ? 2 : 1, NT = 2 * p;
   AdvGeom g = make_geom(H, W, p, dt, min_lat, min_lon, d_lat, d_lon);
@@ -1732,11 +1699,11 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   if (!use_tiled(whole, flags)) {
     if (use_row64(W, flags))
       ADV_LAUNCH_ROW64(sl_advect_bwd_row64, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
-                       K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, vec4, gf_amax, guv_amax);
+                       K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, vec4);
     else
       ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
                  cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
-                 gf_bs, guv_bs, 0, 1, 1, vec4, gf_amax, guv_amax);
+                 gf_bs, guv_bs, 0, 1, 1, vec4);
     PD_CHECK_LAUNCH("sl_advect_bwd");
     return 0;
   }
@@ -1782,7 +1749,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   } else {
     ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
                gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-               f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4, (uint32_t*)nullptr, (uint32_t*)nullptr);
+               f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4);
   }
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");

@@ -101,12 +101,6 @@ __device__ __forceinline__ void geo_for_each_alias(int y, int x, int H, int W, i
   }
 }
 
-// ---- amax side output of producer kernels (feeds the f16x2 GEMM scheme): a thread keeps the running
-// maximum of |v| over what it stores (one v_max_f32 with the |.| modifier per value; a NaN is skipped - it
-// poisons the consumer's products by itself - an Inf is kept); amax_flush (EVERY lane of the wave) folds the
-// wave and adds the bit pattern with one atomic into one of the PARADIS_AMAX_PARTIALS words the caller has
-// zeroed (bit patterns of non-negative floats order like unsigned integers).
-__device__ __forceinline__ float amax_acc(float m, float v) { return fmaxf(m, fabsf(v)); }
 // unsigned maximum over the wave by DPP (no LDS-pipe shuffles, no waits): row_shr 1/2/4/8 leave each 16-lane
 // row's maximum in its last lane, row_bcast 15 / 31 carry it on; LANE 63 ends up with the maximum of the wave.
 // Lanes a shift has no source for read 0 (bound_ctrl): neutral for an unsigned maximum.
@@ -117,11 +111,6 @@ __device__ __forceinline__ uint32_t wave_umax_lane63(uint32_t v) {
 #undef PD_DPP_MAX
   return v;
 }
-__device__ __forceinline__ void amax_flush(float m, uint32_t* __restrict__ partials) {
-  const uint32_t v = wave_umax_lane63(__float_as_uint(m));
-  if ((threadIdx.x & 63) == 63) atomicMax(partials + (blockIdx.x & (PARADIS_AMAX_PARTIALS - 1)), v);
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

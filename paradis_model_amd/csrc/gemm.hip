@@ -55,7 +55,6 @@ struct GemmArgs {
   // f16x2 scheme: where the operands' max |value| comes from.  a_amax: one word (bits of max |A|, weight
   // image tail) for fwd/dgrad, PARADIS_AMAX_PARTIALS words for wgrad; b_amax: PARADIS_AMAX_PARTIALS words.
   const uint32_t* a_amax; const uint32_t* b_amax;
-  uint32_t* c_amax;   // optional amax side output of C (PARADIS_AMAX_PARTIALS zeroed words), any scheme
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -155,7 +154,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
   const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
   float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
   if (g.pw) gemm_add_projection(g, acc, m0, n0, wm, wn, li, lh);
-  float am = 0.f;
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -203,10 +201,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) Cb[base + ROWOFF(q)] = v[q];
-          if (g.c_amax) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) am = amax_acc(am, v[q]);
-          }
           // keep the scheduler from hoisting the next chunk's loads (register pressure)
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
@@ -214,7 +208,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         }
       }
     }
-    if (g.c_amax) amax_flush(am, g.c_amax);
     return;
   }
 #pragma unroll
@@ -236,11 +229,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         else if (g.act) v = act_apply(v, g.act);
         if (resb) v += resb[off];
         Cb[off] = v;
-        am = amax_acc(am, v);
       }
     }
   }
-  if (g.c_amax) amax_flush(am, g.c_amax);
 }
 
 template <bool A_KC, bool B_KC, int BK>
@@ -1458,7 +1449,7 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
                                    const float* bias, const float* map, const float* m8,
                                    const float* pwT, int cin, const float* res, float* Y, float* zpre,
                                    int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
-                                   int64_t y_bs, int act, uint32_t* y_amax, void* stream) {
+                                   int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
   PD_REQUIRE(known_scheme(scheme) && (Wsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
@@ -1473,7 +1464,6 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
   g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0;
   g.bias = bias; g.map = map; g.res = res; g.res_bs = res_bs; g.zmul = nullptr; g.zout = zpre;
   g.zout_bs = (int64_t)M * N; g.act = act;
-  g.c_amax = y_amax;
   g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
   if (Wsplit != nullptr) {   // split image of the weights: split kernel (any shape)
@@ -1545,7 +1535,7 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int s
                                      const float* dY, const float* zpre,
                                      const float* addend, float* dX, int B, int M, int K, int N,
                                      int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
-                                     int act, uint32_t* dx_amax, void* stream) {
+                                     int act, void* stream) {
   // W is [M,K] (M = Co, K = Ci); result dX is [K,N] per sample: GEMM with M' = K, K' = M.
   if (int e = check_gemm("pw_gemm_dgrad", B, K, M, N)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_dgrad: unknown activation code %d", act);
@@ -1557,7 +1547,6 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int s
   g.lda = K; g.ldb = N; g.ldc = N;
   g.a_bs = 0; g.b_bs = dy_bs; g.c_bs = dx_bs; g.nbatch = B; g.inner = 0;
   g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
-  g.c_amax = dx_amax;
   g.stagger = g_stagger;
   const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
   if (WTsplit != nullptr) {   // split image of W^T

@@ -140,8 +140,7 @@ gbias_finish_kernel(const float* __restrict__ T1, const float* __restrict__ T2,
 template <bool BWD>
 __global__ void __launch_bounds__(256)
 act_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ out,
-           int64_t n, int act, bool vec, uint32_t* __restrict__ out_amax) {
-  float am = 0.f;
+           int64_t n, int act, bool vec) {
   if (vec) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -155,16 +154,13 @@ act_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __r
         o = make_float4(act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act));
       }
       reinterpret_cast<float4*>(out)[i] = o;
-      am = amax_acc(amax_acc(amax_acc(amax_acc(am, o.x), o.y), o.z), o.w);
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
       const float o = BWD ? gy[i] * act_grad(x[i], act) : act_apply(x[i], act);
       out[i] = o;
-      am = amax_acc(am, o);
     }
   }
-  if (out_amax) amax_flush(am, out_amax);
 }
 
 __global__ void __launch_bounds__(256)
@@ -221,20 +217,18 @@ __global__ void __launch_bounds__(256)
 gated_blend_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ h,
                        const float* __restrict__ adv, const float* __restrict__ alpha,
                        float* __restrict__ gh, float* __restrict__ gadv, float* __restrict__ partial,
-                       int C, int P, uint32_t* __restrict__ gadv_amax) {
+                       int C, int P) {
   __shared__ float red[4];
   const int c = blockIdx.x % C;
   const float g = 1.0f / (1.0f + expf(-alpha[c]));
   const int64_t base = (int64_t)blockIdx.x * P;
-  float acc = 0.f, am = 0.f;
+  float acc = 0.f;
   for (int p = threadIdx.x; p < P; p += 256) {
     const float go = gout[base + p];
     gh[base + p] = (1.0f - g) * go;
     gadv[base + p] = g * go;
-    am = amax_acc(am, g * go);
     acc += go * (adv[base + p] - h[base + p]);
   }
-  if (gadv_amax) amax_flush(am, gadv_amax);
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -345,18 +339,17 @@ extern "C" int paradis_act_fwd(const float* x, float* y, int64_t n, int act, voi
   if (n == 0) return 0;
   const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(y);
   hipLaunchKernelGGL(act_kernel<false>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
-                     (hipStream_t)stream, nullptr, x, y, n, act, vec, (uint32_t*)nullptr);
+                     (hipStream_t)stream, nullptr, x, y, n, act, vec);
   PD_CHECK_LAUNCH("act_fwd");
   return 0;
 }
 
-extern "C" int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act,
-                               uint32_t* gx_amax, void* stream) {
+extern "C" int paradis_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int act, void* stream) {
   PD_REQUIRE(n >= 0 && act >= 0 && act <= 2, "act_bwd: bad arguments");
   if (n == 0) return 0;
   const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(gx);
   hipLaunchKernelGGL(act_kernel<true>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
-                     (hipStream_t)stream, gy, x, gx, n, act, vec, gx_amax);
+                     (hipStream_t)stream, gy, x, gx, n, act, vec);
   PD_CHECK_LAUNCH("act_bwd");
   return 0;
 }
@@ -388,14 +381,14 @@ extern "C" size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P) {
 
 extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv,
                                        const float* alpha, float* gh, float* gadv, float* galpha, int B,
-                                       int C, int P, void* workspace, uint32_t* gadv_amax, void* stream) {
+                                       int C, int P, void* workspace, void* stream) {
   PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "gated_blend_bwd: bad shape");
   PD_REQUIRE(workspace != nullptr, "gated_blend_bwd: workspace required");
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   if (B > 0)
     hipLaunchKernelGGL(gated_blend_bwd_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0, st, gout, h,
-                       adv, alpha, gh, gadv, partial, C, P, gadv_amax);
+                       adv, alpha, gh, gadv, partial, C, P);
   hipLaunchKernelGGL(gated_blend_finish, dim3((C + 255) / 256), dim3(256), 0, st, partial, alpha, galpha, B, C);
   PD_CHECK_LAUNCH("gated_blend_bwd");
   return 0;

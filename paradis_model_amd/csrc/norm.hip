@@ -29,7 +29,7 @@ template <int MAXV, int NPXF>
 __global__ void __launch_bounds__(1024)
 channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
                         float* __restrict__ y, float* __restrict__ mean_out,
-                        float* __restrict__ rstd_out, int P, int tiles, float eps, uint32_t* __restrict__ y_amax) {
+                        float* __restrict__ rstd_out, int P, int tiles, float eps) {
   constexpr int G = 1024 / NPXF;
   __shared__ float red[G][NPXF];
   __shared__ float stat[2][NPXF];
@@ -92,7 +92,6 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   }
   __syncthreads();
   const float rstd = stat[1][lane];
-  float am = 0.f;
   if (live) {
     float* yb = y + (int64_t)b * C * P + p;
     if (MAXV > 0) {
@@ -102,18 +101,15 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
         if (c < C) {
           const float v = (vals[i] - mean) * rstd * w[c] + bias[c];
           yb[(int64_t)c * P] = v;
-          am = amax_acc(am, v);
         }
       }
     } else {
       for (int c = grp; c < C; c += G) {
         const float v = (s.row(b, c, P)[p] - mean) * rstd * w[c] + bias[c];
         yb[(int64_t)c * P] = v;
-        am = amax_acc(am, v);
       }
     }
   }
-  if (y_amax) amax_flush(am, y_amax);
 }
 
 // gx = rstd * ( g*w - mean_c(g*w) - xhat * sum_c(g*w*xhat)/(C-1) )
@@ -121,10 +117,8 @@ __global__ void __launch_bounds__(1024)
 channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                            float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                           int64_t gbs2, const float* __restrict__ add1, int64_t abs1, int P, int tiles,
-                           uint32_t* __restrict__ gx1_amax) {
+                           int64_t gbs2, const float* __restrict__ add1, int64_t abs1, int P, int tiles) {
   __shared__ float red[2][16][NPX];
-  float am = 0.f;
   __shared__ float stat[2][NPX];
   const int C = s.C1 + s.C2;
   const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPX;
@@ -162,11 +156,9 @@ channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* 
       if (c < s.C1) {
         const float o = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
         gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = o;
-        am = amax_acc(am, o);
       } else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
     }
   }
-  if (gx1_amax) amax_flush(am, gx1_amax);
 }
 
 // gw[c] = sum_{b,p} gy * xhat ; gb[c] = sum_{b,p} gy.  grid (C, chunks): partial[c][chunk][2]
@@ -222,10 +214,8 @@ __global__ void __launch_bounds__(NPB * 32)
 channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                               float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                              int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles,
-                              uint32_t* __restrict__ gx1_amax) {
+                              int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][32][NPB] reduce + [C][NPB] xhat
-  float am = 0.f;
   float (*red)[32][NPB] = reinterpret_cast<float (*)[32][NPB]>(lds);
   float* xs = lds + 2 * 32 * NPB;
   const int C = s.C1 + s.C2;
@@ -287,7 +277,6 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
         if (c < s.C1) {
           const float o = v + (add1 ? add1[(int64_t)b * abs1 + (int64_t)c * P + p] : 0.f);
           gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = o;
-          am = amax_acc(am, o);
         } else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
       }
       float a = g[i] * xh, d = g[i];       // dead pixels hold zeros
@@ -299,7 +288,6 @@ channel_norm_bwd_fused_kernel(const float* __restrict__ gy, CatSrc s, const floa
       if (px == 0) { pw[c] = a; pw[C + c] = d; }
     }
   }
-  if (gx1_amax) amax_flush(am, gx1_amax);
 }
 
 // Same work with nothing parked between the two phases: gy and x are streamed twice, the second time
@@ -312,10 +300,8 @@ __global__ void __launch_bounds__(512)
 channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1,
-                               int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles,
-                               uint32_t* __restrict__ gx1_amax) {
+                               int64_t gbs2, const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial, int P, int tiles) {
   constexpr int NPB = 32, G = 16;
-  float am = 0.f;
   __shared__ float red[2][G][NPB];
   const int C = s.C1 + s.C2;
   const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPB;
@@ -375,7 +361,6 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
           const float v = rstd * (g * wv[j] - m1 - xh * m2);
           if (c < s.C1) {
             gx1[(int64_t)b * gbs1 + (int64_t)c * P + p] = v + av[j];
-            am = amax_acc(am, v + av[j]);
           } else if (gx2) gx2[(int64_t)b * gbs2 + (int64_t)(c - s.C1) * P + p] = v;
         }
         float a = g * xh, d = g;
@@ -388,7 +373,6 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
       }
     }
   }
-  if (gx1_amax) amax_flush(am, gx1_amax);
 }
 
 // Two-stage reduction of the per-block partial sums in a fixed order (no atomics: bit-reproducible):
@@ -449,8 +433,7 @@ extern "C" void paradis_debug_set_norm_bwd_reread(int on) { g_norm_bwd_reread = 
 
 extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
                                         const float* b, float* y, float* mean, float* rstd, int B,
-                                        int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps,
-                                        uint32_t* y_amax, void* stream) {
+                                        int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
   if (int e = check_norm("channel_norm_fwd", B, C1, C2, P)) return e;
   PD_REQUIRE(C2 == 0 || x2 != nullptr, "channel_norm_fwd: x2 missing");
   if (B == 0) return 0;
@@ -462,18 +445,18 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
     const int tiles = (P + 31) / 32;
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 32 * 4)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
   } else {
     const int tiles = (P + NPX - 1) / NPX;
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 16 * 8)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else if (C <= 16 * 72)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps, y_amax);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
   }
   PD_CHECK_LAUNCH("channel_norm_fwd");
   return 0;
@@ -491,7 +474,7 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
                                         float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
                                         int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
                                         int64_t gx2_bs, const float* addend1, int64_t add1_bs,
-                                        void* workspace, uint32_t* gx1_amax, void* stream) {
+                                        void* workspace, void* stream) {
   if (int e = check_norm("channel_norm_bwd", B, C1, C2, P)) return e;
   PD_REQUIRE(workspace != nullptr, "channel_norm_bwd: workspace required");
   const int C = C1 + C2;
@@ -527,16 +510,16 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     }
     if (g_norm_bwd_reread == 1 && addend1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<true>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
-                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else if (g_norm_bwd_reread == 1)
       hipLaunchKernelGGL(channel_norm_bwd_reread_kernel<false>, dim3(nblk), dim3(512), 0, st, gy, s, w, mean,
-                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
+                         rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else if (C <= 32 * 4)
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<4, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
-                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
+                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     else
       hipLaunchKernelGGL((channel_norm_bwd_fused_kernel<36, 32>), dim3(nblk), dim3(32 * 32), lds, st, gy, s,
-                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32, gx1_amax);
+                         w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P, tiles32);
     const int rows = 64, chunks = (nblk + rows - 1) / rows;
     float* chunk = partial + (size_t)nblk * 2 * C;
     hipLaunchKernelGGL(channel_norm_bwd_fused_finish, dim3((C + 255) / 256, chunks), dim3(256), 0, st, partial,
@@ -548,7 +531,7 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   }
   const int tiles = (P + NPX - 1) / NPX;
   hipLaunchKernelGGL(channel_norm_bwd_dx_kernel, dim3((unsigned)((int64_t)B * tiles)), dim3(1024), 0, st,
-                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, P, tiles, gx1_amax);
+                     gy, s, w, mean, rstd, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, P, tiles);
   const int chunks = dw_chunks(B, C, P);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(channel_norm_bwd_dw_kernel, dim3(C * chunks), dim3(256), 0, st, gy, s, mean, rstd,

@@ -87,7 +87,7 @@ template <int K>
 __global__ void __launch_bounds__(256)
 dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                       const float* __restrict__ bias, float* __restrict__ y, int C, int H, int W,
-                      int tiles_x, int tiles, int whole_vec4, uint32_t* __restrict__ y_amax) {
+                      int tiles_x, int tiles, int whole_vec4) {
   __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
   const int64_t plane = blockIdx.x / tiles;
   const int t = blockIdx.x - plane * tiles;
@@ -99,7 +99,6 @@ dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
   tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
   const float bv = bias ? bias[c] : 0.f;
   const int xx = tx0 + (threadIdx.x & 63), r0 = ty0 + (threadIdx.x >> 6) * RPT;
-  float am = 0.f;
   if (xx < W) {
     float* yp = y + plane * (int64_t)H * W;
 #pragma unroll
@@ -107,10 +106,8 @@ dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
       if (r0 + o < H) {
         const float v = acc[o] + bv;
         yp[(int64_t)(r0 + o) * W + xx] = v;
-        am = amax_acc(am, v);
       }
   }
-  if (y_amax) amax_flush(am, y_amax);
 }
 
 // Data gradient.  With the halo virtual, gx = PadAdjoint(ConvTranspose(gy)).  Folding the halo
@@ -404,14 +401,14 @@ static int whole_plane_vec4(const float* src, int H, int W, int k) {
   }
 
 extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
-                                      int B, int C, int H, int W, int k, uint32_t* y_amax, void* stream) {
+                                      int B, int C, int H, int W, int k, void* stream) {
   if (int e = check_dw("dwconv_geo_fwd", B, C, H, W, k)) return e;
   if (B == 0) return 0;
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
   const unsigned grid = (unsigned)((int64_t)B * C * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_fwd_kernel<KK>, dim3(grid), dim3(256), 0,
                                    (hipStream_t)stream, x, w, bias, y, C, H, W, tx, tiles,
-                                   whole_plane_vec4(x, H, W, k), y_amax));
+                                   whole_plane_vec4(x, H, W, k)));
   PD_CHECK_LAUNCH("dwconv_geo_fwd");
   return 0;
 }

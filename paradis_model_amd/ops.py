@@ -207,7 +207,7 @@ def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
               dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
-              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), None, stream_ptr())
+              f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), stream_ptr())
     return out
 
 
@@ -235,7 +235,7 @@ def _sl_advect_backward(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_l
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
               dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
               dptr(cl), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), None, None, stream_ptr())
+              flags, dptr(ws), stream_ptr())
     return gfield, gu, gv
 
 
@@ -271,7 +271,7 @@ def _sl_advect_vel(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, m
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(vel[:, :K]), dptr(vel[:, K:]), dptr(out),
               dptr(sl), dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), None, stream_ptr())
+              flags, dptr(ws), stream_ptr())
     return out
 
 
@@ -295,7 +295,7 @@ def _sl_advect_vel_backward(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, 
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
               dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
               dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
-              flags, dptr(ws), None, None, stream_ptr())
+              flags, dptr(ws), stream_ptr())
     return gfield, gvel
 
 
@@ -367,7 +367,7 @@ def _dwconv_geo(x, weight, bias):
     assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
     w = weight.contiguous()
     y = torch.empty_like(x)
-    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, None, stream_ptr()),
+    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, stream_ptr()),
           "dwconv_geo_fwd")
     return y
 
@@ -568,7 +568,7 @@ def _channel_norm(x1, x2, weight, bias, eps):
     mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
     rstd = torch.empty_like(mean)
     check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y), dptr(mean),
-                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, None, stream_ptr()),
+                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, stream_ptr()),
           "channel_norm_fwd")
     return y, mean, rstd
 
@@ -605,7 +605,7 @@ def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
     check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight), dptr(mean),
                                        dptr(rstd), dptr(gx1), dptr(gx2) if C2 else None, dptr(gw), dptr(gb), B,
                                        C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add), add_bs, dptr(ws),
-                                       None, stream_ptr()), "channel_norm_bwd")
+                                       stream_ptr()), "channel_norm_bwd")
     return gx1, gx2, gw, gb
 
 
@@ -970,7 +970,7 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
     _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), scheme,
               dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
               dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
-              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, None, stream_ptr())
+              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
     return y, z, x_amax
 
 
@@ -987,7 +987,7 @@ def _act_backward(gy, z, act):
     _f32(gy, z)
     gy, z = gy.contiguous(), z.contiguous()
     dz = torch.empty_like(gy)
-    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, None, stream_ptr()), "act_bwd")
+    check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, stream_ptr()), "act_bwd")
     return dz
 
 
@@ -1017,7 +1017,7 @@ def _pw_gemm_dgrad(dz, weight, zmul, x_act, dz_amax, scheme):
     _lib.call("pw_gemm_dgrad", 2.0 * B * Co * Ci * P, dptr(w2), dptr(wtsp), scheme,
               dptr(dz_amax) if scheme == GEMM_F16X2 else None, dptr(dz),
               dptr(zmul) if x_act != 0 else None, None, dptr(gx), B, Co, Ci, P, Co * P, Ci * P, 0, Ci * P,
-              x_act, None, stream_ptr())
+              x_act, stream_ptr())
     return gx
 
 
@@ -1227,7 +1227,7 @@ def _gated_blend_backward(gout, h, adv, alpha):
     gh, gadv, galpha = torch.empty_like(h), torch.empty_like(h), torch.empty_like(alpha)
     ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
     check(lib.paradis_gated_blend_bwd(dptr(gout), dptr(h), dptr(adv), dptr(alpha), dptr(gh), dptr(gadv),
-                                      dptr(galpha), B, C, H * W, dptr(ws), None, stream_ptr()), "gated_blend_bwd")
+                                      dptr(galpha), B, C, H * W, dptr(ws), stream_ptr()), "gated_blend_bwd")
     return gh, gadv, galpha
 
 

@@ -298,38 +298,6 @@ def test_split_extreme_magnitudes(ops):
         assert not torch.isfinite(ys[0, 5]).any() and torch.isfinite(ys[0, :5]).all()
 
 
-def test_amax_side_outputs_c_abi(ops):
-    """C-ABI feature kept for the opt-in f16x2 scheme: producer kernels take an optional zeroed
-    ``uint32[PARADIS_AMAX_PARTIALS]`` and add the partial maxima of what they store (include/paradis_hip.h).
-    The Python ops no longer use it (every f16x2 operand gets its read pass: no hidden state next to a tensor);
-    here the words are compared with a read pass through the ABI directly."""
-    from paradis_model_amd._lib import check, dptr, lib, stream_ptr
-    g = torch.Generator().manual_seed(31)
-    B, C, H, W = 2, 64, 32, 64
-    x = torch.randn(B, C, H, W, generator=g).cuda()
-    w = (torch.randn(C, generator=g) + 1).cuda()
-    b = torch.randn(C, generator=g).cuda()
-
-    def amax_of(words):
-        return float(words.max().view(1).view(torch.float32))
-
-    words = torch.zeros(ops.AMAX_PARTIALS, dtype=torch.int32, device="cuda")
-    y = torch.empty_like(x)
-    mean, rstd = torch.empty(B, H * W, device="cuda"), torch.empty(B, H * W, device="cuda")
-    check(lib.paradis_channel_norm_fwd(dptr(x), None, dptr(w), dptr(b), dptr(y), dptr(mean), dptr(rstd), B, C, 0,
-                                       H * W, C * H * W, 0, 1e-5, dptr(words), stream_ptr()), "channel_norm_fwd")
-    assert amax_of(words) == float(y.abs().max()) == amax_of(ops._amax_partials(y))
-    words.zero_()
-    dw = torch.randn(C, 1, 5, 5, generator=g).cuda()
-    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(dw), dptr(b), dptr(y), B, C, H, W, 5, dptr(words), stream_ptr()),
-          "dwconv_geo_fwd")
-    assert amax_of(words) == float(y.abs().max())
-    words.zero_()
-    check(lib.paradis_act_bwd(dptr(x), dptr(y), dptr(mean.new_empty(x.shape)), x.numel(), 1, dptr(words),
-                              stream_ptr()), "act_bwd")
-    assert amax_of(words) == float(ops._act_backward(x, y, 1).abs().max())
-
-
 def test_f16x2_is_opt_in_and_traceable(ops):
     """The default arithmetic is bf16x3; f16x2 is chosen per call (``scheme=``) or through ``ops.GEMM_SCHEME`` and
     is an explicit integer argument of the ops, so its amax words are ordinary op outputs / inputs (no tensor

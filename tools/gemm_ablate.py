@@ -18,7 +18,7 @@ lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, 2, dptr(wsp), st)
 xa = torch.empty(1024, dtype=torch.int32, device="cuda")
 lib.paradis_amax_partials(dptr(x), B, Ci * P, Ci * P, dptr(xa), st)
 run = lambda: lib.paradis_pw_gemm_fwd(dptr(w), None, dptr(wsp), 2, dptr(xa), dptr(x), None, None, None, None, 0, None,
-                                      dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, None, st)
+                                      dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
 for _ in range(30):
     run()
 torch.cuda.synchronize()

@@ -69,8 +69,8 @@ def main():
                 lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 0, 3, dptr(wsp), st)
                 lib.paradis_pw_gemm_split_weights(dptr(w), Co, Ci, 1, 3, dptr(wtsp), st)
             t = {}
-            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(wsp), 3 if wsp is not None else 0, None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, None, st))
-            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(wtsp), 3 if wtsp is not None else 0, None, dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, None, st))
+            t["fwd"] = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt) if use_t else None, dptr(wsp), 3 if wsp is not None else 0, None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
+            t["dgrad"] = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(wtsp), 3 if wtsp is not None else 0, None, dptr(dy), None, None, dptr(dx), B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
             t["wgrad"] = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P, 3 if cfg[3] else 0, None, None, dptr(ws), st))
             if ACCURACY:   # max error / max |exact| against fp64 on two samples
                 if ref is None:

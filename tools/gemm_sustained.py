@@ -15,7 +15,7 @@ x = torch.randn(B, Ci, P, device="cuda"); y = torch.empty(B, Co, P, device="cuda
 big = torch.randn(256 << 20, device="cuda"); big2 = torch.empty_like(big)
 st = stream_ptr()
 flops = 2.0 * B * Co * Ci * P
-gemm = lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt), None, 0, None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, None, st)
+gemm = lambda: lib.paradis_pw_gemm_fwd(dptr(w), dptr(wt), None, 0, None, dptr(x), None, None, None, None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st)
 for _ in range(5):
     gemm()
 torch.cuda.synchronize()

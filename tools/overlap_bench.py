@@ -22,8 +22,8 @@ def gemm(s, n=4):
 def mem(s, n=8):
     for _ in range(n):
         lib.paradis_channel_norm_bwd(dptr(ga), dptr(a), None, dptr(w), dptr(mean), dptr(rstd), dptr(gx), None, dptr(gw),
-                                     dptr(gb), B, 1152, 0, P, 1152 * P, 0, 1152 * P, 0, None, 0, dptr(ws2), None, sp(s))
-        lib.paradis_act_bwd(dptr(ga), dptr(a), dptr(gx), a.numel(), 1, None, sp(s))
+                                     dptr(gb), B, 1152, 0, P, 1152 * P, 0, 1152 * P, 0, None, 0, dptr(ws2), sp(s))
+        lib.paradis_act_bwd(dptr(ga), dptr(a), dptr(gx), a.numel(), 1, sp(s))
 def wall(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e3
 for _ in range(2):

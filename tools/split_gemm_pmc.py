@@ -22,5 +22,5 @@ xa = torch.empty(1024, dtype=torch.int32, device="cuda")
 lib.paradis_amax_partials(dptr(x), B, Ci * P, Ci * P, dptr(xa), st)
 for _ in range(100):
     assert lib.paradis_pw_gemm_fwd(dptr(w), None, dptr(wsp), SCHEME, dptr(xa), dptr(x), None, None, None, None, 0, None, dptr(y),
-                                   None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, None, st) == 0
+                                   None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st) == 0
 torch.cuda.synchronize()

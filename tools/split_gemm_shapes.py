@@ -52,9 +52,9 @@ def main():
                              lib.paradis_amax_partials(dptr(dy), B, Co * P, Co * P, dptr(da), st)))
         flops = 2.0 * B * Co * Ci * P
         tf = timeit(lambda: lib.paradis_pw_gemm_fwd(dptr(w), None, dptr(wsp), SCHEME, dptr(xa), dptr(x), None, None, None,
-                                                   None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, None, st))
+                                                   None, 0, None, dptr(y), None, B, Co, Ci, P, Ci * P, 0, Co * P, 0, st))
         td = timeit(lambda: lib.paradis_pw_gemm_dgrad(dptr(w), dptr(wtsp), SCHEME, dptr(da), dptr(dy), None, None, dptr(dx),
-                                                     B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, None, st))
+                                                     B, Co, Ci, P, Co * P, 0, 0, Ci * P, 0, st))
         tw = timeit(lambda: lib.paradis_pw_gemm_wgrad(dptr(dy), dptr(x), dptr(dw), None, B, Co, Ci, P, Co * P, Ci * P,
                                                      SCHEME, dptr(da), dptr(xa), dptr(ws), st))
         wd = w.double()

@@ -35,9 +35,9 @@ def main():
     from paradis_model_amd._lib import lib, dptr, stream_ptr
     y = torch.empty_like(x); gx = torch.empty_like(x); gw = torch.empty_like(w)
     st = stream_ptr()
-    t = timeit(lambda: lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), None, dptr(y), B, C, H, W, 5, None, st))
+    t = timeit(lambda: lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), None, dptr(y), B, C, H, W, 5, st))
     print(f"dwconv fwd   {t:7.1f} us  {2 * nb / t / 1e6:6.2f} TB/s")
-    t = timeit(lambda: lib.paradis_dwconv_geo_dgrad(dptr(gy), dptr(w), dptr(gx), B, C, H, W, 5, None, st))
+    t = timeit(lambda: lib.paradis_dwconv_geo_dgrad(dptr(gy), dptr(w), dptr(gx), B, C, H, W, 5, st))
     print(f"dwconv dgrad {t:7.1f} us  {2 * nb / t / 1e6:6.2f} TB/s")
     ws = torch.empty(lib.paradis_dwconv_geo_wgrad_ws_bytes(B, C, H, W, 5) // 4 + 64, device="cuda")
     t = timeit(lambda: lib.paradis_dwconv_geo_wgrad(dptr(gy), dptr(x), dptr(gw), None, B, C, H, W, 5, dptr(ws), st))
