@@ -50,7 +50,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 5: no amax side outputs (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -61,9 +61,14 @@ int paradis_geocyclic_pad_bwd(const float* gy, float* gx, int64_t planes, int H,
 /* ---- a3-a5: fused core of NeuralSemiLagrangian.forward (reference model/advection.py:129-169):
  * pole mean -> departure point (advection.py:74-98) -> virtual geocyclic index map ->
  * bilinear/bicubic gather (ATen grid_sampler_2d semantics, align_corners, zeros) -> pole mean.
- * field/out [B,K,H,W]; u,v [B,K,H,W] with batch stride uv_bs; sin_lat/cos_lat/lon tables [H*W]. */
+ * field/out [B,K,H,W]; u,v [B,K,H,W] with batch stride uv_bs; sin_lat/cos_lat/lon tables [H*W].
+ * lat_cells [H*W] (optional, NULL allowed): the arrival latitude in PADDED cells,
+ *   p + (lat - min_lat) (H-1)/d_lat   with p = 2 (bicubic) | 1 (bilinear), evaluated in double and rounded once.
+ *   The separable schedules (PARADIS_ADVECT_SEPARABLE) need it: they take the departure latitude relative to the
+ *   arrival latitude at small displacements (no asin half-angle chain, no 1/cos(lat) amplification of the rounding
+ *   of sin(lat_d) next to the poles); without the table the per-point kernels run. */
 int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, float* out,
-                          const float* sin_lat, const float* cos_lat, const float* lon,
+                          const float* sin_lat, const float* cos_lat, const float* lat_cells, const float* lon,
                           int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs, int64_t o_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
                           int mode, int flags, void* workspace, void* stream);
@@ -72,7 +77,7 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
 size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
 int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u, const float* v,
                           float* gfield, float* gu, float* gv,
-                          const float* sin_lat, const float* cos_lat, const float* lon,
+                          const float* sin_lat, const float* cos_lat, const float* lat_cells, const float* lon,
                           int B, int K, int H, int W, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                           int64_t gf_bs, int64_t guv_bs,
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,

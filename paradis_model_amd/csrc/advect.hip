@@ -116,20 +116,22 @@ __device__ __forceinline__ void sincos_kernel_small(float r, float& ps, float& p
   pc = fmaf(4.1666668e-2f * z, z, fmaf(-0.5f, z, 1.0f));
 }
 
-__device__ __forceinline__ void sincos_pair(float phi, float lam, float& sp, float& cp, float& sl, float& cl) {
+// Returns the tier taken (wave-uniform): 0 = every lane below 0.125 rad, 1 = below 0.78, 2 = general.
+__device__ __forceinline__ int sincos_pair(float phi, float lam, float& sp, float& cp, float& sl, float& cl) {
   const float big = fmaxf(fabsf(phi), fabsf(lam));
   if (__all(big < 0.125f)) {     // displacements below 7 degrees per step: the usual case
     sincos_kernel_small(phi, sp, cp);
     sincos_kernel_small(lam, sl, cl);
-    return;
+    return 0;
   }
   if (__all(big < 0.78f)) {
     sincos_kernel(phi, sp, cp);
     sincos_kernel(lam, sl, cl);
-    return;
+    return 1;
   }
   sincos_reduced(phi, sp, cp);
   sincos_reduced(lam, sl, cl);
+  return 2;
 }
 
 // (asin(x) - x) / x^3 as a polynomial in y = x^2 on [0, 1/4]; with the half-angle identity
@@ -210,6 +212,55 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
   const float q = floorf(fmaf(t, g.inv_per, g.qoff));
   ix = fmaf(-q, g.per, t);                             // in [c0x, c0x + period) up to one rounding
   iy = fmaf(lat_d, g.cy, g.c0y);
+  if (st) {
+    st->sp = sp; st->cp = cp; st->sl = sl; st->cl = cl; st->s = s; st->n = n; st->d = d;
+  }
+}
+
+// The same map for a wave that is ONE LATITUDE ROW (separable schedules): sa, ca and iya - the arrival latitude
+// in padded cells, p + (lat_a - min_lat) cy - are wave-uniform scalars.  The small-displacement regime is decided
+// ONCE per row by a single vector condition - both rotation angles below 0.125 rad, departure less than 45 degrees
+// of longitude away, no clamp active - behind which the code is straight-line: short sin/cos series, plain atan
+// quotient, and the latitude either from the short asin polynomial (rows within asin's small-argument range for
+// every such displacement: |sin(lat_a)| < 1/4) or RELATIVE to the arrival latitude:
+//     sin(lat_d - lat_a) = s cos(lat_a) - cos(lat_d) sin(lat_a) = sin(phi') - sin(lat_a) (cos(lat_d) - d),
+//     cos(lat_d) = sqrt(n^2 + d^2)
+// (expand s and d: the products of sa, ca cancel exactly), iy = iya + cy asin(small argument): no half-angle chain,
+// and the rounding of s is not amplified by 1 / cos(lat_d) next to the poles - against the fp64 evaluation this form
+// is ~20 x closer than asin(s) in fp32 at every grid size.  Any other wave takes departure().
+__device__ __forceinline__ void departure_row(float u, float v, float sa, float ca, float lonc, float iya,
+                                              const AdvGeom& g, float& ix, float& iy, DepState* st) {
+  const float lam = u * g.ndt;
+  const float phi = v * g.ndt;
+  float sp, cp, sl, cl;
+  sincos_kernel_small(phi, sp, cp);
+  sincos_kernel_small(lam, sl, cl);
+  const float cc = cp * cl;
+  const float s = fmaf(sp, ca, cc * sa);
+  const float n = cp * sl;
+  const float d = fmaf(cc, ca, -(sp * sa));
+#ifndef ADV_NO_REL    // (diagnostic A/B builds only)
+  const bool ok = fmaxf(fabsf(phi), fabsf(lam)) < 0.125f && fabsf(n) < d && fabsf(s) <= CLAMP_HI;
+#else
+  const bool ok = false;
+#endif
+  if (!__all(ok)) {
+    departure(u, v, sa, ca, lonc, g, ix, iy, st);
+    return;
+  }
+  if (fabsf(sa) < 0.25f) {           // scalar: |s| <= |sa| + sin(0.25) < 1/2 for every lane
+    const float y2 = s * s;
+    iy = fmaf(fmaf(s, y2 * asin_poly(y2), s), g.cy, g.c0y);
+  } else {
+    const float cosd = __builtin_amdgcn_sqrtf(fmaf(d, d, n * n));
+    const float arg = fmaf(-sa, cosd - d, sp);         // |arg| <= sin(0.25)
+    const float y2 = arg * arg;
+    iy = fmaf(fmaf(arg, y2 * asin_poly(y2), arg), g.cy, iya);
+  }
+  const float a = atan_poly(n * __builtin_amdgcn_rcpf(d));
+  const float t = fmaf(a, g.cx, lonc);
+  const float q = floorf(fmaf(t, g.inv_per, g.qoff));
+  ix = fmaf(-q, g.per, t);
   if (st) {
     st->sp = sp; st->cp = cp; st->sl = sl; st->cl = cl; st->s = s; st->n = n; st->d = d;
   }
@@ -517,8 +568,8 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
                                             float* __restrict__ O, const float* __restrict__ u,
                                             const float* __restrict__ v, VelCursor& vc, float (&qu)[ADV_PF],
                                             float (&qv)[ADV_PF], const float* __restrict__ sin_lat,
-                                            const float* __restrict__ cos_lat, float lonc, const AdvGeom& g,
-                                            int wave, unsigned lane, bool fill_halo) {
+                                            const float* __restrict__ cos_lat, const float* __restrict__ lat_cells,
+                                            float lonc, const AdvGeom& g, int wave, unsigned lane, bool fill_halo) {
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;
   const int H = g.H, Hp = H + 2 * p, tid = threadIdx.x;
   // halo columns (p left, p + XR right) and the p mirrored rows beyond each pole are copies of interior
@@ -553,7 +604,7 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
     if (y < H) {
       const float sa = sin_lat[y * W], ca = cos_lat[y * W];   // uniform address: scalar loads
       float ix, iy;
-      departure(cu, cv, sa, ca, lonc, g, ix, iy, nullptr);
+      departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
       float acc = XR ? sample_wide<MODE>(cur, ix, iy, WS, WSf) : sample_whole<MODE>(cur, ix, iy, Hp, WS, Hpf, WSf);
       if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
       ADV_ST(acc, &srow(O + y * W)[lane]);
@@ -575,7 +626,7 @@ __global__ void __launch_bounds__(256)
 sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u,
                     const float* __restrict__ v, float* __restrict__ out,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
-                    const float* __restrict__ lon, int K, AdvGeom g, int64_t f_bs, int64_t uv_bs,
+                    const float* __restrict__ lat_cells, const float* __restrict__ lon, int K, AdvGeom g, int64_t f_bs, int64_t uv_bs,
                     int64_t o_bs, int planes, int chunk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;   // WS: window row stride
@@ -613,7 +664,7 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
     const bool has_next = plane + 1 < last;
     const int64_t next_off = has_next ? (int64_t)nb * f_bs + (int64_t)nk * P : 0;
     row64_plane<MODE, XR>(cur, nxt, field, next_off, has_next, out + (int64_t)b * o_bs + (int64_t)k * P, u, v, vc,
-                          qu, qv, sin_lat, cos_lat, lonc, g, wave, lane, plane != first);
+                          qu, qv, sin_lat, cos_lat, lat_cells, lonc, g, wave, lane, plane != first);
     float* t = cur; cur = nxt; nxt = t;
     b = nb; k = nk;
   }
@@ -808,7 +859,7 @@ __global__ void __launch_bounds__(TILED_THREADS_FWD)
 sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__ u,
                       const float* __restrict__ v, float* __restrict__ out,
                       const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
-                      const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
+                      const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans, int K,
                       AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int halo, int tiles_x, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT, NTH = TILED_THREADS_FWD;
@@ -894,7 +945,7 @@ sl_advect_fwd_tilerow(const float* __restrict__ field, const float* __restrict__
         const int y = ty0 + yl;
         const float sa = sin_lat[y * W], ca = cos_lat[y * W];
         float ix, iy, tx, ty;
-        departure(cu, cv, sa, ca, lonc, g, ix, iy, nullptr);
+        departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
         int cell;
         const bool fast = tap_block_window<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, wy0f, WWf, WHf, tx, ty, cell);
         float acc;
@@ -936,14 +987,15 @@ __device__ __forceinline__ unsigned long long fixed_from_float(float x) {
 
 // mx = max |cotangent| of the tile, NaN if any cotangent is NaN (the reduction runs on the bit
 // patterns of |g|: as unsigned integers they order like the floats, and every NaN sorts above +inf)
+template <int BITS = 40>
 __device__ __forceinline__ void fixed_point_scale(float mx, float& scale, float& inv) {
   scale = 0.f; inv = 0.f;
   if (mx > 0.f && mx < INFINITY) {
     int e = 0;
     frexpf(mx, &e);                       // mx < 2^e
     e = e < -80 ? -80 : (e > 80 ? 80 : e);
-    scale = ldexpf(1.0f, 40 - e);
-    inv = ldexpf(1.0f, e - 40);
+    scale = ldexpf(1.0f, BITS - e);
+    inv = ldexpf(1.0f, e - BITS);
   } else if (!(mx < INFINITY)) {
     inv = NAN;                            // Inf or NaN cotangent: the field gradient is NaN, like float adds would give
   }
@@ -1009,6 +1061,73 @@ __device__ __forceinline__ void scatter_gather(unsigned long long* acc, const fl
   }
 }
 
+// ---- scatter variants of the one-wave-per-row kernel (diagnostic A/B: -DADV_BWD_SCATTER=n) -----------------
+#ifndef ADV_BWD_SCATTER
+#define ADV_BWD_SCATTER 0
+#endif
+constexpr int ROW64_ACC_BITS = ADV_BWD_SCATTER >= 3 ? 34 : 40;
+// VAR 0: 16 ds_add_u64 in tap order.
+// VAR 1: odd lanes take the x taps in the order 2,3,0,1: at small displacements the integer tap origin of
+//        neighbouring lanes jitters between x and x-1, so two adjacent lanes meet in one cell of the same
+//        instruction at every second boundary (same-address serialisation); rotated, they are two columns apart.
+// VAR 2: even and odd lanes in separate (exec-masked) instructions.
+// VAR 3: every value as a 32-bit pair n = hi 2^16 + lo (lo in [0, 2^16)) added by two ds_add_u32 into two planes
+//        of 32-bit accumulators (the 64-bit integer add is 3-5x the LDS time of a 32-bit one); |n| < 2^34, at most
+//        2048 contributions per cell: |sum hi| < 2^29, sum lo < 2^27.
+// VAR 4: 3 + 1.
+template <int MODE, int VAR>
+__device__ __forceinline__ void scatter_gather_row64(unsigned long long* acc, int lo_off, const float* win, int base,
+                                                     int WW, const float* wx, const float* wy, const float* dwx,
+                                                     const float* dwy, float gs_, unsigned lane, float& gix, float& giy) {
+  constexpr int NT = Interp<MODE>::NT, ROT = NT / 2;
+  gix = 0.f; giy = 0.f;
+  const bool odd = (lane & 1u) != 0;
+  constexpr bool rotate = VAR == 1 || VAR == 4;
+  double wxd[NT];
+#pragma unroll
+  for (int bb = 0; bb < NT; ++bb) {
+    const float w = rotate ? (odd ? wx[(bb + ROT) % NT] : wx[bb]) : wx[bb];
+    wxd[bb] = (double)w;
+  }
+  // rotated: taps [0, ROT) of an odd lane sit ROT columns further right, taps [ROT, NT) ROT columns further left
+  const int sh = (rotate && odd) ? ROT : 0;
+  unsigned long long* accA = acc + base + sh;
+  unsigned long long* accB = acc + base - sh;
+  unsigned* hiA = reinterpret_cast<unsigned*>(acc) + base + sh;
+  unsigned* hiB = reinterpret_cast<unsigned*>(acc) + base - sh;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    float sxv = 0.f, sdx = 0.f;
+    const double gwy = (double)(gs_ * wy[a]);
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) {
+      const float val = win[base + a * WW + bb];
+      const int off = a * WW + bb;
+      if constexpr (VAR >= 3) {
+        const double d = fma(gwy, wxd[bb], 6755399441055744.0);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+        const unsigned w0 = (unsigned)bits, w1 = (unsigned)(bits >> 32);
+        unsigned* h = (bb < ROT ? hiA : hiB) + off;
+        atomicAdd(h, __builtin_amdgcn_alignbit(w1, w0, 16));   // bits 16..47 of n: floor(n / 2^16) as int32
+        atomicAdd(h + lo_off, w0 & 0xffffu);
+      } else {
+        const unsigned long long v = fixed_from_product(gwy, wxd[bb]);
+        unsigned long long* q = (bb < ROT ? accA : accB) + off;
+        if constexpr (VAR == 2) {
+          if (!odd) atomicAdd(q, v);
+          if (odd) atomicAdd(q, v);
+        } else {
+          atomicAdd(q, v);
+        }
+      }
+      sxv = fmaf(val, wx[bb], sxv);
+      sdx = fmaf(val, dwx[bb], sdx);
+    }
+    gix = fmaf(wy[a], sdx, gix);
+    giy = fmaf(dwy[a], sxv, giy);
+  }
+}
+
 // workgroup maximum of the |cotangent| bit patterns; contains a barrier
 __device__ __forceinline__ float reduce_gmax(unsigned gmaxb, float* misc, int nwaves) {
 #pragma unroll
@@ -1021,13 +1140,17 @@ __device__ __forceinline__ float reduce_gmax(unsigned gmaxb, float* misc, int nw
 }
 
 // W == 64, separable grid: one workgroup per plane, wave w owns rows w, w+4, ...
+// (five workgroups per CU: 29 KB of LDS each; the second launch-bound keeps the registers at 96)
+#ifndef ADV_BWD_WAVES
+#define ADV_BWD_WAVES 5
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, ADV_BWD_WAVES)
 sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ field,
                     const float* __restrict__ u, const float* __restrict__ v,
                     float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
-                    const float* __restrict__ lon, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
+                    const float* __restrict__ lat_cells, const float* __restrict__ lon, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
                     int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int vec4) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0, W = 64;
@@ -1063,7 +1186,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
     Window w{0, 0, Hp, Wp};
     stage_window(win, F, w, H, W, p, false, 0.f, 0.f, 256);
   }
-  for (int i = tid; i < wn; i += 256) acc[i] = 0ull;
+  for (int i = tid; i < wn2; i += 256) acc[i] = 0ull;     // (wn2 64-bit cells = both 32-bit planes of the u32 variants)
   unsigned gmaxb = 0;
   for (int y = wave; y < H; y += 4) {
     const float gval = srow(GO + y * W)[lane];
@@ -1078,7 +1201,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
   __syncthreads();
   const float gm0 = misc[0], gm1 = misc[1];
   float scale, inv_scale;   // every thread derives the same power-of-two scale
-  fixed_point_scale(mxall, scale, inv_scale);
+  fixed_point_scale<ROW64_ACC_BITS>(mxall, scale, inv_scale);
 
   const float Hpf = (float)Hp, Wpf = (float)Wp;
   for (int y0 = wave; y0 < H; y0 += 4 * ADV_PF) {
@@ -1094,7 +1217,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
         const float sa = sin_lat[y * W], ca = cos_lat[y * W];
         float ix, iy, tx, ty, wx[NT], wy[NT], dwx[NT], dwy[NT];
         DepState st;
-        departure(cu, cv, sa, ca, lonc, g, ix, iy, &st);
+        departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, &st);
         int cell;
         const bool edge = tap_block_whole<MODE>(ix, iy, Hpf, Wpf, tx, ty, cell);
         int base = cell + OFF0 * (Wp + 1);
@@ -1112,7 +1235,8 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
         }
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
         float gix, giy;
-        scatter_gather<MODE>(acc, win, base, Wp, wx, wy, dwx, dwy, gval * scale, gix, giy);
+        scatter_gather_row64<MODE, ADV_BWD_SCATTER>(acc, wn2, win, base, Wp, wx, wy, dwx, dwy, gval * scale, lane, gix,
+                                                    giy);
         float guv, gvv;
         departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
         srow(GU + y * W)[lane] = guv;
@@ -1129,20 +1253,38 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
   const unsigned xm = lane ^ 32u;                     // (x + W/2) mod W
   const bool mlo = xm < p, mhi = xm >= W - p;
   for (int y = wave; y < H; y += 4) {
-    const unsigned long long* row = acc + (y + p) * Wp + p;
-    long long s = (long long)row[lane];
-    if (lo_edge) s += (long long)row[lane + W];
-    if (hi_edge) s += (long long)row[lane - W];
     int mr = -1;                                 // padded row of the over-the-pole alias (wave-uniform)
     if (y >= 1 && y <= p) mr = p - y;
     else if (y >= H - 1 - p && y <= H - 2) mr = 2 * (H - 1) - y + p;
-    if (mr >= 0) {
-      const unsigned long long* mrow = acc + mr * Wp + p;
-      s += (long long)mrow[xm];
-      if (mlo) s += (long long)mrow[xm + W];
-      if (mhi) s += (long long)mrow[xm - W];
+    float val;
+    if constexpr (ADV_BWD_SCATTER >= 3) {
+      const unsigned* hrow = reinterpret_cast<const unsigned*>(acc) + (y + p) * Wp + p;
+      const unsigned* lrow = hrow + wn2;
+      int sh = (int)hrow[lane];
+      unsigned sl = lrow[lane];
+      if (lo_edge) { sh += (int)hrow[lane + W]; sl += lrow[lane + W]; }
+      if (hi_edge) { sh += (int)hrow[lane - W]; sl += lrow[lane - W]; }
+      if (mr >= 0) {
+        const unsigned* mh = reinterpret_cast<const unsigned*>(acc) + mr * Wp + p;
+        const unsigned* ml = mh + wn2;
+        sh += (int)mh[xm]; sl += ml[xm];
+        if (mlo) { sh += (int)mh[xm + W]; sl += ml[xm + W]; }
+        if (mhi) { sh += (int)mh[xm - W]; sl += ml[xm - W]; }
+      }
+      val = (float)(fma((double)sh, 65536.0, (double)sl) * inv);
+    } else {
+      const unsigned long long* row = acc + (y + p) * Wp + p;
+      long long s = (long long)row[lane];
+      if (lo_edge) s += (long long)row[lane + W];
+      if (hi_edge) s += (long long)row[lane - W];
+      if (mr >= 0) {
+        const unsigned long long* mrow = acc + mr * Wp + p;
+        s += (long long)mrow[xm];
+        if (mlo) s += (long long)mrow[xm + W];
+        if (mhi) s += (long long)mrow[xm - W];
+      }
+      val = (float)((double)s * inv);
     }
-    float val = (float)((double)s * inv);
     if (y == 0 || y == H - 1) val = wave_sum(val) * (1.0f / 64.0f);
     srow(GF + y * W)[lane] = val;
   }
@@ -1331,7 +1473,7 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
                       const float* __restrict__ u, const float* __restrict__ v,
                       float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
                       const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
-                      const float* __restrict__ lon, const float* __restrict__ fmeans,
+                      const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
                       const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
                       int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1428,7 +1570,7 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
         const float sa = sin_lat[y * W], ca = cos_lat[y * W];
         float ix, iy, tx, ty;
         DepState st;
-        departure(cu, cv, sa, ca, lonc, g, ix, iy, &st);
+        departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, &st);
         int cell;
         const bool fast = tap_block_window<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, wy0f, WWf, WHf, tx, ty, cell);
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
@@ -1570,9 +1712,10 @@ bool taps_stay_inside(const AdvGeom& g, int NT, int xr) {
 }
 // one wave per latitude row with scalar table loads: W == 64 and a grid whose latitude depends on the
 // row only and whose longitude depends on the column only (the caller vouches for it through `flags`)
-bool use_row64(int W, int flags) {
-  return W == 64 && (flags & PARADIS_ADVECT_SEPARABLE) && !(flags & PARADIS_ADVECT_GENERIC);
+bool separable(int flags, const float* lat_cells) {
+  return (flags & PARADIS_ADVECT_SEPARABLE) && !(flags & PARADIS_ADVECT_GENERIC) && lat_cells != nullptr;
 }
+bool use_row64(int W, int flags, const float* lat_cells) { return W == 64 && separable(flags, lat_cells); }
 
 }  // namespace
 
@@ -1600,7 +1743,8 @@ extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W) {
   } while (0)
 
 extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, float* out,
-                                     const float* sin_lat, const float* cos_lat, const float* lon,
+                                     const float* sin_lat, const float* cos_lat, const float* lat_cells,
+                                     const float* lon,
                                      int B, int K, int H, int W, int64_t f_bs, int64_t uv_bs,
                                      int64_t o_bs, float dt, float min_lat, float min_lon,
                                      float d_lat, float d_lon, int mode, int flags, void* workspace,
@@ -1616,7 +1760,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
   // 16-byte staging path: aligned planes, p even (bicubic), padded width even
   const int vec4 = (W % 4 == 0) && (f_bs % 4 == 0) && (((int64_t)H * W) % 4 == 0) && a16(field) && (p % 2 == 0);
   if (!use_tiled(whole, flags)) {
-    if (use_row64(W, flags)) {
+    if (use_row64(W, flags, lat_cells)) {
       const bool wide = taps_stay_inside(g, NT, ROW64_XR);
       const size_t lds = 2 * (size_t)(H + 2 * p) * (W + 2 * p + (wide ? ROW64_XR : 0)) * sizeof(float);
       static PerDeviceOnce once64;
@@ -1630,7 +1774,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
       const int chunk = ROW64_CHUNK, groups = (planes + chunk - 1) / chunk;
 #define ROW64_FWD(MODE_, XR_)                                                                              \
       hipLaunchKernelGGL((sl_advect_fwd_row64<MODE_, XR_>), dim3(groups), dim3(256), lds, st, field, u, v, out, \
-                         sin_lat, cos_lat, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk)
+                         sin_lat, cos_lat, lat_cells, lon, K, g, f_bs, uv_bs, o_bs, planes, chunk)
       if (mode == PARADIS_INTERP_BICUBIC) { if (wide) ROW64_FWD(PARADIS_INTERP_BICUBIC, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BICUBIC, 0); }
       else { if (wide) ROW64_FWD(PARADIS_INTERP_BILINEAR, ROW64_XR); else ROW64_FWD(PARADIS_INTERP_BILINEAR, 0); }
 #undef ROW64_FWD
@@ -1655,7 +1799,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
         reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
       return 2;
   }
-  if (flags & PARADIS_ADVECT_SEPARABLE && !(flags & PARADIS_ADVECT_GENERIC)) {
+  if (separable(flags, lat_cells)) {
     static PerDeviceOnce once_row;
     if (once_row.first()) {
       if (reserve_lds(&sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>, "sl_advect_fwd: cannot reserve LDS") ||
@@ -1664,12 +1808,12 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
     }
     if (mode == PARADIS_INTERP_BICUBIC)
       hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
-                         dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
+                         dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lat_cells,
+                         lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
     else
       hipLaunchKernelGGL((sl_advect_fwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
-                         dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
+                         dim3(TILED_THREADS_FWD), lds, st, field, u, v, out, sin_lat, cos_lat, lat_cells,
+                         lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles);
   } else {
     ADV_LAUNCH(sl_advect_fwd_kernel, false, TILED_THREADS_FWD, (unsigned)(planes * tiles), lds, field, u, v, out, sin_lat,
                cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, halo, tx, tiles, vec4);
@@ -1681,7 +1825,8 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
 
 extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u,
                                      const float* v, float* gfield, float* gu, float* gv,
-                                     const float* sin_lat, const float* cos_lat, const float* lon,
+                                     const float* sin_lat, const float* cos_lat, const float* lat_cells,
+                                     const float* lon,
                                      int B, int K, int H, int W, int64_t go_bs, int64_t f_bs,
                                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, float dt,
                                      float min_lat, float min_lon, float d_lat, float d_lon, int mode,
@@ -1697,8 +1842,8 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                    (reinterpret_cast<uintptr_t>(field) & 15) == 0;
   const size_t whole = lds_of((size_t)(H + 2 * p) * (W + 2 * p));
   if (!use_tiled(whole, flags)) {
-    if (use_row64(W, flags))
-      ADV_LAUNCH_ROW64(sl_advect_bwd_row64, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
+    if (use_row64(W, flags, lat_cells))
+      ADV_LAUNCH_ROW64(sl_advect_bwd_row64, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon,
                        K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, vec4);
     else
       ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
@@ -1729,7 +1874,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
         reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS"))
       return 2;
   }
-  if (flags & PARADIS_ADVECT_SEPARABLE && !(flags & PARADIS_ADVECT_GENERIC)) {
+  if (separable(flags, lat_cells)) {
     static PerDeviceOnce once_row;
     if (once_row.first()) {
       if (reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC>, "sl_advect_bwd: cannot reserve LDS") ||
@@ -1738,13 +1883,13 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
     }
     if (mode == PARADIS_INTERP_BICUBIC)
       hipLaunchKernelGGL((sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
-                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
+                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells,
+                         lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
                          tx, tiles);
     else
       hipLaunchKernelGGL((sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
-                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon,
-                         (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
+                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells,
+                         lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
                          tx, tiles);
   } else {
     ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,

@@ -175,15 +175,20 @@ class AdvectGeometry:
         self.d_lon = float(lon.max() - lon.min())
         # regular lat-lon grid: latitude depends on the row only, longitude on the column only
         self.separable = bool((lat == lat[:, :1]).all()) and bool((lon == lon[:1, :]).all())
+        # arrival latitude in cells, (lat - min_lat) (H-1)/d_lat, in double; the padding p is added per mode
+        cells = (lat.double() - self.min_lat) * ((self.H - 1.0) / self.d_lat) if self.d_lat > 0 else lat.double() * 0
+        self.lat_cells = {p: (cells + float(p)).to(torch.float32).contiguous() for p in (1, 2)}
         self._dev = {}
 
-    def tables(self, device):
-        key = str(device)
+    def tables(self, device, p: int = 2):
+        """(sin_lat, cos_lat, lat_cells, lon) on ``device``; lat_cells = p + (lat - min_lat)(H-1)/d_lat as fp32"""
+        key = (str(device), p)
         if key not in self._dev:
-            self._dev[key] = tuple(t.to(device) for t in (self.sin_lat, self.cos_lat, self.lon))
+            self._dev[key] = tuple(t.to(device) for t in (self.sin_lat, self.cos_lat, self.lat_cells[p], self.lon))
         return self._dev[key]
 
 
+_ADV_TABLES = "Tensor sin_lat, Tensor cos_lat, Tensor lat_cells, Tensor lon"
 _ADV_GEOM = "float dt, float min_lat, float min_lon, float d_lat, float d_lon, int mode, int flags"
 
 
@@ -193,8 +198,8 @@ def _bstride_view(t: Tensor, K: int, H: int, W: int) -> Tuple[Tensor, int]:
     return t.contiguous(), K * H * W
 
 
-@_define(f"sl_advect(Tensor field, Tensor u, Tensor v, Tensor sin_lat, Tensor cos_lat, Tensor lon, {_ADV_GEOM}) -> Tensor")
-def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+@_define(f"sl_advect(Tensor field, Tensor u, Tensor v, {_ADV_TABLES}, {_ADV_GEOM}) -> Tensor")
+def _sl_advect(field, u, v, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     _f32(field, u, v)
     B, K, H, W = field.shape
     field, f_bs = _bstride_view(field, K, H, W)
@@ -206,19 +211,19 @@ def _sl_advect(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
-              dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lo), B, K, H, W,
+              dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lc), dptr(lo), B, K, H, W,
               f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), stream_ptr())
     return out
 
 
 @_fake("sl_advect")
-def _(field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+def _(field, u, v, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     return field.new_empty(field.shape)
 
 
-@_define(f"sl_advect_backward(Tensor gout, Tensor field, Tensor u, Tensor v, Tensor sin_lat, Tensor cos_lat, "
-         f"Tensor lon, {_ADV_GEOM}) -> (Tensor, Tensor, Tensor)")
-def _sl_advect_backward(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+@_define(f"sl_advect_backward(Tensor gout, Tensor field, Tensor u, Tensor v, {_ADV_TABLES}, "
+         f"{_ADV_GEOM}) -> (Tensor, Tensor, Tensor)")
+def _sl_advect_backward(gout, field, u, v, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     _f32(gout, field, u, v)
     B, K, H, W = gout.shape
     P = K * H * W
@@ -234,31 +239,31 @@ def _sl_advect_backward(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_l
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
               dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
-              dptr(cl), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
+              dptr(cl), dptr(lc), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
               flags, dptr(ws), stream_ptr())
     return gfield, gu, gv
 
 
 @_fake("sl_advect_backward")
-def _(gout, field, u, v, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+def _(gout, field, u, v, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     return gout.new_empty(gout.shape), gout.new_empty(gout.shape), gout.new_empty(gout.shape)
 
 
 def _adv_setup(ctx, inputs, output):
-    ctx.save_for_backward(*inputs[:6])
-    ctx.geom = inputs[6:]
+    ctx.save_for_backward(*inputs[:7])
+    ctx.geom = inputs[7:]
 
 
 def _adv_backward(ctx, gout):
     gf, gu, gv = _sl_advect_backward(gout, *ctx.saved_tensors, *ctx.geom)
-    return (gf, gu, gv) + (None,) * 10
+    return (gf, gu, gv) + (None,) * 11
 
 
 _autograd("sl_advect", _adv_setup, _adv_backward)
 
 
-@_define(f"sl_advect_vel(Tensor field, Tensor vel, Tensor sin_lat, Tensor cos_lat, Tensor lon, {_ADV_GEOM}) -> Tensor")
-def _sl_advect_vel(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+@_define(f"sl_advect_vel(Tensor field, Tensor vel, {_ADV_TABLES}, {_ADV_GEOM}) -> Tensor")
+def _sl_advect_vel(field, vel, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     """Same operator taking the velocity tensor [B,2K,H,W] whole (channels [0,K) = u, [K,2K) = v,
     reference model/paradis.py:236-237): no slice views, and the velocity gradient is written in
     place into one [B,2K,H,W] tensor."""
@@ -270,19 +275,19 @@ def _sl_advect_vel(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, m
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(vel[:, :K]), dptr(vel[:, K:]), dptr(out),
-              dptr(sl), dptr(cl), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
+              dptr(sl), dptr(cl), dptr(lc), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
               flags, dptr(ws), stream_ptr())
     return out
 
 
 @_fake("sl_advect_vel")
-def _(field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+def _(field, vel, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     return field.new_empty(field.shape)
 
 
-@_define(f"sl_advect_vel_backward(Tensor gout, Tensor field, Tensor vel, Tensor sin_lat, Tensor cos_lat, "
-         f"Tensor lon, {_ADV_GEOM}) -> (Tensor, Tensor)")
-def _sl_advect_vel_backward(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+@_define(f"sl_advect_vel_backward(Tensor gout, Tensor field, Tensor vel, {_ADV_TABLES}, "
+         f"{_ADV_GEOM}) -> (Tensor, Tensor)")
+def _sl_advect_vel_backward(gout, field, vel, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     _f32(gout, field, vel)
     B, K, H, W = gout.shape
     P = K * H * W
@@ -294,24 +299,24 @@ def _sl_advect_vel_backward(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, 
     ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
               dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
-              dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
+              dptr(lc), dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
               flags, dptr(ws), stream_ptr())
     return gfield, gvel
 
 
 @_fake("sl_advect_vel_backward")
-def _(gout, field, vel, sl, cl, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
+def _(gout, field, vel, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, mode, flags):
     return gout.new_empty(gout.shape), vel.new_empty(vel.shape)
 
 
 def _advv_setup(ctx, inputs, output):
-    ctx.save_for_backward(*inputs[:5])
-    ctx.geom = inputs[5:]
+    ctx.save_for_backward(*inputs[:6])
+    ctx.geom = inputs[6:]
 
 
 def _advv_backward(ctx, gout):
     gf, gvel = _sl_advect_vel_backward(gout, *ctx.saved_tensors, *ctx.geom)
-    return (gf, gvel) + (None,) * 10
+    return (gf, gvel) + (None,) * 11
 
 
 _autograd("sl_advect_vel", _advv_setup, _advv_backward)
@@ -334,11 +339,11 @@ def advect_flags(tiled: bool = False, halo: Optional[int] = None, halo_bwd: Opti
 def _geom_args(geom: AdvectGeometry, device, dt: float, mode: str, flags: Optional[int]):
     if mode not in MODE_CODES:
         raise ValueError(f"interpolation must be one of {list(MODE_CODES)}")
-    sl, cl, lo = geom.tables(device)
+    sl, cl, lc, lo = geom.tables(device, 2 if mode == "bicubic" else 1)
     flags = ADVECT_FLAGS if flags is None else int(flags)
     if geom.separable:
         flags |= ADVECT_SEPARABLE
-    return sl, cl, lo, float(dt), geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode], flags
+    return sl, cl, lc, lo, float(dt), geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode], flags
 
 
 def sl_advect_vel(field, vel, geom: AdvectGeometry, dt: float, mode: str = "bicubic", flags: Optional[int] = None):

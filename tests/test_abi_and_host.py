@@ -39,10 +39,10 @@ def test_argument_validation_without_gpu():
     assert L.paradis_geocyclic_pad_fwd(None, None, 1, 8, 7, 1, None) == 1      # odd longitude count
     assert "even" in _lib.last_error()
     assert L.paradis_geocyclic_pad_fwd(None, None, 1, 4, 8, 3, None) == 1      # pad > H-2
-    assert L.paradis_dwconv_geo_fwd(None, None, None, None, 1, 4, 16, 32, 4, None, None) == 1   # even kernel
-    assert L.paradis_sl_advect_fwd(None, None, None, None, None, None, None, 1, 1, 16, 32, 0, 0, 0,
-                                   0.1, 0.0, 0.0, 1.0, 1.0, 3, 0, None, None, None) == 1        # bad mode
-    assert L.paradis_pw_gemm_fwd(None, None, None, 0, None, None, None, None, None, None, 0, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None, None) == 1
+    assert L.paradis_dwconv_geo_fwd(None, None, None, None, 1, 4, 16, 32, 4, None) == 1   # even kernel
+    assert L.paradis_sl_advect_fwd(None, None, None, None, None, None, None, None, 1, 1, 16, 32, 0, 0, 0,
+                                   0.1, 0.0, 0.0, 1.0, 1.0, 3, 0, None, None) == 1              # bad mode
+    assert L.paradis_pw_gemm_fwd(None, None, None, 0, None, None, None, None, None, None, 0, None, None, None, 1, 0, 4, 4, 0, 0, 0, 0, None) == 1
     assert L.paradis_avgpool_geo_fwd(None, None, 1, 16, 32, 0, None) == 1      # stride < 1
     # data feed (row f4): window longer than the series; unknown forcing code; no variables
     import ctypes

@@ -104,7 +104,7 @@ def test_fake_kernels_of_backward_ops_give_the_right_shapes():
         e = lambda *s: torch.empty(*s, device="cuda")
         B, C, H, W, K = 2, 6, 8, 16, 3
         assert O.geocyclic_pad_backward(e(B, C, H + 4, W + 4), 2).shape == (B, C, H, W)
-        tabs = (e(H, W), e(H, W), e(H, W), 0.1, 0.0, 0.0, 1.0, 1.0, 2, 0)
+        tabs = (e(H, W), e(H, W), e(H, W), e(H, W), 0.1, 0.0, 0.0, 1.0, 1.0, 2, 0)
         gf, gu, gv = O.sl_advect_backward(e(B, K, H, W), e(B, K, H, W), e(B, K, H, W), e(B, K, H, W), *tabs)
         assert gf.shape == gu.shape == gv.shape == (B, K, H, W)
         gf, gvel = O.sl_advect_vel_backward(e(B, K, H, W), e(B, K, H, W), e(B, 2 * K, H, W), *tabs)

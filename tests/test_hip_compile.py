@@ -102,11 +102,11 @@ def test_opcheck_registrations():
     H, W = 8, 16
     _, lg, og = make_grid(H, W, False)
     geom = ops.AdvectGeometry(lg, og)
-    sl, cl, lo = geom.tables(torch.device("cuda"))
+    sl, cl, lc, lo = geom.tables(torch.device("cuda"), 2)
     g = lambda *s: torch.randn(*s, device="cuda", requires_grad=True)
     opcheck(torch.ops.paradis.geocyclic_pad.default, (g(1, 2, H, W), 2), test_utils=tests)
     opcheck(torch.ops.paradis.sl_advect.default,
-            (g(1, 2, H, W), g(1, 2, H, W), g(1, 2, H, W), sl, cl, lo, 0.2, geom.min_lat, geom.min_lon,
+            (g(1, 2, H, W), g(1, 2, H, W), g(1, 2, H, W), sl, cl, lc, lo, 0.2, geom.min_lat, geom.min_lon,
              geom.d_lat, geom.d_lon, 2, 0), test_utils=tests)
     opcheck(torch.ops.paradis.dwconv_geo.default, (g(1, 3, H, W), g(3, 1, 5, 5), None), test_utils=tests)
     opcheck(torch.ops.paradis.channel_norm.default, (g(1, 4, H, W), g(1, 2, H, W), g(6), g(6), 1e-5),

@@ -160,12 +160,25 @@ def test_cfg3_default_model_128x256_forward_vs_oracle():
     assert e <= 1e-5, e
 
 
+def _smooth(x, k=9, times=2):
+    """low-pass in both directions (longitude periodic): what ERA5 fields look like next to white noise"""
+    import torch.nn.functional as F
+    h = k // 2
+    for _ in range(times):
+        x = F.pad(x, (h, h, 0, 0), mode="circular")
+        x = F.pad(x, (0, 0, h, h), mode="replicate")
+        x = F.avg_pool2d(x, k, stride=1)
+    return x
+
+
 def _oracle_grads_ckpt(model, spec, x, ct, lg, og, dtype):
-    """oracle forward + every parameter gradient with one ADR layer's intermediates alive at a time"""
+    """oracle forward + every parameter gradient with one ADR layer's intermediates alive at a time.  Both
+    precisions go through ATen's grid_sample (the reference's own operator; in fp64 it agrees with the oracle's
+    explicit tap formula to 1e-12, tests/test_oracle_golden.py, and is 30 x faster on the host)."""
     ps = {k: v.detach().cpu().to(dtype).requires_grad_(True) if v.dtype.is_floating_point else v.detach().cpu()
           for k, v in model.state_dict().items()}
-    y = O.paradis_forward(ps, spec, x.to(dtype), lg.to(dtype), og.to(dtype),
-                          interp_impl="aten_ref" if dtype == torch.float32 else "taps", checkpoint_layers=True)
+    y = O.paradis_forward(ps, spec, x.to(dtype), lg.to(dtype), og.to(dtype), interp_impl="aten_ref",
+                          checkpoint_layers=True)
     (y * ct.to(dtype)).sum().backward()
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
@@ -174,16 +187,22 @@ def test_cfg3_default_model_128x256_gradients_fp64_protocol():
     """configs[3]'s per-sample work inside the 60 M-parameter model: forward AND every parameter gradient at
     128x256, B=1 - the tile-row advection scatter with its window flush, the GlobalBias projection adjoint
     behind the GEMM epilogue, split-k weight gradients over 32,768 points - by the fp64 protocol of SURVEY 8c(iii):
-    the HIP gradient's distance to the fp64 oracle against the CPU-fp32 oracle's own distance."""
-    from tests.test_hip_model import _check_grads_by_fp64_protocol
+    the HIP gradient's distance to the fp64 oracle against the CPU-fp32 oracle's own distance.
+
+    Smooth inputs (what ERA5 fields look like): with white noise the field slope per cell does not fall with the
+    grid spacing, eight layers of semi-Lagrangian displacement amplify fp32 coordinate rounding chaotically and
+    the CPU-fp32 oracle itself is 1-20 % off the fp64 one in the velocity networks' gradients (measured) - nothing
+    could be told apart.  Even so the velocity path stays ill-conditioned (CPU-fp32 vs fp64: median 8e-5 over the
+    335 parameters, up to 7e-2 in velocity_nets.3), so besides the max-abs metric (ratio of two maxima of
+    heavy-tailed errors: factor 6) the norm-wise error is bounded by factor 4."""
     cfg = default_config()
     H, W = 128, 256
     _, lg, og = make_grid(H, W, False)
-    model = _build(cfg, lg, og)
+    model = _build(cfg, lg, og, bias_scale=0.05)
     spec = _spec(cfg, H, W)
-    x = seeded(23, 1, 186, H, W)
+    x = _smooth(seeded(23, 1, 186, H, W)) * 4.0
     x[:, -2], x[:, -1] = lg, og
-    ct = seeded(24, 1, 97, H, W)
+    ct = _smooth(seeded(24, 1, 97, H, W)) * 4.0
     y32, g32 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float32)
     y64, g64 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float64)
     got = model(x.cuda())
@@ -191,8 +210,23 @@ def test_cfg3_default_model_128x256_gradients_fp64_protocol():
     e, e_cpu = max_rel(got.detach().cpu(), y32), max_rel(y32, y64)
     print("cfg3 128x256 default model: forward max-rel vs cpu32 %.2e (cpu32 vs fp64 %.2e)" % (e, e_cpu))
     assert e <= 1e-5, e
-    worst = _check_grads_by_fp64_protocol(model, g32, g64)
-    print("cfg3 128x256 default model: worst grad error vs fp64 (gpu, cpu32)", worst)
+    bad, worst, ratios = [], ("", 0.0, 0.0), []
+    for n, p in model.named_parameters():
+        ref = g64.get(n)
+        if ref is None or float(ref.abs().max()) == 0:
+            continue
+        gg, gc = p.grad.cpu().double(), g32[n].double()
+        m_gpu, m_cpu = max_rel(gg, ref), max_rel(gc, ref)
+        r_gpu, r_cpu = rms_rel(gg, ref), rms_rel(gc, ref)
+        ratios.append(r_gpu / max(r_cpu, 1e-12))
+        if not (m_gpu <= 6.0 * m_cpu + 2e-5 and r_gpu <= 4.0 * r_cpu + 1e-5):
+            bad.append((n, m_gpu, m_cpu, r_gpu, r_cpu))
+        if m_gpu > worst[1]:
+            worst = (n, m_gpu, m_cpu)
+    ratios.sort()
+    print("cfg3 128x256 default model: worst grad max-rel vs fp64 (gpu, cpu32)", worst,
+          "; rms ratio gpu/cpu32 median %.2f max %.2f" % (ratios[len(ratios) // 2], ratios[-1]))
+    assert not bad, bad
 
 
 def test_cfg3_train_step_b8_properties():
@@ -310,17 +344,6 @@ def _roll_lon(model, x, s):
             if n.endswith(".V"):           # GlobalBias V[rank, W]
                 p.copy_(torch.roll(p, s, dims=1))
     return m2, torch.roll(x, s, dims=-1)
-
-
-def _smooth(x, k=9, times=2):
-    """low-pass in both directions (longitude periodic): what ERA5 fields look like next to white noise"""
-    import torch.nn.functional as F
-    h = k // 2
-    for _ in range(times):
-        x = F.pad(x, (h, h, 0, 0), mode="circular")
-        x = F.pad(x, (0, 0, h, h), mode="replicate")
-        x = F.avg_pool2d(x, k, stride=1)
-    return x
 
 
 @pytest.mark.parametrize("H,W,poles", [(721, 1440, True)])
