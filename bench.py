@@ -192,6 +192,9 @@ def main():
                     help="skip the extra timed loops (exact_f32_gemm, f16x2_emulated)")
     ap.add_argument("--bucket-mb", type=int, default=32, help="DDP gradient bucket size (N>1)")
     ap.add_argument("--static-graph", action="store_true", help="DDP static_graph=True (N>1)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole training step from a captured HIP graph (harness.GraphedTrainStep; N = 1); "
+                         "implies --no-kernel-events and skips the extra legs")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
@@ -236,9 +239,16 @@ def main():
     model = Paradis(stub_datamodule(cfg), cfg, lg, og).to(dev)
     loss_fn = build_loss(cfg, lat_deg).to(dev)
     ddp = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, static_graph=args.static_graph)
+    if args.graph:
+        if world > 1 or args.optimizer != "adamw":
+            raise SystemExit("--graph: single GPU, AdamW only")
+        args.no_kernel_events = args.no_extra_legs = True
     step = TrainStep(ddp, loss_fn, cfg, num_common=lay.num_common_features,
-                     n_inputs=cfg.dataset.n_time_inputs)
+                     n_inputs=cfg.dataset.n_time_inputs, capturable=args.graph)
     batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234 + rank, device=dev)
+    if args.graph and not args.forward_only:
+        from paradis_model_amd.harness import GraphedTrainStep
+        step = GraphedTrainStep(step, batch, warmup=2)
     if args.forward_only:
         from paradis_model_amd.harness import assemble_model_input
         mi = assemble_model_input(batch[0], batch[2].permute(0, 1, 4, 2, 3)[:, 0].unsqueeze(1),
@@ -319,6 +329,7 @@ def main():
                                  "range per element), 6 products on bf16 MFMA, fp32 accumulate",
                        "exact": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}[args.gemm],
                    "mode": "forward-only" if args.forward_only else "train",
+                   "hip_graph": bool(args.graph),
                    "activation_checkpointing": bool(args.checkpoint),
                    "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
                    "final_loss": float(loss)},

@@ -233,11 +233,16 @@ int paradis_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, 
                        float beta2, float eps, float weight_decay, int step, void* stream);
 /* The same update for a whole parameter group in one launch.  Device tables: ptrs[4][n_tensors]
  * (addresses of p, g, m, v as int64), numel[n_tensors], and one entry per chunk of
- * paradis_adamw_chunk() elements: chunk_tensor[n_chunks], chunk_off[n_chunks]. */
+ * paradis_adamw_chunk() elements: chunk_tensor[n_chunks], chunk_off[n_chunks].
+ * dev_state (optional, NULL = use `step` and `lr`): int32[2] on the device, [0] = step count, [1] = the bits of
+ * the fp32 learning rate.  With it the bias corrections are formed on the device, so a HIP graph captured around
+ * the training step (harness.GraphedTrainStep) stays valid from replay to replay; paradis_adamw_tick advances the
+ * count on the stream (once per optimiser step, before the groups' updates). */
 int paradis_adamw_chunk(void);
 int paradis_adamw_multi(const int64_t* ptrs, const int64_t* numel, const int* chunk_tensor,
                         const int64_t* chunk_off, int n_tensors, int n_chunks, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, int step, void* stream);
+                        float beta2, float eps, float weight_decay, int step, const int* dev_state, void* stream);
+int paradis_adamw_tick(int* dev_state, void* stream);
 
 /* ---- f3 (second half): Muon / NorMuon step on T same-shaped weight matrices w_t[rows, cols] (conv
  * weights flattened to [out, in*kh*kw]), the reference's default optimiser for Conv/Linear weights

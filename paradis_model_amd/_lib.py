@@ -81,7 +81,8 @@ SIGNATURES = {
     "paradis_muon_step": (I, [P, I, I, I, I, F, F, F, F, F, F, I, I, I, P, P]),
     "paradis_bgemm": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P, P]),
     "paradis_adamw_chunk": (I, []),
-    "paradis_adamw_multi": (I, [P, P, P, P, I, I, F, F, F, F, F, I, P]),
+    "paradis_adamw_multi": (I, [P, P, P, P, I, I, F, F, F, F, F, I, P, P]),
+    "paradis_adamw_tick": (I, [P, P]),
 }
 
 _missing = []

@@ -52,7 +52,16 @@ namespace {
 
 constexpr float CLAMP_HI = 0.9999999f;  // float(1 - 1e-7), as torch.clamp converts its python bound
 constexpr float KA = -0.75f;
-constexpr int TILE_H = 16, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
+#ifndef ADV_TILE_H         // (A/B builds: tools/build_variant.sh)
+#define ADV_TILE_H 16
+#endif
+#ifndef ADV_TILED_THREADS_BWD
+#define ADV_TILED_THREADS_BWD 512
+#endif
+#ifndef ADV_HALO_BWD
+#define ADV_HALO_BWD 10
+#endif
+constexpr int TILE_H = ADV_TILE_H, TILE_W = 128;  // arrival tile of the tiled schedule (backward)
 // forward tile height: a taller tile amortises the halo (window cells per arrival point 2.6 at 16
 // rows, 1.9 at 32, 1.5 at 64 with a halo of 8); the forward window is 4 B/cell, so LDS is not the
 // limit.  Measured at 128x256: 1.64 / 1.42 / 1.23 ms per launch for 16 / 32 / 64 rows
@@ -60,7 +69,7 @@ constexpr int TILE_HF = 64;
 // threads per tile in the tiled schedule: the window fixes the LDS per workgroup, so waves per SIMD
 // come from the workgroup size.  Backward (12 B/cell, 2 workgroups per CU): at 256 threads it ran 1.7
 // waves per SIMD at 29 % VALU issue, 512 threads measured 6.9 -> 5.6 ms at 128x256
-constexpr int TILED_THREADS_FWD = 512, TILED_THREADS_BWD = 512;
+constexpr int TILED_THREADS_FWD = 512, TILED_THREADS_BWD = ADV_TILED_THREADS_BWD;
 constexpr int ADV_PF = 2;   // prefetch distance (points) of the operand loads
 
 struct AdvGeom {
@@ -1007,9 +1016,17 @@ __device__ __forceinline__ void departure_backward(const DepState& st, float sa,
                                                    float giy, const AdvGeom& g, float& gu, float& gv) {
   const float glam_c = gix * g.cx, gphi_c = giy * g.cy;
   const float sc = __builtin_amdgcn_fmed3f(st.s, -CLAMP_HI, CLAMP_HI);
+  // d asin(s) / ds = 1 / sqrt(1 - s^2) = 1 / cos(lat_d), and 1 - s^2 = n^2 + d^2 identically ((s, n, d) is a unit
+  // vector): the sum of squares has no cancellation, whereas 1 - s^2 formed from the rounded s loses
+  // log2(1 / cos^2(lat_d)) bits next to the poles (at 89.3 degrees: relative error 8e-4 in fp32) - the reference's
+  // fp32 autograd carries that error, the fp64 evaluation does not.
   // v_rsq / v_rcp (1 ulp) with one Newton step on the reciprocal: gradient error ~1e-7 relative
-  const float gs = (sc == st.s) ? gphi_c * __builtin_amdgcn_rsqf(fmaf(-sc, sc, 1.0f)) : 0.f;
   const float den = fmaf(st.n, st.n, st.d * st.d);
+#ifdef ADV_GS_FROM_S     // (diagnostic A/B builds only: the reference's form)
+  const float gs = (sc == st.s) ? gphi_c * __builtin_amdgcn_rsqf(fmaf(-sc, sc, 1.0f)) : 0.f;
+#else
+  const float gs = (sc == st.s) ? gphi_c * __builtin_amdgcn_rsqf(den) : 0.f;
+#endif
   float rden = __builtin_amdgcn_rcpf(den);
   rden = fmaf(fmaf(-den, rden, 1.0f), rden, rden);
   const float gl = glam_c * rden;
@@ -1468,7 +1485,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
 // sl_advect_fwd_tilerow); window accumulators, flush and the global-atomic fallback as in the generic
 // tiled kernel below.
 template <int MODE>
-__global__ void __launch_bounds__(TILED_THREADS_BWD, 4)   // two workgroups per CU: <= 128 VGPRs
+__global__ void __launch_bounds__(TILED_THREADS_BWD, 4)   // four waves per SIMD: <= 128 VGPRs
 sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ field,
                       const float* __restrict__ u, const float* __restrict__ v,
                       float* __restrict__ gfield, float* __restrict__ gu, float* __restrict__ gv,
@@ -1674,7 +1691,7 @@ constexpr size_t WHOLE_LDS_LIMIT = 64 * 1024;
 // backward holds 12 B/cell (64-bit accumulators + field), so its halo is what LDS allows at 2
 // workgroups per CU.  Taps outside the window take the L2 / global-atomic path.
 constexpr int HALO_FWD = 8;    // in-model optimum 6-12 at 128x256 and 721x1440; 24 pays only for ~45 px displacements
-constexpr int HALO_BWD = 10;   // two workgroups of 512 threads per CU
+constexpr int HALO_BWD = ADV_HALO_BWD;   // two workgroups of 512 threads per CU
 constexpr int MAX_HALO = 32;
 
 template <typename K>

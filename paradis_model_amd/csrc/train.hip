@@ -102,10 +102,21 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
 // tensors share the hyper-parameters and the step count.  (335 per-tensor launches of ~5 us are
 // launch-bound: 0.7 % of the training step.)
 constexpr int ADAMW_CHUNK = 32768;
+// dev (optional): {step count as float bits are NOT used - int32 step at [0], float lr at [1]} kept on the device so
+// that a captured HIP graph of the training step stays valid from one replay to the next (the host-side step
+// count and learning rate would be frozen into the kernel arguments): the bias corrections are then formed
+// here, in double like the host path.
 __global__ void __launch_bounds__(256)
 adamw_multi_kernel(const int64_t* __restrict__ ptrs /* [4][T]: p, g, m, v */, const int64_t* __restrict__ numel,
                    const int* __restrict__ chunk_tensor, const int64_t* __restrict__ chunk_off, int T,
-                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                   const int* __restrict__ dev) {
+  if (dev) {
+    const int step = dev[0];
+    lr = __int_as_float(dev[1]);
+    bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  }
   const int t = chunk_tensor[blockIdx.x];
   const int64_t off = chunk_off[blockIdx.x];
   const int64_t n = min((int64_t)ADAMW_CHUNK, numel[t] - off);
@@ -125,6 +136,8 @@ adamw_multi_kernel(const int64_t* __restrict__ ptrs /* [4][T]: p, g, m, v */, co
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
+
+__global__ void adamw_tick_kernel(int* __restrict__ dev) { dev[0] += 1; }
 
 inline int blocks_for(int64_t n) {
   return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 8));
@@ -174,15 +187,24 @@ extern "C" int paradis_adamw_chunk(void) { return ADAMW_CHUNK; }
 extern "C" int paradis_adamw_multi(const int64_t* ptrs, const int64_t* numel, const int* chunk_tensor,
                                    const int64_t* chunk_off, int n_tensors, int n_chunks, float lr,
                                    float beta1, float beta2, float eps, float weight_decay, int step,
-                                   void* stream) {
-  PD_REQUIRE(n_tensors >= 0 && n_chunks >= 0 && step >= 1, "adamw_multi: bad arguments");
+                                   const int* dev_state, void* stream) {
+  PD_REQUIRE(n_tensors >= 0 && n_chunks >= 0 && (step >= 1 || dev_state != nullptr), "adamw_multi: bad arguments");
   if (n_chunks == 0) return 0;
   PD_REQUIRE(ptrs && numel && chunk_tensor && chunk_off, "adamw_multi: tables missing");
-  const float bc1 = (float)(1.0 - pow((double)beta1, step));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+  const int st = step >= 1 ? step : 1;
+  const float bc1 = (float)(1.0 - pow((double)beta1, st));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, st));
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, ptrs, numel,
-                     chunk_tensor, chunk_off, n_tensors, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+                     chunk_tensor, chunk_off, n_tensors, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, dev_state);
   PD_CHECK_LAUNCH("adamw_multi");
+  return 0;
+}
+
+// dev_state[0] += 1 on the stream (the step count of a captured training step lives on the device)
+extern "C" int paradis_adamw_tick(int* dev_state, void* stream) {
+  PD_REQUIRE(dev_state != nullptr, "adamw_tick: state missing");
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev_state);
+  PD_CHECK_LAUNCH("adamw_tick");
   return 0;
 }
 

@@ -113,7 +113,8 @@ class TrainStep:
     """forward(S rollout steps) + ParadisLoss + backward + AdamW, the unit the benchmark times
     (SURVEY.md section 8d).  AdamW hyper-parameters follow reference trainer.py:327-335."""
 
-    def __init__(self, model, loss_fn, cfg, *, num_common: int = 83, n_inputs: int = 2, fused=None):
+    def __init__(self, model, loss_fn, cfg, *, num_common: int = 83, n_inputs: int = 2, fused=None,
+                 capturable: bool = False):
         self.model, self.loss_fn = model, loss_fn
         self.num_common, self.n_inputs = num_common, n_inputs
         o = cfg.training.optimizer
@@ -134,7 +135,8 @@ class TrainStep:
                            use_triton=True)
         elif on_hip and fused is None:
             from .optim import AdamW   # HIP kernel, torch.optim.AdamW semantics
-            self.opt = AdamW(params, lr=o.lr, weight_decay=o.weight_decay, betas=(o.beta1, o.beta2))
+            self.opt = AdamW(params, lr=o.lr, weight_decay=o.weight_decay, betas=(o.beta1, o.beta2),
+                             capturable=capturable)
         else:
             self.opt = torch.optim.AdamW(params, lr=o.lr, weight_decay=o.weight_decay,
                                          betas=(o.beta1, o.beta2), fused=bool(fused))
@@ -146,6 +148,52 @@ class TrainStep:
                                n_inputs=self.n_inputs, detach_every=self.detach_every)
         self.opt.step()
         return loss
+
+
+class GraphedTrainStep:
+    """The whole training step - forward (S rollout steps), ParadisLoss, backward, AdamW: ~2,500 kernel launches -
+    captured once into a HIP graph (``torch.cuda.CUDAGraph``) and replayed: the host enqueues one graph launch per
+    step instead of walking dispatcher -> autograd -> Python kernel -> ctypes for every op (23.5 ms of host time per
+    step at 32x64, the bound below ~4 samples per GPU).  Everything on the path is capture-safe: the ops launch on
+    the current stream through the C ABI without host synchronisation, workspaces come from the caching allocator
+    (the graph's private pool under capture), and the optimiser's step count and learning rate live on the device
+    (``optim.AdamW(capturable=True)``).
+
+    ``step`` must be a ``TrainStep(..., capturable=True)`` on one GPU (no DDP: its bucket hooks are not capturable),
+    ``example_batch`` fixes the shapes.  ``warmup`` eager steps run first on a side stream (they are real optimiser
+    steps: kernel attributes, optimiser state and the allocator's pools must exist before capture)."""
+
+    def __init__(self, step: TrainStep, example_batch, warmup: int = 2):
+        if not getattr(step.opt, "capturable", False):
+            raise ValueError("GraphedTrainStep needs TrainStep(..., capturable=True)")
+        self.step = step
+        self.static_batch = tuple(t.clone() for t in example_batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                step(self.static_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.warmup_steps = max(1, warmup)
+        self.graph = torch.cuda.CUDAGraph()
+        step.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.static_loss = step(self.static_batch)
+        # the capture ran the Python side of one step (host step counts advanced) without executing it on the
+        # device: bring the device-side count of the captured tick back in line on first replay
+        self._first = True
+
+    def __call__(self, batch):
+        for dst, src in zip(self.static_batch, batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if self._first:
+            self._first = False      # host counters already include this step (incremented during capture)
+        else:
+            self.step.opt.note_replayed()
+        self.graph.replay()
+        return self.static_loss
 
 
 # ---------------------------------------------------------------------------------- data parallel

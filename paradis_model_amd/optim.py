@@ -11,10 +11,45 @@ from ._lib import check, dptr, lib, require_hip, stream_ptr
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """``capturable=True``: the step count and the learning rate of every group also live on the device
+    (``paradis_adamw_multi(..., dev_state)``), so a HIP graph captured around ``step()`` stays valid from replay to
+    replay (``harness.GraphedTrainStep``); the update is the same to the last bit."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
+        self._dev_state = {}      # group index -> (int32[2] device tensor, lr it holds)
+
+    def _device_state(self, gi, group, dev, step_before):
+        """int32[2] = [step count, bits of lr] of group ``gi`` on the device (created at the group's first update)"""
+        import struct
+        ent = self._dev_state.get(gi)
+        lr_bits = struct.unpack("<i", struct.pack("<f", float(group["lr"])))[0]
+        if ent is None:
+            ent = [torch.tensor([step_before, lr_bits], dtype=torch.int32, device=dev), float(group["lr"])]
+            self._dev_state[gi] = ent
+        elif ent[1] != float(group["lr"]):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("AdamW(capturable): the learning rate changed inside a graph capture")
+            ent[0][1:2].copy_(torch.tensor([lr_bits], dtype=torch.int32), non_blocking=False)
+            ent[1] = float(group["lr"])
+        return ent[0]
+
+    def sync_device_state(self):
+        """push the host-side learning rates to the device (call between graph replays after a scheduler step)"""
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._dev_state:
+                self._device_state(gi, group, self._dev_state[gi][0].device, 0)
+
+    def note_replayed(self):
+        """a captured step() was replayed: advance the host-side step counts (state_dict compatibility)"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -39,9 +74,11 @@ class AdamW(torch.optim.Optimizer):
                 state["step"] += 1
                 steps.add(int(state["step"]))
             uniform = len(steps) == 1 and all(p.is_contiguous() and p.grad.is_contiguous() for p in params)
-            if uniform and len(params) > 1:
+            if uniform and (len(params) > 1 or self.capturable):
                 self._step_group_fused(gi, group, params, steps.pop(), st)
                 continue
+            if self.capturable:
+                raise RuntimeError("AdamW(capturable) needs contiguous parameters with one common step count per group")
             for p in params:
                 state = self.state[p]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -77,7 +114,8 @@ class AdamW(torch.optim.Optimizer):
                 chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
                 chunk_off=torch.tensor(co, dtype=torch.int64, device=dev), n_chunks=len(ct))
         T, host = c["T"], c["host"]
-        if c.get("pending") is not None:     # the previous step's async copy out of `host` (long done)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if c.get("pending") is not None and not capturing:     # the previous step's async copy out of `host` (long done)
             c["pending"].synchronize()
         moments = [(self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in params]
         for m, v in moments:
@@ -88,13 +126,20 @@ class AdamW(torch.optim.Optimizer):
                                 + [m.data_ptr() for m, _ in moments] + [v.data_ptr() for _, v in moments],
                                 dtype=torch.int64))
         c["ptrs"].copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        c["pending"] = ev
+        if capturing:
+            c["pending"] = None      # (inside a capture the copy is a graph node; nothing to wait for on the host)
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            c["pending"] = ev
         b1, b2 = group["betas"]
+        dev_state = None
+        if self.capturable:
+            dev_state = self._device_state(gi, group, dev, step - 1)
+            check(lib.paradis_adamw_tick(dptr(dev_state), st), "adamw_tick")
         check(lib.paradis_adamw_multi(dptr(c["ptrs"]), dptr(c["numel"]), dptr(c["chunk_tensor"]),
                                       dptr(c["chunk_off"]), T, c["n_chunks"], group["lr"], b1, b2, group["eps"],
-                                      group["weight_decay"], step, st), "adamw_multi")
+                                      group["weight_decay"], step, dptr(dev_state), st), "adamw_multi")
 
 
 # ---------------------------------------------------------------------------------------------

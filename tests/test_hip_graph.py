@@ -1,0 +1,83 @@
+"""GPU: the training step captured in a HIP graph (harness.GraphedTrainStep) replays to the same parameters and
+losses as the eager step - forward, ParadisLoss, backward and the AdamW update inside ONE graph launch per step
+(host time per step; reference trainer.py:498-587 is the step being captured)."""
+import pytest
+import torch
+
+from paradis_model_amd.config import reduced_config, stub_datamodule
+from tests._util import make_grid, max_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(capturable):
+    from paradis_model_amd.harness import TrainStep, synthetic_batch
+    from paradis_model_amd.loss import build_loss
+    from paradis_model_amd.model import Paradis
+    cfg = reduced_config()
+    lat_deg, lg, og = make_grid(16, 32, False)
+    torch.manual_seed(42)
+    model = Paradis(stub_datamodule(cfg), cfg, lg, og).cuda()
+    step = TrainStep(model, build_loss(cfg, lat_deg).cuda(), cfg, capturable=capturable)
+    batches = [synthetic_batch(16, 32, False, 2, 2, seed=5 + i, device="cuda") for i in range(2)]   # S = 2 rollout
+    return model, step, batches
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "exact"])
+def test_graphed_train_step_equals_eager(gemm, monkeypatch):
+    from paradis_model_amd import ops
+    from paradis_model_amd.harness import GraphedTrainStep
+    monkeypatch.setattr(ops, "GEMM_SCHEME", ops._SCHEMES[gemm])
+    n_steps, warm = 6, 2
+    # eager reference: n_steps steps over alternating batches (the first `warm` on batch 0 like the warm-up below)
+    model_e, step_e, batches = _setup(False)
+    order = [0] * warm + [i % 2 for i in range(n_steps - warm)]
+    losses_e = [float(step_e(batches[i])) for i in order]
+    # graphed: warm-up steps (eager, on batch 0) + replays
+    model_g, step_g, _ = _setup(True)
+    g = GraphedTrainStep(step_g, batches[0], warmup=warm)
+    losses_g = [float(g(batches[i])) for i in order[warm:]]
+    torch.cuda.synchronize()
+    for a, b in zip(losses_e[warm:], losses_g):
+        assert abs(a - b) <= 1e-6 * abs(a), (losses_e, losses_g)
+    pe = torch.cat([p.detach().flatten() for p in model_e.parameters()])
+    pg = torch.cat([p.detach().flatten() for p in model_g.parameters()])
+    assert max_rel(pg, pe) <= 1e-6
+    # host-side optimiser state followed the replays
+    st = step_g.opt.state[next(iter(model_g.parameters()))]
+    assert int(st["step"]) == n_steps
+    # a learning-rate change between replays reaches the captured update
+    for grp in step_g.opt.param_groups:
+        grp["lr"] = 0.0
+    step_g.opt.sync_device_state()
+    before = pg.clone()
+    wd = step_g.opt.param_groups[0]["weight_decay"]
+    g(batches[0])
+    torch.cuda.synchronize()
+    after = torch.cat([p.detach().flatten() for p in model_g.parameters()])
+    assert torch.equal(after, before) or wd == 0 or max_rel(after, before) < 1e-12   # lr = 0: no update at all
+
+
+def test_graphed_step_host_time_is_one_launch():
+    """what the graph buys: the host returns from a replay long before an eager step has been enqueued"""
+    import time
+    from paradis_model_amd.harness import GraphedTrainStep
+    model_e, step_e, batches = _setup(False)
+    for _ in range(3):
+        step_e(batches[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step_e(batches[0])
+    t_eager = (time.perf_counter() - t0) / 5          # host time to enqueue (no sync inside)
+    torch.cuda.synchronize()
+    model_g, step_g, _ = _setup(True)
+    g = GraphedTrainStep(step_g, batches[0], warmup=2)
+    g(batches[0]); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g(batches[0])
+    t_graph = (time.perf_counter() - t0) / 5
+    torch.cuda.synchronize()
+    print("host time per step: eager %.2f ms, graph replay %.2f ms" % (1e3 * t_eager, 1e3 * t_graph))
+    assert t_graph < 0.5 * t_eager

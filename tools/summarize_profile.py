@@ -14,7 +14,7 @@ import subprocess
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("PARADIS_PROFILE_DST") or os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
 
 
@@ -105,8 +105,10 @@ if path:
 
 tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
 with open(os.path.join(DST, f"{TAG}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary {TAG}\n\ncommand: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-            f"--no-kernel-events --no-exact-leg` (4 training steps traced)\n\n")
+    cmd_file = os.path.join(SRC, "command.txt")
+    cmd = open(cmd_file).read().strip() if os.path.exists(cmd_file) else "python3 bench.py (default)"
+    f.write(f"# rocprofv3 summary {TAG}\n\ncommand: `{cmd}` (warm-up + timed steps traced; "
+            f"library sha256 {str(META.get('library_sha256'))[:16]}, commit {META.get('commit')})\n\n")
     f.write("| kernel | calls | total ms | avg us | % | HBM MB/launch (PMC, corrected) | MFMA busy (PMC) | clock GHz (PMC pass) |\n"
             "|---|---|---|---|---|---|---|---|\n")
     for r in rows[:30]:
