@@ -1876,7 +1876,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   const int mean_blocks = (planes * 2 * 64 + 255) / 256;
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, field, fmeans, planes, K, H, W, f_bs);
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, gout, gmeans, planes, K, H, W, go_bs);
-  if (hipMemsetAsync(gfield, 0, (size_t)planes * P * sizeof(float), st) != hipSuccess) {
+  if (pd_zero_async(gfield, (size_t)planes * P * sizeof(float), st) != hipSuccess) {
     paradis_set_error("sl_advect_bwd: memset failed");
     return 2;
   }

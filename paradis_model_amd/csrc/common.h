@@ -111,6 +111,21 @@ __device__ __forceinline__ uint32_t wave_umax_lane63(uint32_t v) {
 #undef PD_DPP_MAX
   return v;
 }
+// Zero-fill by a KERNEL, not hipMemsetAsync: inside a captured HIP graph (harness.GraphedTrainStep) the memset
+// nodes of ROCm 7.0 were observed to run out of order with their neighbouring kernel nodes when a replay starts on
+// an idle device (NaN bias gradients: the atomics that accumulate into the buffer ran against stale contents);
+// kernel nodes keep the stream order.
+static __global__ void __launch_bounds__(256) pd_zero_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline hipError_t pd_zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  const size_t n = (bytes + 3) / 4;       // every buffer zeroed here is a float / uint32 array
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pd_zero_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

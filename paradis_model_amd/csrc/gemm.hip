@@ -960,11 +960,11 @@ pw_gemm_split_kernel(GemmArgs g) {
 // 4.1c): 24 KiB per two 128 x 128 x 16 tiles here instead of 32.  48 KiB of LDS, <= 128 VGPRs: two workgroups =
 // 16 waves per CU.  An odd last n-tile leaves sub 1 without work: it runs along on the clamped last tile and
 // skips the epilogue.
-template <int NSUB>
+template <int NSUB, int NP = 2>
 __global__ void __launch_bounds__(256 * NSUB, 4)      // (second argument: waves per SIMD)
 pw_gemm_split_wide_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NP = 2, SIMG = simg(NP), SA = 2, DA = SA - 1;
+  constexpr int SIMG = simg(NP), SA = 2, DA = SA - 1;
   u32x4* img = reinterpret_cast<u32x4*>(lds);        // [NSUB][2 activation stages][SIMG] | [SA weight stages][SIMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = __builtin_amdgcn_readfirstlane(wave >> 2), lw = wave & 3, ltid = tid & 255;
@@ -984,8 +984,10 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   const int m0 = mt * BM, n0 = nt * BN;
   const int T = (g.K + SBK - 1) / SBK;
 
-  // one 16-byte chunk of the 512-chunk weight tile per thread (of the first 512)
+  // the weight tile (SIMG = 256 NP chunks of 16 bytes) goes by LDS-DMA, one chunk per thread and piece: f16x2 one
+  // piece of 512 chunks (the first 512 threads), bf16x3 a piece of 512 and a piece of 256 (waves 0-3)
   const bool doA = NSUB == 2 || wave < 8;            // wave-uniform
+  const bool doA2 = NP == 3 && wave < 4;             // wave-uniform: second piece
   const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + (tid & 511);
   const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
   const float* Bb;
@@ -996,8 +998,8 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   }
   const int bn = min(n0 + (ltid & 127), g.N - 1);
 
-  float sc_b, inv_a, inv_b;
-  {
+  float sc_b = 1.f, inv_a = 1.f, inv_b = 1.f;
+  if constexpr (NP == 2) {
     float sc_a;
     __shared__ uint32_t red[4 * NSUB];
     const uint32_t* pp = g.b_amax;
@@ -1016,11 +1018,19 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   auto issueA = [&](int t) __attribute__((always_inline)) {
     if (doA)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * SIMG), (lds_ptr_t)(img + (2 * NSUB + t % SA) * SIMG + wave * 64), 16, 0, 0);
+    if (doA2)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * SIMG + 512), (lds_ptr_t)(img + (2 * NSUB + t % SA) * SIMG + 512 + wave * 64), 16, 0, 0);
   };
   auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
-    u32x4 h, l;
-    split8_f16(x, sc_b, h, l);
-    o[0] = h; o[2 * SCH] = l;
+    if constexpr (NP == 3) {
+      u32x4 h, m, l;
+      split8(x, h, m, l);
+      o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+    } else {
+      u32x4 h, l;
+      split8_f16(x, sc_b, h, l);
+      o[0] = h; o[2 * SCH] = l;
+    }
   };
   // inline-asm loads with hand-counted waits: see pw_gemm_split_kernel
   const uint32_t boff = (uint32_t)bn * 4u;
@@ -1059,8 +1069,9 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
     const bool dmaA = t + DA < T, ldB = t + 2 < T;
     if (dmaA) issueA(t + DA);
     if (ldB) fetchB(t + 2, xload);
-    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's DMA and 8 loads
-    if (dmaA && ldB && doA) USE_X(xsplit, 9);
+    // xsplit (tile t+1) was loaded a step ago; younger operations: this step's DMA piece(s) and 8 loads
+    if (dmaA && ldB && doA2) USE_X(xsplit, 10);
+    else if (dmaA && ldB && doA) USE_X(xsplit, 9);
     else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
     SplitFrags<NP> f;
@@ -1069,9 +1080,9 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
     split_store(xsplit, Bst + (cur ^ 1) * SIMG);
     __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 3 : 2, 0);
     }
     // weight tile t+1 landed (8 loads of this step are younger), own ds_writes done, the loads of t+2 in flight
     if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1083,7 +1094,7 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   }
 #undef USE_X
   if (live) {
-    split_unscale(acc, inv_a, inv_b);
+    if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
     gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
   }
 }
@@ -1346,27 +1357,41 @@ int launch_split_np(const GemmArgs& d, hipStream_t st) {
   hipLaunchKernelGGL(pw_gemm_split_kernel<NP>, dim3(grid), dim3(256), split_lds(NP), st, d);
   return 0;
 }
-constexpr size_t split_wide_lds(int nsub) { return (size_t)(2 * nsub + 2) * simg(2) * 16; }   // 48 / 80 KiB
+constexpr size_t split_wide_lds(int nsub, int np = 2) { return (size_t)(2 * nsub + 2) * simg(np) * 16; }   // f16x2: 48 KiB, bf16x3: 72 KiB
 // n-tiles per workgroup: 2 (two 8-wave workgroups per CU).  4 - one 16-wave workgroup per CU, another 17 % fewer
 // bytes - measured 2.5 % SLOWER: a single workgroup's waves all stop at the same barriers.
 constexpr int SPLIT_WIDE_NSUB = 2;
 // scheme: PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 (the latter with d.a_amax / d.b_amax set)
-int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
-  if (scheme != PARADIS_GEMM_F16X2) return launch_split_np<3>(d, st);
-  const int NT = (d.N + BN - 1) / BN;
-  if (NT < 2) return launch_split_np<2>(d, st);
+// bf16x3 on the 128 x 256 tile: its three-plane fragments and split temporaries need ~150 registers; at the 128 that
+// two 8-wave workgroups per CU allow, hipcc spills 1.2 KB per lane (round 3).  Kept behind a build flag for A/B only.
+#ifndef SPLIT_WIDE_BF16X3
+#define SPLIT_WIDE_BF16X3 0
+#endif
+template <int NP>
+int launch_split_wide(const GemmArgs& d, int NT, hipStream_t st) {
   constexpr int NSUB = SPLIT_WIDE_NSUB;
   static PerDeviceOnce once;
-  if (split_wide_lds(NSUB) > 64 * 1024 && once.first()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_wide_kernel<NSUB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_wide_lds(NSUB)) != hipSuccess) {
+  if (split_wide_lds(NSUB, NP) > 64 * 1024 && once.first()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_split_wide_kernel<NSUB, NP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_wide_lds(NSUB, NP)) != hipSuccess) {
       paradis_set_error("pw_gemm(split): cannot reserve LDS");
       return 2;
     }
   }
   const int grid = ((d.M + BM - 1) / BM) * ((NT + NSUB - 1) / NSUB) * d.nbatch;     // 128 x (128 NSUB) tiles
-  hipLaunchKernelGGL(pw_gemm_split_wide_kernel<NSUB>, dim3(grid), dim3(256 * NSUB), split_wide_lds(NSUB), st, d);
+  hipLaunchKernelGGL((pw_gemm_split_wide_kernel<NSUB, NP>), dim3(grid), dim3(256 * NSUB), split_wide_lds(NSUB, NP), st, d);
   return 0;
+}
+int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
+  const int NT = (d.N + BN - 1) / BN;
+  if (scheme != PARADIS_GEMM_F16X2) {
+#if SPLIT_WIDE_BF16X3
+    if (NT >= 2) return launch_split_wide<3>(d, NT, st);
+#endif
+    return launch_split_np<3>(d, st);
+  }
+  if (NT < 2) return launch_split_np<2>(d, st);
+  return launch_split_wide<2>(d, NT, st);
 }
 
 int check_gemm(const char* name, int B, int M, int K, int N) {
@@ -1586,8 +1611,8 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
              "pw_gemm_wgrad: the f16x2 scheme needs dy_amax and x_amax");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    if (hipMemsetAsync(dW, 0, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
-    if (gbias && hipMemsetAsync(gbias, 0, (size_t)M * sizeof(float), st) != hipSuccess) return 2;
+    if (pd_zero_async(dW, (size_t)M * K * sizeof(float), st) != hipSuccess) return 2;
+    if (gbias && pd_zero_async(gbias, (size_t)M * sizeof(float), st) != hipSuccess) return 2;
     return 0;
   }
   // a split scheme: both operands are split in registers (same layout requirements as the LDS-DMA kernel)

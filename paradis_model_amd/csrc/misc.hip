@@ -312,7 +312,7 @@ extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, co
     hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
     // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
     if (Cin <= 16) {
-      if (hipMemsetAsync(gm8, 0, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
+      if (pd_zero_async(gm8, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
       const int och = paradis_deterministic() ? Co : 32;   // one chunk: a single add per element, fixed order
       hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och),
                          dim3(256), 0, st, Pw, gmap, gm8, Cin, Co, P, och);
@@ -398,7 +398,7 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
                                   int64_t dz_bs, void* stream) {
   PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "bias_grads: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  if (gbias && hipMemsetAsync(gbias, 0, (size_t)C * sizeof(float), st) != hipSuccess) {
+  if (gbias && pd_zero_async(gbias, (size_t)C * sizeof(float), st) != hipSuccess) {
     paradis_set_error("bias_grads: memset failed");
     return 2;
   }
@@ -451,7 +451,7 @@ extern "C" int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, 
   PD_REQUIRE(Cin >= 1 && Cin <= 16 && Co >= 1 && P >= 1, "global_bias_proj_bwd: bad shape (Cin <= 16)");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
-  if (hipMemsetAsync(gm8, 0, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
+  if (pd_zero_async(gm8, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
   const int och = paradis_deterministic() ? Co : 32;
   hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och), dim3(256),
                      0, st, Pw, gmap, gm8, Cin, Co, P, och);

@@ -193,7 +193,7 @@ extern "C" int paradis_muon_step(const int64_t* ptrs, int table_stride, int T, i
   // split != 0: the three products of every iteration run on the bf16-split GEMM (gemm.hip); the images
   // of their left operands ([M,K] or [M,M], K >= M) live behind the float workspace
   void* img = split ? (void*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
-  if (hipMemsetAsync(sc, 0, 3 * (size_t)T * sizeof(float), st) != hipSuccess) {
+  if (pd_zero_async(sc, 3 * (size_t)T * sizeof(float), st) != hipSuccess) {
     paradis_set_error("muon_step: memset failed");
     return 2;
   }

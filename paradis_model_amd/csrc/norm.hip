@@ -480,8 +480,8 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   const int C = C1 + C2;
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) {
-    if (hipMemsetAsync(gw, 0, C * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(gb, 0, C * sizeof(float), st) != hipSuccess) {
+    if (pd_zero_async(gw, C * sizeof(float), st) != hipSuccess ||
+        pd_zero_async(gb, C * sizeof(float), st) != hipSuccess) {
       paradis_set_error("channel_norm_bwd: memset failed");
       return 2;
     }

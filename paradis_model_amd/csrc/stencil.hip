@@ -497,7 +497,7 @@ extern "C" int paradis_upsample_lonp_bwd(const float* gy, float* gx, int64_t pla
                                          int H, int W, void* stream) {
   PD_REQUIRE(planes >= 0 && Hc >= 1 && Wc >= 1 && H >= Hc && W >= Wc, "upsample_lonp_bwd: bad shape");
   if (planes == 0) return 0;
-  if (hipMemsetAsync(gx, 0, (size_t)planes * Hc * Wc * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+  if (pd_zero_async(gx, (size_t)planes * Hc * Wc * sizeof(float), (hipStream_t)stream) != hipSuccess) {
     paradis_set_error("upsample_lonp_bwd: memset failed");
     return 2;
   }
