@@ -630,8 +630,20 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
   }
 }
 
+// Scalar-register cap of the forward kernel.  The compiler's own choice (106 SGPRs: row pointers, table values and the
+// constants of five code paths) admits 6 workgroups per CU (800 SGPRs per SIMD / (112 + 16)); at <= 80 the
+// hardware admits 8, which is also what the 59 VGPRs and the 19.9 KB of LDS allow.  27 values then live in VGPR
+// lanes (v_readlane / v_writelane around the rare paths): 178 -> 173 us per launch, same box (round 3).
+#ifndef ADV_FWD_SGPRS      // (0 = the compiler's choice)
+#define ADV_FWD_SGPRS 80
+#endif
+#if ADV_FWD_SGPRS
+#define ADV_FWD_SGPR_ATTR __attribute__((amdgpu_num_sgpr(ADV_FWD_SGPRS)))
+#else
+#define ADV_FWD_SGPR_ATTR
+#endif
 template <int MODE, int XR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) ADV_FWD_SGPR_ATTR
 sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u,
                     const float* __restrict__ v, float* __restrict__ out,
                     const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
