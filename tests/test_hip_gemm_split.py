@@ -3,7 +3,7 @@ the exact f32-MFMA kernels and an fp64 evaluation of the same product.
 
 Claim under test (include/paradis_hip.h, a6): the split paths are fp32 GEMMs, not reduced-precision ones:
 their error against fp64 is not above the exact f32 chain's.  Bounds written here, for "bf16x3" (exact
-three-term decomposition) and for "f16x2" (two f16 terms of the per-tensor scaled operands, the default):
+three-term decomposition, the default) and for "f16x2" (two f16 terms of the per-tensor scaled operands, opt-in):
   * max |split - fp64| / max |fp64|  <=  1.25 x the same figure of the exact kernel + 1e-7, and
   * <= 2e-6 absolutely (an fp32 dot product of length <= 1024 with |x|,|w| ~ 1 sits at ~3e-7).
 What f16x2 gives up - relative accuracy of elements far below their TENSOR's largest magnitude - and its

@@ -22,7 +22,7 @@ def _build(cfg, lg, og, state=None):
                                                      ("c", True)])
 @pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "exact"])
 def test_reduced_model_vs_reference_golden(variant, fuse_projection, gemm, monkeypatch):
-    """Same tolerances for the three GEMM arithmetics (f16x2 = default, bf16x3, exact f32 MFMA)."""
+    """Same tolerances for the three GEMM arithmetics (bf16x3 = default, exact f32 MFMA, opt-in f16x2)."""
     from paradis_model_amd import ops
     from paradis_model_amd.loss import build_loss
     from paradis_model_amd.model import blocks

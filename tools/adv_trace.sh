@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/adv_trace.sh <variant names...>  -> median kernel duration of the W=64 forward advection kernel per
 # build/variants/lib_<name>.so (rocprofv3 --kernel-trace; run on the GPU box from the repo root)
-R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp; export TMPDIR=/tmp
 for n in "$@"; do
   for sc in 0.05; do
     rm -rf /tmp/tr_$n; PARADIS_HIP_LIB=$R/build/variants/lib_$n.so rocprofv3 --kernel-trace -d /tmp/tr_$n -o out --output-format csv -- python3 $R/tools/adv_fwd_only.py $sc > /dev/null 2>&1

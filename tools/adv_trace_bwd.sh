@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/adv_trace_bwd.sh <variant names...>  -> median duration of the W=64 backward advection kernel per
 # build/variants/lib_<name>.so (rocprofv3 --kernel-trace; GPU box, repo root)
-R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp; export TMPDIR=/tmp
 for n in "$@"; do
   rm -rf /tmp/trb_$n; PARADIS_HIP_LIB=$R/build/variants/lib_$n.so rocprofv3 --kernel-trace -d /tmp/trb_$n -o out --output-format csv -- python3 $R/tools/adv_bwd_only.py 0.05 > /dev/null 2>&1
   python3 - <<PY

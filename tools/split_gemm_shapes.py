@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: the split forward / data-gradient / weight-gradient GEMMs on every (Co, Ci) of the default layer
 at B=32, P=2048 with the shipped library: TF/s (fp32-equivalent) and error against fp64.
-    python tools/split_gemm_shapes.py [f16x2|bf16x3]      (default f16x2; amax passes timed separately)
+    python tools/split_gemm_shapes.py [f16x2|bf16x3]      (default f16x2 = the scheme this tool was written for; amax passes timed separately)
   PARADIS_HIP_LIB
 selects another build of the same ABI for an A/B (round 2: a warp-specialised 128x256 kernel - four
 MFMA-only waves, four loader/splitter waves, four LDS stages - measured 178 TF where this one does 200)."""
