@@ -50,14 +50,24 @@ def _library_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
+# suffix of the profile tags of each workload (tools/profile_round.sh <tag> [bench args]): profiles/r03b_* is the
+# default workload, profiles/r03a_cfg3_* the 128x256 one ...
+PROFILE_SUFFIX = {"era5_5.625deg_32x64_S1_B32": "", "era5_5.625deg_32x64_S6_B32": "_cfg2",
+                  "era5_1.4deg_128x256_S1_B8": "_cfg3", "era5_0.25deg_721x1440_fwd_B1": "_cfg4"}
+WORKLOAD = "era5_5.625deg_32x64_S1_B32"     # set by main()
+
+
 def _profile(kind: str):
-    """Newest committed PMC summary of `kind` (profiles/<tag>_<kind>.json, written by
-    tools/profile_round.sh + tools/summarize_profile.py for this same bench command under rocprofv3
-    --pmc) with its provenance: the summary records the sha256 of the library it profiled; a summary of
-    another build is still reported but marked, and one whose kernels no longer exist in the loaded
-    library is dropped.  Returns (data, source) or (None, None)."""
+    """Newest committed PMC summary of `kind` FOR THE WORKLOAD BEING RUN (profiles/<tag>[_cfgN]_<kind>.json, written by
+    tools/profile_round.sh + tools/summarize_profile.py for this same bench command under rocprofv3 --pmc) with its
+    provenance: the summary records the sha256 of the library it profiled; a summary of another build is still
+    reported but marked, and one whose kernels no longer exist in the loaded library is dropped.
+    Returns (data, source) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}.json")), key=os.path.getmtime)
+    import re
+    pat = re.compile(r"^r\d+[a-z]*%s_%s\.json$" % (re.escape(PROFILE_SUFFIX.get(WORKLOAD, "_none")), re.escape(kind)))
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}.json"))
+                    if pat.match(os.path.basename(f))), key=lambda f: (os.path.basename(f).split("_")[0], os.path.getmtime(f)))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -225,6 +235,8 @@ def main():
         if len(set(ids)) != world:
             raise SystemExit(f"ranks share a device: {ids}")
 
+    global WORKLOAD
+    WORKLOAD = args.workload
     nlat, nlon, poles, B, S = WORKLOADS[args.workload]
     if "_fwd_" in args.workload:
         args.forward_only = True   # 0.25 deg is an inference configuration (BASELINE configs[4])
@@ -316,12 +328,22 @@ def main():
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 gstep(batch)
-            host = time.perf_counter() - t1
             torch.cuda.synchronize()
             e = time.perf_counter() - t1
+            # host time of ONE step issued into an idle queue (a loop of launches measures the queue's back-pressure,
+            # not the host): the captured replay against the eager step
+            t2 = time.perf_counter()
+            gstep(batch)
+            host_graph = time.perf_counter() - t2
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            step(batch)
+            host_eager = time.perf_counter() - t2
+            torch.cuda.synchronize()
             legs["hip_graph_replay"] = {"value": B * args.steps / e, "unit": "samples/s",
                                         "ms_per_step": 1e3 * e / args.steps,
-                                        "host_ms_per_step": 1e3 * host / args.steps,
+                                        "host_ms_one_replay": 1e3 * host_graph,
+                                        "host_ms_one_eager_step": 1e3 * host_eager,
                                         "gemm_arithmetic": args.gemm,
                                         "what": "forward + ParadisLoss + backward + AdamW captured once "
                                                 "(harness.GraphedTrainStep), one graph launch per step"}

@@ -1094,6 +1094,9 @@ __device__ __forceinline__ void scatter_gather(unsigned long long* acc, const fl
 #ifndef ADV_BWD_SCATTER
 #define ADV_BWD_SCATTER 0
 #endif
+#ifndef ADV_ABLATE          // (timing-only ablation builds, results wrong by construction: 1 no atomics, 2 no gather reads,
+#define ADV_ABLATE 0        //  3 no coordinate-gradient chain)
+#endif
 constexpr int ROW64_ACC_BITS = ADV_BWD_SCATTER >= 3 ? 34 : 40;
 // VAR 0: 16 ds_add_u64 in tap order.
 // VAR 1: odd lanes take the x taps in the order 2,3,0,1: at small displacements the integer tap origin of
@@ -1130,8 +1133,18 @@ __device__ __forceinline__ void scatter_gather_row64(unsigned long long* acc, in
     const double gwy = (double)(gs_ * wy[a]);
 #pragma unroll
     for (int bb = 0; bb < NT; ++bb) {
+#if ADV_ABLATE == 2
+      const float val = 1.0f;
+#else
       const float val = win[base + a * WW + bb];
+#endif
       const int off = a * WW + bb;
+#if ADV_ABLATE == 1
+      if (gs_ == 123456.f) atomicAdd(acc + base + off, 1ull);   // (never true: keeps the operands alive)
+      sxv = fmaf(val, wx[bb], sxv);
+      sdx = fmaf(val, dwx[bb], sdx);
+      continue;
+#endif
       if constexpr (VAR >= 3) {
         const double d = fma(gwy, wxd[bb], 6755399441055744.0);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
@@ -1267,7 +1280,11 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
         scatter_gather_row64<MODE, ADV_BWD_SCATTER>(acc, wn2, win, base, Wp, wx, wy, dwx, dwy, gval * scale, lane, gix,
                                                     giy);
         float guv, gvv;
+#if ADV_ABLATE == 3
+        guv = gix * gval; gvv = giy * gval;
+#else
         departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
+#endif
         srow(GU + y * W)[lane] = guv;
         srow(GV + y * W)[lane] = gvv;
       }

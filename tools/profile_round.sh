@@ -8,6 +8,8 @@
 # The program after `--` is python3 itself (no env / bash hop: the profiler's library initialises the GPU first).
 TAG=${1:-r03}; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
+# the GPU box has no .git: `git rev-parse --short HEAD > .build_commit` before the gpurun call records the commit
+export PARADIS_COMMIT=${PARADIS_COMMIT:-$(cat $R/.build_commit 2>/dev/null)}
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-extra-legs $*"
 mkdir -p $R/gpurun_out/prof_$TAG
 echo "python3 bench.py $ARGS" > $R/gpurun_out/prof_$TAG/command.txt
