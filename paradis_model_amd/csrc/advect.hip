@@ -1008,15 +1008,14 @@ __device__ __forceinline__ unsigned long long fixed_from_float(float x) {
 
 // mx = max |cotangent| of the tile, NaN if any cotangent is NaN (the reduction runs on the bit
 // patterns of |g|: as unsigned integers they order like the floats, and every NaN sorts above +inf)
-template <int BITS = 40>
 __device__ __forceinline__ void fixed_point_scale(float mx, float& scale, float& inv) {
   scale = 0.f; inv = 0.f;
   if (mx > 0.f && mx < INFINITY) {
     int e = 0;
     frexpf(mx, &e);                       // mx < 2^e
     e = e < -80 ? -80 : (e > 80 ? 80 : e);
-    scale = ldexpf(1.0f, BITS - e);
-    inv = ldexpf(1.0f, e - BITS);
+    scale = ldexpf(1.0f, 40 - e);
+    inv = ldexpf(1.0f, e - 40);
   } else if (!(mx < INFINITY)) {
     inv = NAN;                            // Inf or NaN cotangent: the field gradient is NaN, like float adds would give
   }
@@ -1090,86 +1089,6 @@ __device__ __forceinline__ void scatter_gather(unsigned long long* acc, const fl
   }
 }
 
-// ---- scatter variants of the one-wave-per-row kernel (diagnostic A/B: -DADV_BWD_SCATTER=n) -----------------
-#ifndef ADV_BWD_SCATTER
-#define ADV_BWD_SCATTER 0
-#endif
-#ifndef ADV_ABLATE          // (timing-only ablation builds, results wrong by construction: 1 no atomics, 2 no gather reads,
-#define ADV_ABLATE 0        //  3 no coordinate-gradient chain)
-#endif
-constexpr int ROW64_ACC_BITS = ADV_BWD_SCATTER >= 3 ? 34 : 40;
-// VAR 0: 16 ds_add_u64 in tap order.
-// VAR 1: odd lanes take the x taps in the order 2,3,0,1: at small displacements the integer tap origin of
-//        neighbouring lanes jitters between x and x-1, so two adjacent lanes meet in one cell of the same
-//        instruction at every second boundary (same-address serialisation); rotated, they are two columns apart.
-// VAR 2: even and odd lanes in separate (exec-masked) instructions.
-// VAR 3: every value as a 32-bit pair n = hi 2^16 + lo (lo in [0, 2^16)) added by two ds_add_u32 into two planes
-//        of 32-bit accumulators (the 64-bit integer add is 3-5x the LDS time of a 32-bit one); |n| < 2^34, at most
-//        2048 contributions per cell: |sum hi| < 2^29, sum lo < 2^27.
-// VAR 4: 3 + 1.
-template <int MODE, int VAR>
-__device__ __forceinline__ void scatter_gather_row64(unsigned long long* acc, int lo_off, const float* win, int base,
-                                                     int WW, const float* wx, const float* wy, const float* dwx,
-                                                     const float* dwy, float gs_, unsigned lane, float& gix, float& giy) {
-  constexpr int NT = Interp<MODE>::NT, ROT = NT / 2;
-  gix = 0.f; giy = 0.f;
-  const bool odd = (lane & 1u) != 0;
-  constexpr bool rotate = VAR == 1 || VAR == 4;
-  double wxd[NT];
-#pragma unroll
-  for (int bb = 0; bb < NT; ++bb) {
-    const float w = rotate ? (odd ? wx[(bb + ROT) % NT] : wx[bb]) : wx[bb];
-    wxd[bb] = (double)w;
-  }
-  // rotated: taps [0, ROT) of an odd lane sit ROT columns further right, taps [ROT, NT) ROT columns further left
-  const int sh = (rotate && odd) ? ROT : 0;
-  unsigned long long* accA = acc + base + sh;
-  unsigned long long* accB = acc + base - sh;
-  unsigned* hiA = reinterpret_cast<unsigned*>(acc) + base + sh;
-  unsigned* hiB = reinterpret_cast<unsigned*>(acc) + base - sh;
-#pragma unroll
-  for (int a = 0; a < NT; ++a) {
-    float sxv = 0.f, sdx = 0.f;
-    const double gwy = (double)(gs_ * wy[a]);
-#pragma unroll
-    for (int bb = 0; bb < NT; ++bb) {
-#if ADV_ABLATE == 2
-      const float val = 1.0f;
-#else
-      const float val = win[base + a * WW + bb];
-#endif
-      const int off = a * WW + bb;
-#if ADV_ABLATE == 1
-      if (gs_ == 123456.f) atomicAdd(acc + base + off, 1ull);   // (never true: keeps the operands alive)
-      sxv = fmaf(val, wx[bb], sxv);
-      sdx = fmaf(val, dwx[bb], sdx);
-      continue;
-#endif
-      if constexpr (VAR >= 3) {
-        const double d = fma(gwy, wxd[bb], 6755399441055744.0);
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
-        const unsigned w0 = (unsigned)bits, w1 = (unsigned)(bits >> 32);
-        unsigned* h = (bb < ROT ? hiA : hiB) + off;
-        atomicAdd(h, __builtin_amdgcn_alignbit(w1, w0, 16));   // bits 16..47 of n: floor(n / 2^16) as int32
-        atomicAdd(h + lo_off, w0 & 0xffffu);
-      } else {
-        const unsigned long long v = fixed_from_product(gwy, wxd[bb]);
-        unsigned long long* q = (bb < ROT ? accA : accB) + off;
-        if constexpr (VAR == 2) {
-          if (!odd) atomicAdd(q, v);
-          if (odd) atomicAdd(q, v);
-        } else {
-          atomicAdd(q, v);
-        }
-      }
-      sxv = fmaf(val, wx[bb], sxv);
-      sdx = fmaf(val, dwx[bb], sdx);
-    }
-    gix = fmaf(wy[a], sdx, gix);
-    giy = fmaf(dwy[a], sxv, giy);
-  }
-}
-
 // workgroup maximum of the |cotangent| bit patterns; contains a barrier
 __device__ __forceinline__ float reduce_gmax(unsigned gmaxb, float* misc, int nwaves) {
 #pragma unroll
@@ -1228,7 +1147,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
     Window w{0, 0, Hp, Wp};
     stage_window(win, F, w, H, W, p, false, 0.f, 0.f, 256);
   }
-  for (int i = tid; i < wn2; i += 256) acc[i] = 0ull;     // (wn2 64-bit cells = both 32-bit planes of the u32 variants)
+  for (int i = tid; i < wn; i += 256) acc[i] = 0ull;
   unsigned gmaxb = 0;
   for (int y = wave; y < H; y += 4) {
     const float gval = srow(GO + y * W)[lane];
@@ -1243,7 +1162,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
   __syncthreads();
   const float gm0 = misc[0], gm1 = misc[1];
   float scale, inv_scale;   // every thread derives the same power-of-two scale
-  fixed_point_scale<ROW64_ACC_BITS>(mxall, scale, inv_scale);
+  fixed_point_scale(mxall, scale, inv_scale);
 
   const float Hpf = (float)Hp, Wpf = (float)Wp;
   for (int y0 = wave; y0 < H; y0 += 4 * ADV_PF) {
@@ -1277,14 +1196,9 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
         }
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
         float gix, giy;
-        scatter_gather_row64<MODE, ADV_BWD_SCATTER>(acc, wn2, win, base, Wp, wx, wy, dwx, dwy, gval * scale, lane, gix,
-                                                    giy);
+        scatter_gather<MODE>(acc, win, base, Wp, wx, wy, dwx, dwy, gval * scale, gix, giy);
         float guv, gvv;
-#if ADV_ABLATE == 3
-        guv = gix * gval; gvv = giy * gval;
-#else
         departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
-#endif
         srow(GU + y * W)[lane] = guv;
         srow(GV + y * W)[lane] = gvv;
       }
@@ -1302,35 +1216,17 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
     int mr = -1;                                 // padded row of the over-the-pole alias (wave-uniform)
     if (y >= 1 && y <= p) mr = p - y;
     else if (y >= H - 1 - p && y <= H - 2) mr = 2 * (H - 1) - y + p;
-    float val;
-    if constexpr (ADV_BWD_SCATTER >= 3) {
-      const unsigned* hrow = reinterpret_cast<const unsigned*>(acc) + (y + p) * Wp + p;
-      const unsigned* lrow = hrow + wn2;
-      int sh = (int)hrow[lane];
-      unsigned sl = lrow[lane];
-      if (lo_edge) { sh += (int)hrow[lane + W]; sl += lrow[lane + W]; }
-      if (hi_edge) { sh += (int)hrow[lane - W]; sl += lrow[lane - W]; }
-      if (mr >= 0) {
-        const unsigned* mh = reinterpret_cast<const unsigned*>(acc) + mr * Wp + p;
-        const unsigned* ml = mh + wn2;
-        sh += (int)mh[xm]; sl += ml[xm];
-        if (mlo) { sh += (int)mh[xm + W]; sl += ml[xm + W]; }
-        if (mhi) { sh += (int)mh[xm - W]; sl += ml[xm - W]; }
-      }
-      val = (float)(fma((double)sh, 65536.0, (double)sl) * inv);
-    } else {
-      const unsigned long long* row = acc + (y + p) * Wp + p;
-      long long s = (long long)row[lane];
-      if (lo_edge) s += (long long)row[lane + W];
-      if (hi_edge) s += (long long)row[lane - W];
-      if (mr >= 0) {
-        const unsigned long long* mrow = acc + mr * Wp + p;
-        s += (long long)mrow[xm];
-        if (mlo) s += (long long)mrow[xm + W];
-        if (mhi) s += (long long)mrow[xm - W];
-      }
-      val = (float)((double)s * inv);
+    const unsigned long long* row = acc + (y + p) * Wp + p;
+    long long s = (long long)row[lane];
+    if (lo_edge) s += (long long)row[lane + W];
+    if (hi_edge) s += (long long)row[lane - W];
+    if (mr >= 0) {
+      const unsigned long long* mrow = acc + mr * Wp + p;
+      s += (long long)mrow[xm];
+      if (mlo) s += (long long)mrow[xm + W];
+      if (mhi) s += (long long)mrow[xm - W];
     }
+    float val = (float)((double)s * inv);
     if (y == 0 || y == H - 1) val = wave_sum(val) * (1.0f / 64.0f);
     srow(GF + y * W)[lane] = val;
   }
