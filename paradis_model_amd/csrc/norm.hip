@@ -375,6 +375,120 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
   }
 }
 
+// ---- backward as two STREAMING kernels (round 3) ------------------------------------------------------------
+// The fused kernels above move 128-byte row segments (32 pixels x 4 B per channel row) because a workgroup must see
+// all C channels of its pixels: 3.4 TB/s forward, and the backward's second read of (gy, x) misses the caches in the
+// training step (256 KiB per workgroup x 1024 resident workgroups).  Split by WHAT IS REDUCED instead:
+//   stats : m1[b,p] = sum_c gy w / C,  m2[b,p] = sum_c gy w xhat / (C-1): lanes along the pixel axis (256-byte row
+//           segments per wave), the four waves of a workgroup take channels g, g+4, ...; reads gy and x once;
+//   apply : gx = rstd (gy w - m1 - xhat m2) (+ addend), one workgroup per (sample, channel) row, 16-byte accesses,
+//           and - the row being one channel - the parameter-gradient sums of that row fall out of the same pass.
+// Same HBM bytes as the reread kernel (gy and x twice), all of them at streaming efficiency; deterministic.
+constexpr int NSTAT_PX = 64, NSTAT_G = 4, NSTAT_U = 8;
+__global__ void __launch_bounds__(NSTAT_PX * NSTAT_G)
+channel_norm_bwd_stats_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
+                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                              float* __restrict__ m1_out, float* __restrict__ m2_out, int P, int tiles) {
+  __shared__ float red[2][NSTAT_G][NSTAT_PX];
+  const int C = s.C1 + s.C2;
+  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NSTAT_PX;
+  const int lane = threadIdx.x & 63;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = min(p0 + lane, P - 1);          // clamped loads, predicated store
+  const float mean = mean_in[(int64_t)b * P + p], rstd = rstd_in[(int64_t)b * P + p];
+  const float* gyb = gy + (int64_t)b * C * P + p;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c0 = grp; c0 < C; c0 += NSTAT_G * NSTAT_U) {
+    float gv[NSTAT_U], xv[NSTAT_U], wv[NSTAT_U];
+#pragma unroll
+    for (int j = 0; j < NSTAT_U; ++j) {
+      const int c = min(c0 + NSTAT_G * j, C - 1);            // wave-uniform
+      gv[j] = gyb[(int64_t)c * P];
+      xv[j] = s.row(b, c, P)[p];
+      wv[j] = c0 + NSTAT_G * j < C ? w[c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NSTAT_U; ++j) {
+      const float gh = gv[j] * wv[j];
+      s1 += gh;
+      s2 += gh * ((xv[j] - mean) * rstd);
+    }
+  }
+  red[0][grp][lane] = s1;
+  red[1][grp][lane] = s2;
+  __syncthreads();
+  if (grp < 2 && p0 + lane < P) {
+    const float t = (red[grp][0][lane] + red[grp][1][lane]) + (red[grp][2][lane] + red[grp][3][lane]);
+    if (grp == 0) m1_out[(int64_t)b * P + p] = t / (float)C;
+    else m2_out[(int64_t)b * P + p] = t / (float)(C - 1);
+  }
+}
+
+// one workgroup per (b, c, chunk of `span` pixels); partial[(b * chunks + chunk)][2][C] = this chunk's sums of
+// gy xhat and of gy for channel c (reduced by channel_norm_bwd_fused_finish / finish2 in a fixed order)
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+channel_norm_bwd_apply_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
+                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                              const float* __restrict__ m1_in, const float* __restrict__ m2_in,
+                              float* __restrict__ gx1, float* __restrict__ gx2, int64_t gbs1, int64_t gbs2,
+                              const float* __restrict__ add1, int64_t abs1, float* __restrict__ partial,
+                              int P, int span, int chunks) {
+  __shared__ float red[2][4];
+  const int C = s.C1 + s.C2;
+  const int chunk = blockIdx.x % chunks, row = blockIdx.x / chunks;
+  const int c = row % C, b = row / C;
+  const int q0 = chunk * span, q1 = min(q0 + span, P);
+  const float* g = gy + ((int64_t)b * C + c) * P;
+  const float* x = s.row(b, c, P);
+  const bool first = c < s.C1;
+  float* out = first ? gx1 + (int64_t)b * gbs1 + (int64_t)c * P
+                     : (gx2 ? gx2 + (int64_t)b * gbs2 + (int64_t)(c - s.C1) * P : nullptr);
+  const float* ad = (first && add1) ? add1 + (int64_t)b * abs1 + (int64_t)c * P : nullptr;
+  const float* mean = mean_in + (int64_t)b * P;
+  const float* rstd = rstd_in + (int64_t)b * P;
+  const float* m1 = m1_in + (int64_t)b * P;
+  const float* m2 = m2_in + (int64_t)b * P;
+  const float wc = w[c];
+  float a = 0.f, d = 0.f;
+  if (VEC) {
+    for (int q = q0 + 4 * (int)threadIdx.x; q < q1; q += 4 * 256) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + q), xv = *reinterpret_cast<const float4*>(x + q);
+      const float4 mu = *reinterpret_cast<const float4*>(mean + q), rs = *reinterpret_cast<const float4*>(rstd + q);
+      const float4 a1 = *reinterpret_cast<const float4*>(m1 + q), a2 = *reinterpret_cast<const float4*>(m2 + q);
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ad) av = *reinterpret_cast<const float4*>(ad + q);
+      const float xh0 = (xv.x - mu.x) * rs.x, xh1 = (xv.y - mu.y) * rs.y, xh2 = (xv.z - mu.z) * rs.z,
+                  xh3 = (xv.w - mu.w) * rs.w;
+      a += (gv.x * xh0 + gv.y * xh1) + (gv.z * xh2 + gv.w * xh3);
+      d += (gv.x + gv.y) + (gv.z + gv.w);
+      if (out) {
+        float4 o;
+        o.x = rs.x * (gv.x * wc - a1.x - xh0 * a2.x) + av.x;
+        o.y = rs.y * (gv.y * wc - a1.y - xh1 * a2.y) + av.y;
+        o.z = rs.z * (gv.z * wc - a1.z - xh2 * a2.z) + av.z;
+        o.w = rs.w * (gv.w * wc - a1.w - xh3 * a2.w) + av.w;
+        *reinterpret_cast<float4*>(out + q) = o;
+      }
+    }
+  } else {
+    for (int q = q0 + (int)threadIdx.x; q < q1; q += 256) {
+      const float gv = g[q], xh = (x[q] - mean[q]) * rstd[q];
+      a += gv * xh;
+      d += gv;
+      if (out) out[q] = rstd[q] * (gv * wc - m1[q] - xh * m2[q]) + (ad ? ad[q] : 0.f);
+    }
+  }
+  a = wave_sum(a);
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = d; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const float t = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    partial[((int64_t)b * chunks + chunk) * 2 * C + (int64_t)threadIdx.x * C + c] = t;
+  }
+}
+
 // Two-stage reduction of the per-block partial sums in a fixed order (no atomics: bit-reproducible):
 // stage 1, grid (ceil(C/256), chunks): chunk[y][0][c] = sum over the chunk's rows of partial[k][0][c] (and [1]);
 // stage 2, grid ceil(C/256): gw[c] = sum_y chunk[y][0][c], gb[c] = sum_y chunk[y][1][c].
@@ -462,11 +576,20 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
   return 0;
 }
 
+// pixels per workgroup of the apply kernel (one (sample, channel) row chunk); multiple of 4
+constexpr int APPLY_SPAN = 8192;
+#ifndef NORM_BWD_STREAMING    // (A/B builds: 0 = the fused reread kernel of round 2)
+#define NORM_BWD_STREAMING 1
+#endif
+
 extern "C" size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P) {
-  const size_t three_kernel = (size_t)C * dw_chunks(std::max(B, 1), C, P) * 2 * sizeof(float);
-  const size_t nblk = (size_t)std::max(B, 1) * ((P + 31) / 32);
+  const size_t b = (size_t)std::max(B, 1);
+  const size_t three_kernel = (size_t)C * dw_chunks((int)b, C, P) * 2 * sizeof(float);
+  const size_t nblk = b * ((P + 31) / 32);
   const size_t fused = (nblk + (nblk + 63) / 64) * 2 * C * sizeof(float);   // per-block partials + per-chunk sums
-  return std::max(three_kernel, fused) + 256;
+  const size_t nrow = b * ((P + APPLY_SPAN - 1) / APPLY_SPAN);
+  const size_t streaming = (2 * b * P + (nrow + (nrow + 63) / 64) * 2 * C) * sizeof(float);
+  return std::max({three_kernel, fused, streaming}) + 256;
 }
 
 extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2,
@@ -489,6 +612,37 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   }
   CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
   int nblk = 0;
+  const int apply_chunks = (P + APPLY_SPAN - 1) / APPLY_SPAN;
+  if (NORM_BWD_STREAMING && (int64_t)B * C * apply_chunks < (1ll << 31) && (int64_t)B * ((P + 63) / 64) < (1ll << 31)) {
+    float* m1 = (float*)workspace;
+    float* m2 = m1 + (size_t)B * P;
+    float* partial = m2 + (size_t)B * P;
+    const int tiles = (P + NSTAT_PX - 1) / NSTAT_PX;
+    hipLaunchKernelGGL(channel_norm_bwd_stats_kernel, dim3((unsigned)((int64_t)B * tiles)), dim3(NSTAT_PX * NSTAT_G), 0,
+                       st, gy, s, w, mean, rstd, m1, m2, P, tiles);
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = P % 4 == 0 && x1_bs % 4 == 0 && (C2 == 0 || (x2_bs % 4 == 0 && a16(x2))) && gx1_bs % 4 == 0 &&
+                     (gx2 == nullptr || (gx2_bs % 4 == 0 && a16(gx2))) && (addend1 == nullptr || (add1_bs % 4 == 0 && a16(addend1))) &&
+                     a16(gy) && a16(x1) && a16(gx1) && a16(mean) && a16(rstd) && a16(workspace) && ((size_t)B * P) % 4 == 0;
+    const unsigned grid = (unsigned)((int64_t)B * C * apply_chunks);
+    if (vec)
+      hipLaunchKernelGGL(channel_norm_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, st, gy, s, w, mean, rstd,
+                         (const float*)m1, (const float*)m2, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P,
+                         APPLY_SPAN, apply_chunks);
+    else
+      hipLaunchKernelGGL(channel_norm_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, gy, s, w, mean, rstd,
+                         (const float*)m1, (const float*)m2, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P,
+                         APPLY_SPAN, apply_chunks);
+    nblk = B * apply_chunks;
+    const int rows = 64, chunks = (nblk + rows - 1) / rows;
+    float* chunk = partial + (size_t)nblk * 2 * C;
+    hipLaunchKernelGGL(channel_norm_bwd_fused_finish, dim3((C + 255) / 256, chunks), dim3(256), 0, st,
+                       (const float*)partial, chunk, C, nblk, rows);
+    hipLaunchKernelGGL(channel_norm_bwd_fused_finish2, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)chunk, gw,
+                       gb, C, chunks);
+    PD_CHECK_LAUNCH("channel_norm_bwd(streaming)");
+    return 0;
+  }
   if (C <= 32 * 36 && (int64_t)B * ((P + 31) / 32) < (1ll << 31)) {
     // g_norm_bwd_reread: 1 = stream-twice kernel (default; in the training step 231.6 vs 235.2 ms),
     // 0 = gy in registers + xhat in LDS, one workgroup per CU (half the HBM traffic, phases serialised).
