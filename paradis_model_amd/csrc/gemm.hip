@@ -1234,11 +1234,24 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
 // out[i] = slabs[0][i] + slabs[1][i] + ... in that order; vec: n % 4 == 0 and 16-byte aligned pointers (four
 // elements per thread, four slabs' loads in flight)
 __global__ void __launch_bounds__(256)
-slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S, int vec) {
+slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S, int vec,
+                   const float* __restrict__ slabs2, float* __restrict__ out2, int n2, int blocks1) {
+  // second, small reduction riding in the same launch (the bias gradient's row sums next to the weight gradient's
+  // slabs: 131 launches per training step less): blocks [blocks1, gridDim.x)
+  if ((int)blockIdx.x >= blocks1) {
+    const int i = ((int)blockIdx.x - blocks1) * 256 + threadIdx.x;
+    if (i < n2) {
+      float t = 0.f;
+      for (int k = 0; k < S; ++k) t += slabs2[(int64_t)k * n2 + i];
+      out2[i] = t;
+    }
+    return;
+  }
+  const int nblk = blocks1;      // (the grid-stride loops below run over the first `blocks1` blocks)
   if (vec) {
     const int64_t n4 = n >> 2;
     const float4* sl = reinterpret_cast<const float4*>(slabs);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)nblk * 256) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       int k = 0;
       for (; k + 4 <= S; k += 4) {
@@ -1256,7 +1269,7 @@ slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int
     }
     return;
   }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += slabs[(int64_t)k * n + i];
     out[i] = s;
@@ -1647,15 +1660,16 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
     else
       hipLaunchKernelGGL(pw_gemm_wgrad_dma_kernel<3>, dim3(grid), dim3(256), (size_t)3 * 2 * DTILE * sizeof(float), st, g);
   } else if (int e = launch_gemm<true, true>(g, grid, st)) return e;
-  if (S > 1) {
-    const int64_t n = (int64_t)M * K;
+  {
+    // slab sums in a fixed order; with one slab the GEMM wrote dW itself and only the row sums (if any) remain
+    const int64_t n = S > 1 ? (int64_t)M * K : 0;
     const int vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dW)) & 15) == 0;
-    const int blocks = (int)std::min<int64_t>(((vec ? n / 4 : n) + 255) / 256, 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, S, vec);
+    const int blocks1 = n ? (int)std::min<int64_t>(((vec ? n / 4 : n) + 255) / 256, 2048) : 0;
+    const int n2 = g.rowsum ? M : 0, blocks2 = (n2 + 255) / 256;
+    if (blocks1 + blocks2 > 0)
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks1 + blocks2), dim3(256), 0, st, (const float*)workspace, dW, n, S,
+                         vec, (const float*)rowsum_ws, gbias, n2, blocks1);
   }
-  if (g.rowsum)
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)rowsum_ws,
-                       gbias, (int64_t)M, S, 0);
   PD_CHECK_LAUNCH("pw_gemm_wgrad");
   return 0;
 }
