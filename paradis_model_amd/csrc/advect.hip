@@ -530,7 +530,10 @@ __device__ __forceinline__ float sample_wide(const float* win, float ix, float i
 //   - the velocity prefetch runs ADV_PF rows ahead ACROSS plane boundaries.
 // XR = ROW64_XR: global grid (the host checked the coordinate range), wide window, unclamped taps;
 // XR = 0: any other grid, taps outside the padded plane count as zero like ATen's grid_sample.
-constexpr int ROW64_CHUNK = 4;   // 1 and 12 (one workgroup per resident slot) measured 3-6 % slower
+#ifndef ADV_ROW64_CHUNK     // (A/B builds)
+#define ADV_ROW64_CHUNK 4
+#endif
+constexpr int ROW64_CHUNK = ADV_ROW64_CHUNK;   // 1 and 12 (one workgroup per resident slot) measured 3-6 % slower
 typedef __attribute__((address_space(3))) void* adv_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* adv_gbl_ptr_t;
 
