@@ -393,7 +393,7 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS}.get(args.gemm)
             if args.gemm == "bf16x3":
-                kname = ("pw_gemm_split_kernel<3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
+                kname = ("pw_gemm_split_wide_kernel<2, 3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
                          "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
                 peak = MFMA_BF16_PEAK_TFLOPS / products
             elif args.gemm == "f16x2":

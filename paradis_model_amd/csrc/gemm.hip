@@ -1074,15 +1074,35 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
     else if (dmaA && ldB && doA) USE_X(xsplit, 9);
     else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
-    SplitFrags<NP> f;
-    split_tile_read<NP, 2 * SCH, 2 * SCH>(As, Bs, f);
-    split_tile_mfma<NP>(f, acc);
-    split_store(xsplit, Bst + (cur ^ 1) * SIMG);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
+    if constexpr (NP == 3) {
+      // three planes at 128 registers: the B fragments of ONE plane at a time (8 registers instead of 24), planes
+      // in the order l, m, h so that the products still arrive roughly smallest first:
+      //   ah.bl | am.bm, ah.bm | al.bh, am.bh, ah.bh
+      u32x4 a[3][2], b[2];
 #pragma unroll
-    for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 3 : 2, 0);
+      for (int pl = 0; pl < 3; ++pl) { a[pl][0] = As[pl * 2 * SCH]; a[pl][1] = As[pl * 2 * SCH + 32]; }
+#pragma unroll
+      for (int pb = 2; pb >= 0; --pb) {
+        b[0] = Bs[pb * 2 * SCH]; b[1] = Bs[pb * 2 * SCH + 32];
+#pragma unroll
+        for (int pa = 2 - pb; pa >= 0; --pa)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) SPLIT_MFMA(a[pa][tm], b[tn], acc[tm][tn]);
+      }
+      split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+    } else {
+      SplitFrags<NP> f;
+      split_tile_read<NP, 2 * SCH, 2 * SCH>(As, Bs, f);
+      split_tile_mfma<NP>(f, acc);
+      split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
     }
     // weight tile t+1 landed (8 loads of this step are younger), own ds_writes done, the loads of t+2 in flight
     if (dmaA && ldB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1375,10 +1395,12 @@ constexpr size_t split_wide_lds(int nsub, int np = 2) { return (size_t)(2 * nsub
 // bytes - measured 2.5 % SLOWER: a single workgroup's waves all stop at the same barriers.
 constexpr int SPLIT_WIDE_NSUB = 2;
 // scheme: PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 (the latter with d.a_amax / d.b_amax set)
-// bf16x3 on the 128 x 256 tile: its three-plane fragments and split temporaries need ~150 registers; at the 128 that
-// two 8-wave workgroups per CU allow, hipcc spills 1.2 KB per lane (round 3).  Kept behind a build flag for A/B only.
-#ifndef SPLIT_WIDE_BF16X3
-#define SPLIT_WIDE_BF16X3 0
+// bf16x3 on the 128 x 256 tile (round 3).  With all twelve fragments of a k-tile live (the 128 x 128 kernel's way) the
+// kernel needs ~150 registers and hipcc spills 1.2 KB per lane at the 128 that two 8-wave workgroups per CU allow;
+// reading the B fragments one PLANE at a time (8 instead of 24 registers, planes in the order l, m, h) brings it to
+// 128 registers and 12 bytes of scratch.  Training step 160.0 -> 156.3 ms, GEMMs 188 -> 194 TF (same box, two rounds).
+#ifndef SPLIT_WIDE_BF16X3      // (0: the 128 x 128 kernel for every shape; A/B builds)
+#define SPLIT_WIDE_BF16X3 1
 #endif
 template <int NP>
 int launch_split_wide(const GemmArgs& d, int NT, hipStream_t st) {
