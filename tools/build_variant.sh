@@ -7,10 +7,9 @@ NAME=$1; SRC=$2; FLAGS=$3
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/build/variants; mkdir -p $OUT
 BASE=$(basename $SRC .hip)
-EXTRA=""
-[ $BASE = advect ] && EXTRA="-ffp-contract=off"
-[ $BASE = feed ] && EXTRA="-ffp-contract=off"
-[ $BASE = gemm ] && EXTRA="-fno-slp-vectorize"
+EXTRA="-fno-slp-vectorize"
+[ $BASE = advect ] && EXTRA="$EXTRA -ffp-contract=off"
+[ $BASE = feed ] && EXTRA="$EXTRA -ffp-contract=off"
 OBJS=$(ls $R/build/obj/*.o | grep -v "/$BASE.o")
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics $EXTRA $FLAGS \
     -c $R/paradis_model_amd/csrc/$BASE.hip -o $OUT/${BASE}_$NAME.o
