@@ -62,7 +62,7 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic):
     """Tolerance protocol of SURVEY.md 8c(iii): rms-rel vs CPU fp32 <= 1e-5 and error vs the fp64
     golden <= 1.5x the CPU-fp32 golden's own error vs fp64 (+ a small absolute floor)."""
     g = load_golden("g2_advect.pt")
-    report = []
+    report, ratios = [], []
     for key, rec in g.items():
         H, W, K, B = rec["H"], rec["W"], rec["K"], rec["B"]
         _, lg, og = make_grid(H, W, rec["poles"])
@@ -81,11 +81,21 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic):
         assert r32 <= 1e-5, (key, r32)
         assert e_gpu <= 1.5 * e_cpu + 2e-7, (key, e_gpu, e_cpu)
         assert max_rel(gf, rec["gfield_f32"]) < 5e-5, key
-        assert rms_rel(gu, rec["gu_f32"]) < 2e-3, key
-        assert rms_rel(gv, rec["gv_f32"]) < 2e-3, key
+        # velocity gradients: the golden is the REFERENCE's fp32 autograd, which is itself up to 1e-3 off an fp64
+        # evaluation where points sit next to a cell boundary (bilinear: the derivative jumps there) or a pole; so
+        # the bound is the fp64 protocol - distance to the oracle's fp64 gradient against the golden's own distance
+        fd, ud, vd = (t.double().requires_grad_(True) for t in (f, u, v))
+        O.sl_advect_core(fd, ud, vd, rec["dt"], O.GridGeometry(lg.double(), og.double()), rec["mode"]).backward(ct.double())
+        for name, got, gold, ref in (("gu", gu, rec["gu_f32"], ud.grad), ("gv", gv, rec["gv_f32"], vd.grad)):
+            e_g, e_c = rms_rel(got, ref), rms_rel(gold, ref)
+            ratios.append((key, name, e_g, e_c))
+            assert e_g <= 2.0 * e_c + 2e-6, (key, name, e_g, e_c)
     print("\nadvect parity (key, rms32, err_gpu_vs64, err_cpu_vs64, gfield, gu, gv):")
     for r in report:
         print("  %-24s %.2e %.2e %.2e %.2e %.2e %.2e" % r)
+    print("velocity gradients vs fp64 (key, which, hip, reference-fp32 golden):")
+    for r in ratios:
+        print("  %-24s %s %.2e %.2e" % r)
 
 
 @pytest.mark.parametrize("H,W,poles,mode", [(32, 64, False, "bicubic"), (33, 64, True, "bilinear"),
