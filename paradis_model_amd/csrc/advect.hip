@@ -380,7 +380,7 @@ __device__ __forceinline__ bool tap_block_whole(float ix, float iy, float Hpf, f
 __device__ __forceinline__ float wave_row_mean(const float* row, int W) {
   float s = 0.f;
   for (int x = threadIdx.x & 63; x < W; x += 64) s += row[x];
-  return wave_sum(s) / (float)W;
+  return wave_sum_dpp(s) / (float)W;
 }
 
 // Window of the padded plane held in LDS: padded rows [wy0, wy0+WH), padded cols [wx0, wx0+WW).
@@ -571,6 +571,36 @@ __device__ __forceinline__ void dma_row_to_lds(const float* grow, unsigned lane_
                :: "s"(m), "v"(lane_bytes), "s"(base) : "memory");   // (M0 is reserved: the compiler keeps nothing in it across statements)
 }
 
+// Halo cells of the W = 64 window: the 2p mirrored rows beyond the poles, then p + (p + XR) columns per row.  Cell q of
+// that list as (destination << 16 | source) offsets into the window, 0xffff0000 for the cells of the two pole rows
+// (written whole by pole_rows_to_mean_lds).  The list does not depend on the plane: each thread keeps its ROW64_HMAP
+// pairs in registers for the whole launch instead of redoing the index arithmetic (~50 vector instructions) per plane.
+constexpr int ROW64_HMAP = 3;
+constexpr unsigned ROW64_NO_CELL = 0xffff0000u;   // (its source half reads cell 0)
+template <int MODE, int XR>
+__device__ __forceinline__ int row64_halo_cells(int H) {
+  constexpr int p = Interp<MODE>::NT / 2, WS = 64 + 2 * p + XR;
+  return 2 * p * WS + H * (2 * p + XR);
+}
+template <int MODE, int XR>
+__device__ __forceinline__ unsigned row64_halo_pair(int q, int H) {
+  constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR, hc = 2 * p + XR, nrow_cells = 2 * p * WS;
+  int lr, lc;
+  if (q < nrow_cells) {
+    const int rr = q / WS;
+    lc = q - rr * WS;
+    lr = rr < p ? rr : H + rr;
+  } else {
+    const int e = q - nrow_cells, rr = e / hc, cc = e - rr * hc;
+    lr = rr + p;
+    lc = cc < p ? cc : W + cc;
+  }
+  if (lr == p || lr == H - 1 + p) return ROW64_NO_CELL;
+  int sr, sc;
+  geo_src(lr - p, lc - p, H, W, sr, sc);
+  return ((unsigned)(lr * WS + lc) << 16) | (unsigned)((sr + p) * WS + sc + p);
+}
+
 // One plane of the pipeline.  The interior of the NEXT plane goes global -> LDS by DMA, one row per row
 // iteration, while this plane is computed.  That the DMA INTO cur - issued one plane earlier - has landed
 // is the caller's counted wait.
@@ -581,29 +611,25 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
                                             const float* __restrict__ v, VelCursor& vc, float (&qu)[ADV_PF],
                                             float (&qv)[ADV_PF], const float* __restrict__ sin_lat,
                                             const float* __restrict__ cos_lat, const float* __restrict__ lat_cells,
-                                            float lonc, const AdvGeom& g, int wave, unsigned lane, bool fill_halo) {
+                                            float lonc, const AdvGeom& g, int wave, unsigned lane, bool fill_halo,
+                                            const unsigned (&hmap)[ROW64_HMAP]) {
   constexpr int W = 64, p = Interp<MODE>::NT / 2, WS = W + 2 * p + XR;
   const int H = g.H, Hp = H + 2 * p, tid = threadIdx.x;
   // halo columns (p left, p + XR right) and the p mirrored rows beyond each pole are copies of interior
   // cells; the two pole rows are written whole by pole_rows_to_mean_lds
   if (fill_halo) {
-    constexpr int hc = 2 * p + XR;
-    const int nrow_cells = 2 * p * WS, nhalo = nrow_cells + H * hc;
-    for (int q = tid; q < nhalo; q += 256) {
-      int lr, lc;
-      if (q < nrow_cells) {
-        const int rr = q / WS;
-        lc = q - rr * WS;
-        lr = rr < p ? rr : H + rr;
-      } else {
-        const int e = q - nrow_cells, rr = e / hc, cc = e - rr * hc;
-        lr = rr + p;
-        lc = cc < p ? cc : W + cc;
+    if (row64_halo_cells<MODE, XR>(H) <= 256 * ROW64_HMAP) {   // the (destination, source) cells of this thread: row64_halo_map
+      float t[ROW64_HMAP];
+#pragma unroll
+      for (int k = 0; k < ROW64_HMAP; ++k) t[k] = cur[hmap[k] & 0xffffu];
+#pragma unroll
+      for (int k = 0; k < ROW64_HMAP; ++k)
+        if (hmap[k] != ROW64_NO_CELL) cur[hmap[k] >> 16] = t[k];
+    } else {
+      for (int q = tid; q < row64_halo_cells<MODE, XR>(H); q += 256) {
+        const unsigned m = row64_halo_pair<MODE, XR>(q, H);
+        if (m != ROW64_NO_CELL) cur[m >> 16] = cur[m & 0xffffu];
       }
-      if (lr == p || lr == H - 1 + p) continue;
-      int sr, sc;
-      geo_src(lr - p, lc - p, H, W, sr, sc);
-      cur[lr * WS + lc] = cur[(sr + p) * WS + sc + p];
     }
   }
   pole_rows_to_mean_lds(cur, H, W, p, WS);
@@ -618,7 +644,7 @@ __device__ __forceinline__ void row64_plane(float* __restrict__ cur, float* __re
       float ix, iy;
       departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
       float acc = XR ? sample_wide<MODE>(cur, ix, iy, WS, WSf) : sample_whole<MODE>(cur, ix, iy, Hp, WS, Hpf, WSf);
-      if (y == 0 || y == H - 1) acc = wave_sum(acc) * (1.0f / 64.0f);   // pole rows <- their mean
+      if (y == 0 || y == H - 1) acc = wave_sum_dpp(acc) * (1.0f / 64.0f);   // pole rows <- their mean
       ADV_ST(acc, &srow(O + y * W)[lane]);
     }
   };
@@ -670,6 +696,12 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
 #pragma unroll
   for (int d = 0; d < ADV_PF; ++d) vc.load(u, v, lane, qu[d], qv[d]);
   const float lonc = lon_cells(lon[lane], g);
+  unsigned hmap[ROW64_HMAP];
+#pragma unroll
+  for (int k = 0; k < ROW64_HMAP; ++k) {
+    const int q = tid + 256 * k;
+    hmap[k] = q < row64_halo_cells<MODE, XR>(H) ? row64_halo_pair<MODE, XR>(q, H) : ROW64_NO_CELL;
+  }
   float* cur = smem;
   float* nxt = smem + Hp * WS;
   {   // the first plane of the chunk is staged through registers, halo included
@@ -688,7 +720,7 @@ sl_advect_fwd_row64(const float* __restrict__ field, const float* __restrict__ u
     const bool has_next = plane + 1 < last;
     const int64_t next_off = has_next ? (int64_t)nb * f_bs + (int64_t)nk * P : 0;
     row64_plane<MODE, XR>(cur, nxt, field, next_off, has_next, out + (int64_t)b * o_bs + (int64_t)k * P, u, v, vc,
-                          qu, qv, sin_lat, cos_lat, lat_cells, lonc, g, wave, lane, plane != first);
+                          qu, qv, sin_lat, cos_lat, lat_cells, lonc, g, wave, lane, plane != first, hmap);
     float* t = cur; cur = nxt; nxt = t;
     b = nb; k = nk;
   }
@@ -1156,7 +1188,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
     const float gval = srow(GO + y * W)[lane];
     gmaxb = max(gmaxb, abs_bits(gval));
     if (y == 0 || y == H - 1) {   // adjoint of the final pole mean: the cotangent of a pole row is its row mean
-      const float m = wave_sum(gval) * (1.0f / 64.0f);
+      const float m = wave_sum_dpp(gval) * (1.0f / 64.0f);
       if (lane == 0) misc[y == 0 ? 0 : 1] = m;
     }
   }
@@ -1230,7 +1262,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
       if (mhi) s += (long long)mrow[xm - W];
     }
     float val = (float)((double)s * inv);
-    if (y == 0 || y == H - 1) val = wave_sum(val) * (1.0f / 64.0f);
+    if (y == 0 || y == H - 1) val = wave_sum_dpp(val) * (1.0f / 64.0f);
     srow(GF + y * W)[lane] = val;
   }
 }

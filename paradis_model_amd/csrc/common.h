@@ -126,6 +126,18 @@ static inline hipError_t pd_zero_async(void* p, size_t bytes, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Sum over the wave by DPP, the same value in every lane: row_shr 1/2/4/8 (lanes without a source add 0) leave each
+// 16-lane row's sum in its last lane, row_bcast 15 / 31 carry it on to lane 63, one v_readlane broadcasts it.
+// Seven dependent vector instructions instead of six LDS-pipe shuffles with a wait each (wave_sum below); the order of
+// the additions differs from wave_sum's, the result agrees to rounding.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define PD_DPP_ADD(ctrl, rows) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rows, 0xf, true))
+  PD_DPP_ADD(0x111, 0xf); PD_DPP_ADD(0x112, 0xf); PD_DPP_ADD(0x114, 0xf); PD_DPP_ADD(0x118, 0xf);
+  PD_DPP_ADD(0x142, 0xa); PD_DPP_ADD(0x143, 0xc);
+#undef PD_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
