@@ -112,6 +112,92 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   }
 }
 
+// The same 32-pixel x 32-group kernel for even C1, C2 with the register diet that two 1024-thread workgroups per CU
+// need (<= 64 VGPRs; the generic kernel above compiles to 102: one 64-bit address per load, and the affine parameters
+// of all MAXV channels hoisted in front of the stores).  A wave holds two channel groups (lanes 0-31: channel
+// 2 wave + 32 i, lanes 32-63: the next one), so the row pair of value i has a wave-uniform base: every load and store
+// is `scalar base + one 32-bit lane offset`; w and bias are staged in LDS once and read at the point of use.
+template <int MAXV>
+__global__ void __launch_bounds__(1024, 8)
+channel_norm_fwd32_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
+                          float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                          int P, int tiles, float eps) {
+  constexpr int G = 32, NPXF = 32;
+  __shared__ float red[G][NPXF];
+  __shared__ float stat[2][NPXF];
+  __shared__ float wl[G * MAXV], bl[G * MAXV];
+  const int C = s.C1 + s.C2;
+  const int b = blockIdx.x / tiles, p0 = (blockIdx.x - b * tiles) * NPXF;
+  const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = p0 + lane;
+  const bool live = p < P;
+  for (int c = tid; c < C; c += 1024) { wl[c] = w[c]; bl[c] = bias[c]; }
+  const unsigned voff = (unsigned)(((tid >> 5) & 1) * P + min(p, P - 1));   // (second group of the wave: one row further)
+  typedef const __attribute__((address_space(1))) float* gptr;
+  auto rowbase = [&](int ce) __attribute__((always_inline)) -> gptr {   // wave-uniform: channel ce (even) of sample b
+    const float* r = s.row(b, ce, P);
+    const uint64_t a = (uint64_t)r;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (gptr)(((uint64_t)hi << 32) | lo);
+  };
+  float vals[MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ce = 2 * wave + G * i;                   // both groups of the wave are valid or not together (C even)
+    vals[i] = ce < C ? rowbase(ce)[voff] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) sum += vals[i];
+  red[grp][lane] = sum;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) t += red[k][lane];
+    stat[0][lane] = t / (float)C;
+  }
+  __syncthreads();
+  const float mean = stat[0][lane];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const float d = (2 * wave + G * i < C) ? vals[i] - mean : 0.f;
+    sq += d * d;
+  }
+  __syncthreads();
+  red[grp][lane] = sq;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) t += red[k][lane];
+    const float r = 1.0f / sqrtf(t / (float)(C - 1) + eps);
+    stat[1][lane] = r;
+    if (live) {
+      mean_out[(int64_t)b * P + p] = mean;
+      rstd_out[(int64_t)b * P + p] = r;
+    }
+  }
+  __syncthreads();
+  const float rstd = stat[1][lane];
+  if (!live) return;
+  typedef __attribute__((address_space(1))) float* gwptr;
+  const uint64_t ybase = (uint64_t)(y + (int64_t)b * C * P);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ce = 2 * wave + G * i;
+    if (ce < C) {
+      const int c = grp + G * i;
+      const float v = (vals[i] - mean) * rstd * wl[c] + bl[c];
+      const uint64_t a = ybase + (uint64_t)ce * P * 4;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+      ((gwptr)(((uint64_t)hi << 32) | lo))[voff] = v;
+    }
+  }
+}
+
 // gx = rstd * ( g*w - mean_c(g*w) - xhat * sum_c(g*w*xhat)/(C-1) )
 __global__ void __launch_bounds__(1024)
 channel_norm_bwd_dx_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
@@ -545,6 +631,9 @@ extern "C" void paradis_debug_set_norm_fwd_px(int px) { g_norm_fwd_px = px == 64
 extern "C" void paradis_debug_set_norm_bwd_reread(int on) { g_norm_bwd_reread = on ? 1 : 0; }
 #endif
 
+#ifndef NORM_FWD32      // (A/B builds: 0 = the generic 32-pixel kernel)
+#define NORM_FWD32 1
+#endif
 extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
                                         const float* b, float* y, float* mean, float* rstd, int B,
                                         int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
@@ -560,6 +649,8 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 32 * 4)
       hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+    else if (NORM_FWD32 && (C1 & 1) == 0 && (C2 & 1) == 0 && (int64_t)2 * P < (1ll << 30))
+      hipLaunchKernelGGL((channel_norm_fwd32_kernel<36>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else
       hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
   } else {
