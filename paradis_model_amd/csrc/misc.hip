@@ -11,25 +11,31 @@ inline int stream_blocks(int64_t n_items) {
 }
 
 // ------------------------------------------------------------------ global bias map, forward
-// grid (ceil(W/256), H, Cin): m8[c,h,w] = sum_r (A[c,r] U[r,h]) V[r,w]
+// grid (ceil(W/64), H, Cin): m8[c,h,w] = sum_r (A[c,r] U[r,h]) V[r,w].  64 columns per workgroup, the rank range in
+// four quarters (one per wave) summed in quarter order: at W = 64 a 256-column workgroup had three idle waves and
+// walked all R ranks in one dependent chain (23 us for 2 M multiply-adds).
 __global__ void __launch_bounds__(256)
 gbias_m8_kernel(const float* __restrict__ A, const float* __restrict__ U, const float* __restrict__ V,
                 float* __restrict__ m8, int Cin, int R, int H, int W) {
-  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, c = blockIdx.z;
-  if (w >= W) return;
-  // rank loop in batches of independent loads (one dependent load per iteration made this 50 us for
-  // 2 M multiply-adds); same summation order
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int w = min(blockIdx.x * 64 + tx, W - 1), h = blockIdx.y, c = blockIdx.z;
+  const int rq = (R + 3) / 4, r1 = min(R, (q + 1) * rq);
+  // rank loop in batches of independent loads (one dependent load per iteration made this 50 us)
   float acc = 0.f;
-  int r = 0;
-  for (; r + 8 <= R; r += 8) {
+  int r = q * rq;
+  for (; r + 8 <= r1; r += 8) {
     float a[8], u[8], v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a[j] = A[c * R + r + j]; u[j] = U[(r + j) * H + h]; v[j] = V[(r + j) * W + w]; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc += a[j] * u[j] * v[j];
   }
-  for (; r < R; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
-  m8[((int64_t)c * H + h) * W + w] = acc;
+  for (; r < r1; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
+  part[q][tx] = acc;
+  __syncthreads();
+  if (q == 0 && blockIdx.x * 64 + tx < W)
+    m8[((int64_t)c * H + h) * W + w] = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
 }
 
 // out[o,p] = sum_c Wm[o*ldo + c*ldc] * in[c,p]      (projection and its transpose)
@@ -267,6 +273,39 @@ bias_grads_kernel(const float* __restrict__ dz, float* __restrict__ gmap, float*
   if (threadIdx.x == 0) atomicAdd(&gbias[c], red[0] + red[1] + red[2] + red[3]);
 }
 
+// the same with 16-byte accesses (P % 4 == 0, 16-byte aligned rows): grid (C, pchunks) over float4 columns
+__global__ void __launch_bounds__(256)
+bias_grads_vec4_kernel(const float* __restrict__ dz, float* __restrict__ gmap, float* __restrict__ gbias,
+                       int B, int C, int P4, int64_t bs, int pchunks) {
+  __shared__ float red[4];
+  const int c = blockIdx.x / pchunks, chunk = blockIdx.x - c * pchunks;
+  const float4* src = reinterpret_cast<const float4*>(dz + (int64_t)c * P4 * 4);
+  const int64_t bs4 = bs / 4;
+  float acc = 0.f;
+  for (int q = chunk * 256 + threadIdx.x; q < P4; q += pchunks * 256) {
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {     // eight independent loads in flight, summed in batch order
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(b + j) * bs4 + q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+    }
+    for (; b < B; ++b) {
+      const float4 v = src[(int64_t)b * bs4 + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (gmap) reinterpret_cast<float4*>(gmap + (int64_t)c * P4 * 4)[q] = s;
+    acc += (s.x + s.y) + (s.z + s.w);
+  }
+  if (!gbias) return;
+  acc = wave_sum_dpp(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&gbias[c], red[0] + red[1] + red[2] + red[3]);
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -280,7 +319,7 @@ extern "C" int paradis_global_bias_map_fwd(const float* A, const float* U, const
   const int64_t P = (int64_t)H * W;
   float* m8_dst = Pw ? m8 : map;
   PD_REQUIRE(H <= 65535 && Cin <= 65535 && Co <= 65535, "global_bias_map_fwd: grid too large");
-  hipLaunchKernelGGL(gbias_m8_kernel, dim3((W + 255) / 256, H, Cin), dim3(256), 0, st, A, U, V, m8_dst, Cin,
+  hipLaunchKernelGGL(gbias_m8_kernel, dim3((W + 63) / 64, H, Cin), dim3(256), 0, st, A, U, V, m8_dst, Cin,
                      R, H, W);
   if (Pw)
     hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Co), dim3(256), 0, st, Pw, Cin, 1,
@@ -403,6 +442,15 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
     return 2;
   }
   if (!gmap && !gbias) return 0;
+  if (P % 4 == 0 && dz_bs % 4 == 0 && aligned16(dz) && (!gmap || aligned16(gmap))) {
+    const int P4 = P / 4;
+    int pch = std::max(1, std::min((P4 + 255) / 256, std::max(1, 2048 / C)));
+    if (paradis_deterministic()) pch = 1;
+    hipLaunchKernelGGL(bias_grads_vec4_kernel, dim3((unsigned)((int64_t)C * pch)), dim3(256), 0, st, dz, gmap,
+                       gbias, B, C, P4, dz_bs, pch);
+    PD_CHECK_LAUNCH("bias_grads");
+    return 0;
+  }
   int pchunks = std::max(1, std::min((P + 255) / 256, std::max(1, 2048 / C)));
   if (paradis_deterministic()) pchunks = 1;   // one workgroup per channel: no atomics between chunks
   hipLaunchKernelGGL(bias_grads_kernel, dim3((unsigned)((int64_t)C * pchunks)), dim3(256), 0, st, dz, gmap,

@@ -264,8 +264,8 @@ channel_norm_bwd_dw_kernel(const float* __restrict__ gy, CatSrc s, const float* 
     aw += g * xh;
     ab += g;
   }
-  aw = wave_sum(aw);
-  ab = wave_sum(ab);
+  aw = wave_sum_dpp(aw);
+  ab = wave_sum_dpp(ab);
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[0][wave] = aw; red[1][wave] = ab; }
   __syncthreads();
@@ -565,8 +565,8 @@ channel_norm_bwd_apply_kernel(const float* __restrict__ gy, CatSrc s, const floa
       if (out) out[q] = rstd[q] * (gv * wc - m1[q] - xh * m2[q]) + (ad ? ad[q] : 0.f);
     }
   }
-  a = wave_sum(a);
-  d = wave_sum(d);
+  a = wave_sum_dpp(a);
+  d = wave_sum_dpp(d);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = d; }
   __syncthreads();
   if (threadIdx.x < 2) {

@@ -247,11 +247,11 @@ dwconv_geo_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
   }
 #pragma unroll
   for (int i = 0; i < K * K; ++i) {
-    float s = wave_sum(acc[i]);
+    float s = wave_sum_dpp(acc[i]);
     if (xl == 0) red[wave][i] = s;
   }
   {
-    float s = wave_sum(gsum);
+    float s = wave_sum_dpp(gsum);
     if (xl == 0) red[wave][K * K] = s;
   }
   __syncthreads();
