@@ -22,11 +22,13 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
     step(batch)
 torch.cuda.synchronize()
-rows = [e for e in prof.events() if e.name in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::add", "aten::add_")]
+NAMES = ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::add", "aten::add_", "aten::copy_",
+         "aten::clone", "aten::contiguous")
+rows = [e for e in prof.events() if e.name in NAMES]
 from collections import Counter
 cnt = Counter()
 for e in rows:
     st = [s for s in (e.stack or []) if "paradis_model_amd" in s or "torch/autograd" in s][:2]
     cnt[(e.name, str(e.input_shapes)[:60], tuple(st))] += 1
-for (name, shp, st), n in cnt.most_common(25):
+for (name, shp, st), n in cnt.most_common(40):
     print(n, name, shp, " | ".join(s.split("/")[-1] for s in st))
