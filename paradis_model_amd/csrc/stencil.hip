@@ -56,6 +56,91 @@ __device__ __forceinline__ void stage_any(float* tile, const float* __restrict__
   else stage_tile<K, true>(tile, src, H, W, ty0, tx0);
 }
 
+// The whole-plane case again (W == TW, H <= TH, k = 5: stage_plane_vec4's conditions), split into LOAD and STORE so
+// that a workgroup walking several planes can have the next plane's loads in flight while it computes the current one:
+// with one plane per workgroup a CU has loads outstanding only about half of the time (4.6 TB/s; Little's law with
+// eight 8-KB planes per CU).  The per-thread cells - two float4 of the interior, two halo cells (destination in the
+// tile, source in the plane) - do not depend on the plane and are computed once.
+// a wave-uniform base address pinned to scalar registers plus an unsigned 32-bit BYTE offset per lane: the access is
+// `global_load/store v, v_off, s[base:base+1]` - no 64-bit address arithmetic, no 64-bit addresses kept in registers
+// (with typed indexing the compiler only finds this form for 4-byte elements)
+typedef __attribute__((address_space(1))) char* ubase_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 struct cannot be read through an address-space pointer on the host pass)
+__device__ __forceinline__ ubase_t uniform_base(const void* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (ubase_t)(((uint64_t)hi << 32) | lo);
+}
+// (the empty asm keeps the 32-bit offset opaque at the access: otherwise the loop optimiser widens it once to a 64-bit
+//  per-thread address, carries that through the plane loop - two registers per access - and adds the base on the
+//  vector unit)
+template <typename T>
+__device__ __forceinline__ T load_at(ubase_t b, unsigned off) {
+  asm volatile("" : "+v"(off));
+  return *(const __attribute__((address_space(1))) T*)(b + off);
+}
+template <typename T>
+__device__ __forceinline__ void store_at(ubase_t b, unsigned off, T v) {
+  asm volatile("" : "+v"(off));
+  *(__attribute__((address_space(1))) T*)(b + off) = v;
+}
+
+template <int K>
+struct PlaneStager {
+  static constexpr int P = (K - 1) / 2, LW = TW + K - 1;
+  unsigned vsrc[2], hsrc[2];
+  int vdst[2], hdst[2];
+  __device__ __forceinline__ void init(int H) {
+    constexpr int W = TW, w4 = W / 4, hc = 2 * P;
+    const int nvec = H * w4, nhalo_rows = 2 * P * LW, nhalo = nhalo_rows + H * hc, Hp = H + 2 * P;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = threadIdx.x + 256 * j, vc = min(v, nvec - 1);
+      const int y = vc / w4, x4 = vc - y * w4;
+      vsrc[j] = (unsigned)vc * 16u;                     // byte offsets
+      vdst[j] = v < nvec ? (y + P) * LW + P + 4 * x4 : -1;
+      const int kk = threadIdx.x + 256 * j, k = min(kk, nhalo - 1);
+      int lr, lc;
+      if (k < nhalo_rows) {
+        const int rr = k / LW;
+        lc = k - rr * LW;
+        lr = rr < P ? rr : Hp - 2 * P + rr;
+      } else {
+        const int e = k - nhalo_rows, rr = e / hc, cc = e - rr * hc;
+        lr = rr + P;
+        lc = cc < P ? cc : W + cc;
+      }
+      int sr, sc;
+      geo_src(lr - P, lc - P, H, W, sr, sc);
+      hsrc[j] = (unsigned)(sr * W + sc) * 4u;
+      hdst[j] = kk < nhalo ? lr * LW + lc : -1;
+    }
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ F, f32x4 (&q)[2], float (&hv)[2]) const {
+    const ubase_t b = uniform_base(F);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { q[j] = load_at<f32x4>(b, vsrc[j]); hv[j] = load_at<float>(b, hsrc[j]); }
+  }
+  __device__ __forceinline__ void store(float* tile, const f32x4 (&q)[2], const float (&hv)[2]) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (vdst[j] >= 0) {
+        float2* d = reinterpret_cast<float2*>(tile + vdst[j]);      // 8-byte aligned (P, LW even)
+        d[0] = make_float2(q[j].x, q[j].y);
+        d[1] = make_float2(q[j].z, q[j].w);
+      }
+      if (hdst[j] >= 0) tile[hdst[j]] = hv[j];
+    }
+  }
+};
+#ifndef DWCONV_PLANE_CHUNK       // (A/B builds)
+#define DWCONV_PLANE_CHUNK 4
+#endif
+constexpr int PLANE_CHUNK = DWCONV_PLANE_CHUNK;   // planes per workgroup on the whole-plane path
+#ifndef DWCONV_PLANES            // (A/B builds: 0 = one plane per workgroup)
+#define DWCONV_PLANES 1
+#endif
+
 // FLIP=false: y = w (*) geo-padded x  (+bias).   FLIP=true: self-alias part of the data gradient.
 template <int K, bool FLIP>
 __device__ __forceinline__ void tile_stencil(const float* tile, const float* __restrict__ wc,
@@ -80,6 +165,42 @@ __device__ __forceinline__ void tile_stencil(const float* tile, const float* __r
         for (int b = 0; b < K; ++b) acc[o] += w[a * K + b] * val[b];
       }
     }
+    // (row by row: left alone the scheduler hoists the LDS reads of many rows and the kernel sits at exactly 64
+    //  registers with no room for the prefetched plane)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// whole-plane path: PLANE_CHUNK planes per workgroup, the next plane's loads in flight during the stencil
+template <int K>
+__global__ void __launch_bounds__(256, 5)   // (8 waves per SIMD = 64 registers spill the prefetched plane: 235 us instead of 99)
+dwconv_geo_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                             const float* __restrict__ bias, float* __restrict__ y, int C, int H, int64_t planes) {
+  constexpr int W = TW;
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  const int xl = threadIdx.x & 63, r0l = (threadIdx.x >> 6) * RPT;
+  const int64_t first = (int64_t)blockIdx.x * PLANE_CHUNK;
+  const int n = (int)min((int64_t)PLANE_CHUNK, planes - first);
+  PlaneStager<K> sg;
+  sg.init(H);
+  f32x4 q[2];
+  float hv[2];
+  sg.load(x + first * (int64_t)H * W, q, hv);
+  for (int i = 0; i < n; ++i) {
+    const int64_t plane = first + i;
+    const int c = (int)(plane % C);
+    sg.store(tile, q, hv);
+    __syncthreads();
+    if (i + 1 < n) sg.load(x + (plane + 1) * (int64_t)H * W, q, hv);
+    float acc[RPT];
+    tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
+    const float bv = bias ? bias[c] : 0.f;
+    const ubase_t yp = uniform_base(y + plane * (int64_t)H * W);
+    const unsigned o0 = (unsigned)(r0l * W + xl) * 4u;
+#pragma unroll
+    for (int o = 0; o < RPT; ++o)
+      if (r0l + o < H) store_at<float>(yp + o * W * 4, o0, acc[o] + bv);   // (the row step is on the scalar base)
+    __syncthreads();
   }
 }
 
@@ -199,6 +320,92 @@ dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
   }
 }
 
+// whole-plane path of the data gradient: PLANE_CHUNK planes per workgroup, next plane's loads in flight (see
+// dwconv_geo_fwd_planes_kernel); the mirrored pole rows come from the tile
+template <int K>
+__global__ void __launch_bounds__(256, 5)
+dwconv_geo_dgrad_planes_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+                               int C, int H, int64_t planes) {
+  constexpr int P = (K - 1) / 2, LW = TW + K - 1, W = TW;
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  const int xl = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RPT;
+  const int64_t first = (int64_t)blockIdx.x * PLANE_CHUNK;
+  const int n = (int)min((int64_t)PLANE_CHUNK, planes - first);
+  PlaneStager<K> sg;
+  sg.init(H);
+  f32x4 q[2];
+  float hv[2];
+  sg.load(gy + first * (int64_t)H * W, q, hv);
+  for (int i = 0; i < n; ++i) {
+    const int64_t plane = first + i;
+    const float* wc = w + (int64_t)(plane % C) * K * K;
+    sg.store(tile, q, hv);
+    __syncthreads();
+    if (i + 1 < n) sg.load(gy + (plane + 1) * (int64_t)H * W, q, hv);
+    float wr[K * K];
+#pragma unroll
+    for (int j = 0; j < K * K; ++j) wr[j] = wc[j];
+    float acc[RPT];
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RPT + K - 1; ++rr) {
+      const int ii = r0 + rr - P;   // image row of this tile row (wave-uniform)
+      float val[K];
+#pragma unroll
+      for (int b = 0; b < K; ++b) val[b] = tile[(r0 + rr) * LW + xl + b];
+      if (ii >= 0 && ii < H) {
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          const int o = rr - a;
+          if (o >= 0 && o < RPT) {
+#pragma unroll
+            for (int b = 0; b < K; ++b) acc[o] += wr[(K - 1 - a) * K + (K - 1 - b)] * val[b];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          const int o = rr - a;
+          if (o >= 0 && o < RPT) {
+            const int yy = r0 + o;
+            const bool feeds = (ii < 0) ? (yy >= 1) : (yy <= H - 2);
+            if (feeds) {
+#pragma unroll
+              for (int b = 0; b < K; ++b) acc[o] += wr[a * K + (K - 1 - b)] * val[b];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const ubase_t gp = uniform_base(gx + plane * (int64_t)H * W);
+    const unsigned o0 = (unsigned)(r0 * W + xl) * 4u;
+    constexpr int half = W >> 1;
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) {
+      const int yy = r0 + o;
+      if (yy < H) {
+        float extra = 0.f;
+        const bool south = yy >= 1 && yy <= P, north = yy >= H - 1 - P && yy <= H - 2;
+        if (south || north) {
+          const int a = south ? P - yy : P + (H - 1 - yy);   // dr = -yy  resp.  H-1-yy
+          const int prow = south ? 0 : H - 1;
+#pragma unroll
+          for (int b = 0; b < K; ++b) {     // dc = P - b
+            int col = xl + P - b + half;
+            if (col >= W) col -= W;
+            if (col >= W) col -= W;
+            extra += wc[a * K + b] * tile[(prow + P) * LW + col + P];
+          }
+        }
+        store_at<float>(gp + o * W * 4, o0, acc[o] + extra);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // partial[c][chunk][K*K (+1 for bias)] ; items of a channel = (batch n, tile t)
 template <int K>
 __global__ void __launch_bounds__(256)
@@ -244,6 +451,73 @@ dwconv_geo_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
         }
       }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) {
+    float s = wave_sum_dpp(acc[i]);
+    if (xl == 0) red[wave][i] = s;
+  }
+  {
+    float s = wave_sum_dpp(gsum);
+    if (xl == 0) red[wave][K * K] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NW) {
+    float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    partial[((int64_t)c * chunks + chunk) * NW + threadIdx.x] = s;
+  }
+}
+
+// whole-plane path of the weight gradient: the items of a chunk are whole planes (sample n, channel c); the next
+// item's x plane and gy rows are loaded while the current one is accumulated
+template <int K>
+__global__ void __launch_bounds__(256, 5)
+dwconv_geo_wgrad_planes_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                               float* __restrict__ partial, int B, int C, int H, int chunks) {
+  constexpr int LW = TW + K - 1, NW = K * K + 1, W = TW;
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  __shared__ float red[4][NW];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x - c * chunks;
+  const int xl = threadIdx.x & 63, wave = threadIdx.x >> 6, r0l = wave * RPT;
+  float acc[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+  float gsum = 0.f;
+  PlaneStager<K> sg;
+  sg.init(H);
+  f32x4 q[2];
+  float hv[2], gn[RPT];
+  const unsigned g0 = (unsigned)(r0l * W + xl) * 4u;
+  auto fetch = [&](int item) __attribute__((always_inline)) {
+    const int64_t off = ((int64_t)item * C + c) * (int64_t)H * W;
+    sg.load(x + off, q, hv);
+    const ubase_t gb = uniform_base(gy + off);
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) gn[o] = (r0l + o < H) ? load_at<float>(gb + o * W * 4, g0) : 0.f;
+  };
+  if (chunk < B) fetch(chunk);
+  for (int item = chunk; item < B; item += chunks) {
+    sg.store(tile, q, hv);
+    float g[RPT];
+#pragma unroll
+    for (int o = 0; o < RPT; ++o) { g[o] = gn[o]; gsum += g[o]; }
+    __syncthreads();
+    if (item + chunks < B) fetch(item + chunks);
+#pragma unroll
+    for (int rr = 0; rr < RPT + K - 1; ++rr) {
+      float val[K];
+#pragma unroll
+      for (int b = 0; b < K; ++b) val[b] = tile[(r0l + rr) * LW + xl + b];
+#pragma unroll
+      for (int a = 0; a < K; ++a) {
+        const int o = rr - a;
+        if (o >= 0 && o < RPT) {
+#pragma unroll
+          for (int b = 0; b < K; ++b) acc[a * K + b] += g[o] * val[b];
+        }
+      }
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < K * K; ++i) {
@@ -405,7 +679,14 @@ extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const floa
   if (int e = check_dw("dwconv_geo_fwd", B, C, H, W, k)) return e;
   if (B == 0) return 0;
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
-  const unsigned grid = (unsigned)((int64_t)B * C * tiles);
+  const int64_t planes = (int64_t)B * C;
+  if (DWCONV_PLANES && whole_plane_vec4(x, H, W, k)) {     // (k == 5 there)
+    hipLaunchKernelGGL(dwconv_geo_fwd_planes_kernel<5>, dim3((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK)),
+                       dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, H, planes);
+    PD_CHECK_LAUNCH("dwconv_geo_fwd");
+    return 0;
+  }
+  const unsigned grid = (unsigned)(planes * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_fwd_kernel<KK>, dim3(grid), dim3(256), 0,
                                    (hipStream_t)stream, x, w, bias, y, C, H, W, tx, tiles,
                                    whole_plane_vec4(x, H, W, k)));
@@ -418,6 +699,13 @@ extern "C" int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* 
   if (int e = check_dw("dwconv_geo_dgrad", B, C, H, W, k)) return e;
   if (B == 0) return 0;
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
+  if (DWCONV_PLANES && whole_plane_vec4(gy, H, W, k) && (reinterpret_cast<uintptr_t>(gx) & 3) == 0) {
+    const int64_t planes = (int64_t)B * C;
+    hipLaunchKernelGGL(dwconv_geo_dgrad_planes_kernel<5>, dim3((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK)),
+                       dim3(256), 0, (hipStream_t)stream, gy, w, gx, C, H, planes);
+    PD_CHECK_LAUNCH("dwconv_geo_dgrad");
+    return 0;
+  }
   const unsigned grid = (unsigned)((int64_t)B * C * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_dgrad_kernel<KK>, dim3(grid), dim3(256), 0,
                                    (hipStream_t)stream, gy, w, gx, C, H, W, tx, tiles,
@@ -440,8 +728,12 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
   const int chunks = B == 0 ? 1 : wgrad_chunks(B, C, tiles);
   float* partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_wgrad_kernel<KK>, dim3(C * chunks), dim3(256), 0, st, gy,
-                                   x, partial, B, C, H, W, tx, tiles, chunks, whole_plane_vec4(x, H, W, k)));
+  if (DWCONV_PLANES && whole_plane_vec4(x, H, W, k) && (reinterpret_cast<uintptr_t>(gy) & 3) == 0)
+    hipLaunchKernelGGL(dwconv_geo_wgrad_planes_kernel<5>, dim3(C * chunks), dim3(256), 0, st, gy, x, partial, B, C,
+                       H, chunks);
+  else
+    DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_wgrad_kernel<KK>, dim3(C * chunks), dim3(256), 0, st, gy,
+                                     x, partial, B, C, H, W, tx, tiles, chunks, whole_plane_vec4(x, H, W, k)));
   const int n = C * (k * k + 1);
   hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias,
                      C, k * k, chunks);
