@@ -73,7 +73,8 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
                           int mode, int flags, void* workspace, void* stream);
 /* gfield [B,K,H,W] (batch stride gf_bs), gu/gv with batch stride guv_bs.
- * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes. */
+ * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes (with PARADIS_DETERMINISTIC=1 this includes the
+ * 64-bit integer plane the tiled backward accumulates into: 8 bytes per gather point). */
 size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
 int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u, const float* v,
                           float* gfield, float* gu, float* gv,

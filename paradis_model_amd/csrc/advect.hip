@@ -1267,7 +1267,7 @@ sl_advect_bwd_row64(const float* __restrict__ gout, const float* __restrict__ fi
   }
 }
 
-template <int MODE, bool WHOLE, int NTH>
+template <int MODE, bool WHOLE, int NTH, bool DET = false>   // DET: integer global accumulators (deterministic tiled mode)
 __global__ void __launch_bounds__(NTH)
 sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ field,
                      const float* __restrict__ u, const float* __restrict__ v,
@@ -1276,7 +1276,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
                      const float* __restrict__ lon, const float* __restrict__ fmeans,
                      const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles,
-                     int vec4) {
+                     int vec4, unsigned long long* __restrict__ gacc, const unsigned* __restrict__ pmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -1318,7 +1318,10 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
     for (int i = tid; i < npts; i += NTH, itg.next())
       gmaxb = max(gmaxb, abs_bits(GO[(ty0 + itg.yl) * W + tx0 + itg.xl]));
   }
-  const float mxall = reduce_gmax(gmaxb, misc, NTH / 64);
+  float mxall = reduce_gmax(gmaxb, misc, NTH / 64);
+  // deterministic tiled mode: integer global accumulators need ONE scale per plane (its max |cotangent|, a pre-pass)
+  unsigned long long* GA = nullptr;
+  if constexpr (DET) { GA = gacc + (int64_t)plane * P; mxall = __uint_as_float(pmax[plane]); }
   if (WHOLE) {
     if (wave < 2) {
       float* row = win + (wave == 0 ? p : H - 1 + p) * Wp;
@@ -1387,7 +1390,8 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
           geo_src(by + a - p, bx + bb - p, H, W, r, c);
           float val = F[(int64_t)r * W + c];
           if (r == 0) val = m0; else if (r == lastrow) val = m1;
-          atomicAdd(&GF[(int64_t)r * W + c], gval * wy[a] * wx[bb]);
+          if constexpr (DET) atomicAdd(&GA[(int64_t)r * W + c], fixed_from_product((double)(gval * scale * wy[a]), (double)wx[bb]));
+          else atomicAdd(&GF[(int64_t)r * W + c], gval * wy[a] * wx[bb]);
           sxv = fmaf(val, wx[bb], sxv);
           sdx = fmaf(val, dwx[bb], sdx);
         }
@@ -1435,7 +1439,8 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
       if (jj < 0) jj += W;
       int sr, sc;
       geo_src(r - p, jj, H, W, sr, sc);
-      atomicAdd(&GF[(int64_t)sr * W + sc], (float)((double)s * inv));
+      if constexpr (DET) atomicAdd(&GA[(int64_t)sr * W + sc], (unsigned long long)s);   // integer: order-independent
+      else atomicAdd(&GF[(int64_t)sr * W + sc], (float)((double)s * inv));
     }
   }
 }
@@ -1444,7 +1449,7 @@ sl_advect_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ f
 // Backward of the tiled schedule on a separable grid, one wave per 64 columns of a tile row (see
 // sl_advect_fwd_tilerow); window accumulators, flush and the global-atomic fallback as in the generic
 // tiled kernel below.
-template <int MODE>
+template <int MODE, bool DET = false>
 __global__ void __launch_bounds__(TILED_THREADS_BWD, 4)   // four waves per SIMD: <= 128 VGPRs
 sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ field,
                       const float* __restrict__ u, const float* __restrict__ v,
@@ -1452,7 +1457,8 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
                       const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                       const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
                       const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs,
-                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles) {
+                      int64_t uv_bs, int64_t gf_bs, int64_t guv_bs, int halo, int tiles_x, int tiles,
+                      unsigned long long* __restrict__ gacc, const unsigned* __restrict__ pmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = Interp<MODE>::NT, NTH = TILED_THREADS_BWD;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -1491,7 +1497,10 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
   unsigned gmaxb = max(abs_bits(gm0), abs_bits(gm1));
   for (int yl = tl.rs; yl < th; yl += tl.rstep)
     gmaxb = max(gmaxb, abs_bits(srow(GO + (ty0 + yl) * W + tl.cbase)[tl.lx]));
-  const float mxall = reduce_gmax(gmaxb, misc, NTH / 64);    // its barrier also closes the staging
+  float mxall = reduce_gmax(gmaxb, misc, NTH / 64);    // its barrier also closes the staging
+  // deterministic mode: integer global accumulators, ONE scale per plane (its max |cotangent|, a pre-pass)
+  unsigned long long* GA = nullptr;
+  if constexpr (DET) { GA = gacc + (int64_t)plane * P; mxall = __uint_as_float(pmax[plane]); }
   float scale, inv_scale;
   fixed_point_scale(mxall, scale, inv_scale);
 
@@ -1525,7 +1534,8 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
         geo_src(by + a - p, bx + bb - p, H, W, r, c);
         float val = F[(int64_t)r * W + c];
         if (r == 0) val = m0; else if (r == lastrow) val = m1;
-        atomicAdd(&GF[(int64_t)r * W + c], gval * wy[a] * wx[bb]);
+        if constexpr (DET) atomicAdd(&GA[(int64_t)r * W + c], fixed_from_product((double)(gval * scale * wy[a]), (double)wx[bb]));
+        else atomicAdd(&GF[(int64_t)r * W + c], gval * wy[a] * wx[bb]);
         sxv = fmaf(val, wx[bb], sxv);
         sdx = fmaf(val, dwx[bb], sdx);
       }
@@ -1589,7 +1599,8 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
           const int ii = r - p;
           const int sr = ii < 0 ? -ii : (ii >= H ? 2 * (H - 1) - ii : ii);
           const int sc = (ii < 0 || ii >= H) ? jm : jj;
-          atomicAdd(&GF[(int64_t)sr * W + sc], (float)((double)sv * inv));
+          if constexpr (DET) atomicAdd(&GA[(int64_t)sr * W + sc], (unsigned long long)sv);   // integer: order-independent
+          else atomicAdd(&GF[(int64_t)sr * W + sc], (float)((double)sv * inv));
         }
       }
     }
@@ -1607,6 +1618,32 @@ pole_row_means(const float* __restrict__ src, float* __restrict__ means, int pla
   const float* row = src + (int64_t)b * bs + (int64_t)k * H * W + (which ? (int64_t)(H - 1) * W : 0);
   const float m = wave_row_mean(row, W);
   if ((threadIdx.x & 63) == 0) means[w] = m;
+}
+
+// ---- deterministic tiled backward (PARADIS_DETERMINISTIC=1): per-plane max |cotangent| and the conversion of the
+// integer accumulators; integer global atomics are associative, so the field gradient no longer depends on the order
+// in which the tiles flush
+__global__ void __launch_bounds__(256)
+plane_absmax_kernel(const float* __restrict__ src, unsigned* __restrict__ pmax, int K, int P, int64_t bs) {
+  __shared__ unsigned red[4];
+  const int plane = blockIdx.x, b = plane / K, k = plane - b * K;
+  const float* s = src + (int64_t)b * bs + (int64_t)k * P;
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < P; i += 256) m = max(m, abs_bits(s[i]));
+  m = wave_umax_lane63(m);
+  if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) pmax[plane] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+__global__ void __launch_bounds__(256)
+fixed_to_float_kernel(const unsigned long long* __restrict__ gacc, const unsigned* __restrict__ pmax,
+                      float* __restrict__ dst, int P, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float scale, inv;
+    fixed_point_scale(__uint_as_float(pmax[i / P]), scale, inv);
+    dst[i] = (float)((double)(long long)gacc[i] * (double)inv);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -1696,10 +1733,14 @@ bool use_row64(int W, int flags, const float* lat_cells) { return W == 64 && sep
 
 }  // namespace
 
+// pole-row means of field and cotangent (tiled schedule); in deterministic mode also the per-plane max |cotangent|
+// and the 64-bit integer plane the tiles accumulate into
 extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W) {
-  (void)H; (void)W;
-  return (size_t)B * K * 4 * sizeof(float) + 256;
+  size_t n = (size_t)B * K * 4 * sizeof(float) + 256;
+  if (paradis_deterministic()) n += (size_t)B * K * sizeof(unsigned) + 16 + (size_t)B * K * H * W * 8;
+  return n;
 }
+inline int stream_blocks_adv(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 256 * 32); }
 
 #define ADV_LAUNCH(KERNEL, WHOLE_, NTH_, grid, lds, ...)                                                  \
   do {                                                                                                    \
@@ -1825,7 +1866,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
     else
       ADV_LAUNCH(sl_advect_bwd_kernel, true, 256, planes, whole, gout, field, u, v, gfield, gu, gv, sin_lat,
                  cos_lat, lon, (const float*)nullptr, (const float*)nullptr, K, g, go_bs, f_bs, uv_bs,
-                 gf_bs, guv_bs, 0, 1, 1, vec4);
+                 gf_bs, guv_bs, 0, 1, 1, vec4, (unsigned long long*)nullptr, (const unsigned*)nullptr);
     PD_CHECK_LAUNCH("sl_advect_bwd");
     return 0;
   }
@@ -1836,7 +1877,17 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   const int mean_blocks = (planes * 2 * 64 + 255) / 256;
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, field, fmeans, planes, K, H, W, f_bs);
   hipLaunchKernelGGL(pole_row_means, dim3(mean_blocks), dim3(256), 0, st, gout, gmeans, planes, K, H, W, go_bs);
-  if (pd_zero_async(gfield, (size_t)planes * P * sizeof(float), st) != hipSuccess) {
+  // PARADIS_DETERMINISTIC=1: the tiles add 64-bit fixed-point values (one power-of-two scale per plane) into an integer
+  // plane in the workspace, converted once at the end - no float atomics on the field gradient
+  unsigned* pmax = nullptr;
+  unsigned long long* gacc = nullptr;
+  if (paradis_deterministic()) {
+    pmax = reinterpret_cast<unsigned*>(gmeans + (size_t)planes * 2);
+    gacc = reinterpret_cast<unsigned long long*>(
+        (reinterpret_cast<uintptr_t>(pmax + planes) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(plane_absmax_kernel, dim3(planes), dim3(256), 0, st, gout, pmax, K, P, go_bs);
+  }
+  if (pd_zero_async(gacc ? (void*)gacc : (void*)gfield, (size_t)planes * P * (gacc ? 8 : 4), st) != hipSuccess) {
     paradis_set_error("sl_advect_bwd: memset failed");
     return 2;
   }
@@ -1847,32 +1898,40 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   PD_REQUIRE(lds <= 160 * 1024, "sl_advect_bwd: window does not fit LDS");
   static PerDeviceOnce once;
   if (once.first()) {
-    if (reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS") ||
-        reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD>, "sl_advect_bwd: cannot reserve LDS"))
+    if (reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_BWD, false>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD, false>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BICUBIC, false, TILED_THREADS_BWD, true>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_BWD, true>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC, false>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR, false>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC, true>, "sl_advect_bwd: cannot reserve LDS") ||
+        reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR, true>, "sl_advect_bwd: cannot reserve LDS"))
       return 2;
   }
+  const dim3 tgrid((unsigned)(planes * tiles)), tblock(TILED_THREADS_BWD);
+#define TILED_BWD_ARGS(...) __VA_ARGS__, (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles
+#define LAUNCH_TILEROW(M, D)                                                                                     \
+  hipLaunchKernelGGL((sl_advect_bwd_tilerow<M, D>), tgrid, tblock, lds, st,                                        \
+                     TILED_BWD_ARGS(gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon), gacc,    \
+                     (const unsigned*)pmax)
+#define LAUNCH_TILED(M, D)                                                                                       \
+  hipLaunchKernelGGL((sl_advect_bwd_kernel<M, false, TILED_THREADS_BWD, D>), tgrid, tblock, lds, st,               \
+                     TILED_BWD_ARGS(gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon), vec4, gacc,         \
+                     (const unsigned*)pmax)
+  const bool cubic = mode == PARADIS_INTERP_BICUBIC;
   if (separable(flags, lat_cells)) {
-    static PerDeviceOnce once_row;
-    if (once_row.first()) {
-      if (reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC>, "sl_advect_bwd: cannot reserve LDS") ||
-          reserve_lds(&sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR>, "sl_advect_bwd: cannot reserve LDS"))
-        return 2;
-    }
-    if (mode == PARADIS_INTERP_BICUBIC)
-      hipLaunchKernelGGL((sl_advect_bwd_tilerow<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * tiles)),
-                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells,
-                         lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
-                         tx, tiles);
-    else
-      hipLaunchKernelGGL((sl_advect_bwd_tilerow<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * tiles)),
-                         dim3(TILED_THREADS_BWD), lds, st, gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells,
-                         lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, halo,
-                         tx, tiles);
+    if (gacc) { if (cubic) LAUNCH_TILEROW(PARADIS_INTERP_BICUBIC, true); else LAUNCH_TILEROW(PARADIS_INTERP_BILINEAR, true); }
+    else { if (cubic) LAUNCH_TILEROW(PARADIS_INTERP_BICUBIC, false); else LAUNCH_TILEROW(PARADIS_INTERP_BILINEAR, false); }
   } else {
-    ADV_LAUNCH(sl_advect_bwd_kernel, false, TILED_THREADS_BWD, (unsigned)(planes * tiles), lds, gout, field, u, v, gfield,
-               gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, K, g, go_bs,
-               f_bs, uv_bs, gf_bs, guv_bs, halo, tx, tiles, vec4);
+    if (gacc) { if (cubic) LAUNCH_TILED(PARADIS_INTERP_BICUBIC, true); else LAUNCH_TILED(PARADIS_INTERP_BILINEAR, true); }
+    else { if (cubic) LAUNCH_TILED(PARADIS_INTERP_BICUBIC, false); else LAUNCH_TILED(PARADIS_INTERP_BILINEAR, false); }
   }
+#undef LAUNCH_TILED
+#undef LAUNCH_TILEROW
+#undef TILED_BWD_ARGS
+  if (gacc)
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3(stream_blocks_adv((int64_t)planes * P)), dim3(256), 0, st,
+                       (const unsigned long long*)gacc, (const unsigned*)pmax, gfield, P, (int64_t)planes * P);
   hipLaunchKernelGGL(pole_rows_to_mean, dim3(mean_blocks), dim3(256), 0, st, gfield, planes, K, H, W, gf_bs);
   PD_CHECK_LAUNCH("sl_advect_bwd(tiled)");
   return 0;
