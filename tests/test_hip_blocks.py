@@ -182,6 +182,25 @@ def test_channel_norm_skip_output_fuses_residual_gradient(ops):
     assert torch.equal(xd2.grad.cpu(), ct_s)
 
 
+@pytest.mark.parametrize("C1,C2,H,W", [(160, 32, 9, 16), (1024, 128, 5, 8), (160, 31, 9, 16), (161, 31, 8, 16)])
+def test_channel_norm_virtual_concat_wide(ops, C1, C2, H, W):
+    """the virtual concat at the widths of the reaction block: even C1, C2 take the two-workgroups-per-CU forward
+    kernel (scalar row bases, a ragged last pixel tile at 9x16), odd ones the generic kernel"""
+    x1, x2 = seeded(1, 2, C1, H, W, scale=2.0) + 0.5, seeded(2, 2, C2, H, W)
+    C = C1 + C2
+    w, b = 1.0 + seeded(3, C, scale=0.1), seeded(4, C, scale=0.1)
+    ct = seeded(5, 2, C, H, W)
+    r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    y = O.channel_norm(torch.cat([r1, r2], 1), w, b)
+    y.backward(ct)
+    d1, d2 = _dev(x1), _dev(x2)
+    yd = ops.channel_norm(d1, w.cuda(), b.cuda(), 1e-5, d2)
+    yd.backward(ct.cuda())
+    _cmp(yd, y, FWD, "y")
+    _cmp(d1.grad, r1.grad, BWD, "gx1")
+    _cmp(d2.grad, r2.grad, BWD, "gx2")
+
+
 def test_channel_norm_virtual_concat_and_golden(ops):
     x1, x2 = seeded(1, 2, 24, 8, 16), seeded(2, 2, 8, 8, 16, scale=2.0)
     w, b = 1.0 + seeded(3, 32, scale=0.1), seeded(4, 32, scale=0.1)
