@@ -35,17 +35,20 @@ extern "C" {
 #define PARADIS_INTERP_BICUBIC 2
 /* `flags` of paradis_sl_advect_{fwd,bwd}.  0 = automatic schedule: the whole padded plane in LDS when it
  * fits 64 KiB (one wave per latitude row when W == 64 and PARADIS_ADVECT_SEPARABLE is set), otherwise
- * 128-column tiles with a halo and an L2 path for taps outside the window.
+ * a windowed schedule with an L2 path for taps outside the window: with PARADIS_ADVECT_SEPARABLE 128-column strips
+ * walked top to bottom through a ring of padded rows in LDS (round 4), otherwise 128-column tiles with a halo.
  *   bit 0  PARADIS_ADVECT_GENERIC   whole-plane schedule with per-point table loads even when W == 64
- *   bit 1  PARADIS_ADVECT_TILED     tiled schedule regardless of the plane size
+ *   bit 1  PARADIS_ADVECT_TILED     windowed schedule regardless of the plane size
  *   bit 2  PARADIS_ADVECT_SEPARABLE the caller vouches that sin_lat/cos_lat are constant along a row and
  *                                   lon along a column (every regular lat-lon grid)
- *   bits 8-15  window halo of the tiled schedule (0 = built-in default, else halo + 1)
+ *   bit 3  PARADIS_ADVECT_TILES     diagnostic: the 64 x 128 / 16 x 128 tile schedule of rounds 2-3 instead of strips
+ *   bits 8-15  window halo in longitude of the windowed schedules (0 = built-in default, else halo + 1)
  *   bits 16-23 the same for the backward kernel only */
 #define PARADIS_ADVECT_AUTO 0
 #define PARADIS_ADVECT_GENERIC 1
 #define PARADIS_ADVECT_TILED 2
 #define PARADIS_ADVECT_SEPARABLE 4
+#define PARADIS_ADVECT_TILES 8
 #define PARADIS_ADVECT_HALO_SHIFT 8
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)

@@ -1607,6 +1607,525 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
   }
 }
 
+// ======================================================================================
+// strip schedule (round 4): large planes on a separable grid (configs[3], configs[4])
+// ======================================================================================
+// A workgroup owns a STRIP of 128 arrival columns of one plane and walks down ALL its rows, eight per step.  The window
+// of the padded plane it samples from is a RING of R padded rows x (128 + 2 hx + NT) columns in LDS: while the eight
+// arrival rows of step s are computed against rows [lo(s), lo(s) + R - 8), the eight rows that enter the window at step
+// s + 1 are written into the ring slots of the eight rows that left it at step s - 1 (their global loads were issued a
+// step earlier and sit in registers), so one barrier per step separates readers and writers and staging overlaps with
+// the arithmetic.  What this buys over the 64 x 128 / 16 x 128 tiles of rounds 1-3:
+//   * a window cell is staged once per strip, not once per tile row band: 1.19 (hx = 10) to 1.5 (hx = 32) cells per
+//     arrival point instead of 1.5-3.0 - the latitude halo costs LDS rows, not HBM bytes - and the halos can be
+//     asymmetric: displacements are a few rows in latitude but tens of columns in longitude next to the poles
+//     (tools/adv_disp_stats.py: in the default model at 721 x 1440 |dy| stays below 22 rows for 99 % of the points
+//     while 30 % of them move more than 16 columns);
+//   * backward: the accumulator rows leave the ring complete - one float atomic per window cell of the strip,
+//     1.19 per point instead of 3.0 - and the power-of-two scale of the 64-bit fixed-point sums follows the running
+//     maximum of the cotangent (a rescale of the ring when a step raises it) instead of a pre-pass over the cotangent;
+//   * taps that leave the window go to L2 with the row / column maps of the tap block evaluated once per point
+//     (4 + 4 index computations instead of 16).
+constexpr int STRIP_W = 128, STRIP_ROWS = 8, STRIP_THREADS = 512, STRIP_CH = 4;   // CH: 64-column chunks of a window row
+constexpr int STRIP_MAX_WS = 64 * STRIP_CH;
+
+// lane's source columns of the window columns lane, lane + 64, ...: image column in the low half, the column of the
+// over-the-pole rows (shifted by W / 2) in the high half
+struct StripCols { unsigned pk[STRIP_CH]; };
+__device__ __forceinline__ StripCols strip_cols(int wx0, int WS, int W, int p, unsigned lane) {
+  StripCols c;
+#pragma unroll
+  for (int i = 0; i < STRIP_CH; ++i) {
+    const int lc = min((int)lane + 64 * i, WS - 1);
+    int jj = (wx0 + lc - p) % W;
+    if (jj < 0) jj += W;
+    int jm = jj + (W >> 1);
+    if (jm >= W) jm -= W;
+    c.pk[i] = (unsigned)jj | ((unsigned)jm << 16);
+  }
+  return c;
+}
+
+// source row of padded row pr (wave-uniform): valid = inside the padded plane, mir = beyond a pole
+struct StripRow { int sr; bool valid, mir; };
+__device__ __forceinline__ StripRow strip_row(int pr, int H, int p) {
+  const int Hp = H + 2 * p;
+  StripRow r;
+  r.valid = pr >= 0 && pr < Hp;
+  const int ii = min(max(pr, 0), Hp - 1) - p;
+  r.mir = ii < 0 || ii >= H;
+  r.sr = ii < 0 ? -ii : (ii >= H ? 2 * (H - 1) - ii : ii);
+  return r;
+}
+
+__device__ __forceinline__ void strip_load_row(const float* __restrict__ F, int pr, int H, int W, int p, const StripCols& cs,
+                                               int nch, float (&pre)[STRIP_CH]) {
+  const StripRow r = strip_row(pr, H, p);
+  const global_ptr<const float> row = srow(F + (int64_t)r.sr * W);
+#pragma unroll
+  for (int i = 0; i < STRIP_CH; ++i)
+    if (i < nch) pre[i] = row[r.mir ? (cs.pk[i] >> 16) : (cs.pk[i] & 0xffffu)];
+}
+
+__device__ __forceinline__ void strip_store_row(float* __restrict__ ring, int pr, int RMASK, int WS, int H, int p, float m0,
+                                                float m1, unsigned lane, int nch, const float (&pre)[STRIP_CH]) {
+  const StripRow r = strip_row(pr, H, p);
+  float* dst = ring + (pr & RMASK) * WS;
+#pragma unroll
+  for (int i = 0; i < STRIP_CH; ++i)
+    if (i < nch) {
+      float v = pre[i];
+      if (r.sr == 0) v = m0;                 // rows 0 and H-1 enter as their longitudinal means (advection.py:100-114)
+      if (r.sr == H - 1) v = m1;
+      if (!r.valid) v = 0.f;
+      const int lc = (int)lane + 64 * i;
+      if (lc < WS) dst[lc] = v;
+    }
+}
+
+// lanes of a wave inside a 128-column strip: waves 2r, 2r+1 own the two 64-column halves of a row
+struct StripLane {
+  int cbase; unsigned lx; bool active;
+  __device__ __forceinline__ StripLane(int half, unsigned lane, int x0, int tw, int W) {
+    const int first = half * 64;
+    active = first + (int)lane < tw;
+    cbase = min(x0 + first, W - 1);
+    lx = min(lane, (unsigned)max(tw - 1 - first, 0));
+  }
+};
+
+// column maps of a tap block at clamped origin column bx (padded coordinates): col[b] / colm[b] = source column of a
+// plain / over-the-pole row
+template <int NT>
+struct TapCols { int col[NT], colm[NT]; };
+template <int NT>
+__device__ __forceinline__ void tap_cols(int bx, int W, int p, TapCols<NT>& m) {
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    int j = bx + b - p;
+    j += j < 0 ? W : 0;
+    j -= j >= W ? W : 0;
+    int jm = j + (W >> 1);
+    jm -= jm >= W ? W : 0;
+    m.col[b] = j; m.colm[b] = jm;
+  }
+}
+// source row of padded tap row pr: returns the row offset sr * W; mir = beyond a pole, pole = 1 / 2 for rows 0 / H-1
+__device__ __forceinline__ int tap_row(int pr, int H, int W, int p, bool& mir, int& pole) {
+  const int ii = pr - p;
+  mir = ii < 0 || ii >= H;
+  const int sr = ii < 0 ? -ii : (ii >= H ? 2 * (H - 1) - ii : ii);
+  pole = sr == 0 ? 1 : (sr == H - 1 ? 2 : 0);
+  return sr * W;
+}
+
+// value of a point whose tap block leaves the window: all taps from global memory (L2) through the a1 map, two tap
+// rows in flight at a time (the registers of this path set the occupancy of the whole kernel)
+template <int MODE>
+__device__ __forceinline__ float gather_global(const float* __restrict__ F, float ix, float iy, int H, int W, int p,
+                                               float m0, float m1) {
+  constexpr int NT = Interp<MODE>::NT;
+  float tx, ty, wx[NT], wy[NT];
+  int bx, by, sx, sy;
+  tap_origin<MODE>(ix, iy, H + 2 * p, W + 2 * p, bx, by, sx, sy, tx, ty);
+  Interp<MODE>::weights(tx, wx);
+  Interp<MODE>::weights(ty, wy);
+  shift_weights<NT>(wx, sx);
+  shift_weights<NT>(wy, sy);
+  TapCols<NT> m;
+  tap_cols<NT>(bx, W, p, m);
+  float acc = 0.f;
+#pragma unroll
+  for (int a0 = 0; a0 < NT; a0 += 2) {
+    float val[2][NT];
+    int pole[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bool mir;
+      const int ro = tap_row(by + a0 + q, H, W, p, mir, pole[q]);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) val[q][b] = F[ro + (mir ? m.colm[b] : m.col[b])];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float rowacc = 0.f;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        const float t = pole[q] == 1 ? m0 : (pole[q] == 2 ? m1 : val[q][b]);
+        rowacc = fmaf(t, wx[b], rowacc);
+      }
+      acc = fmaf(rowacc, wy[a0 + q], acc);
+    }
+    asm volatile("" ::: "memory");      // keeps the next pair's loads behind this pair's use
+  }
+  return acc;
+}
+
+// tap block of a point against the ring window: fraction, plane clamp, window-relative column (the window may
+// straddle the date line), padded row of tap row 0.  Returns true when the NT x NT block lies inside the resident
+// rows [rlo, rhi] x the window columns and the plane clamp did not move it.  All values are integers below 2^24 held
+// in floats; r0 / c0 = padded row / window column of tap (0, 0).
+template <int MODE>
+__device__ __forceinline__ bool tap_block_ring(float ix, float iy, float Hpf, float Wpf, float Wf, float wx0f, float WSf,
+                                               float rlof, float rhif, float& tx, float& ty, int& r0, int& c0) {
+  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
+  tx = __builtin_amdgcn_fractf(ix);
+  ty = __builtin_amdgcn_fractf(iy);
+  const float x0f = ix - tx, y0f = iy - ty;
+  const float xc = __builtin_amdgcn_fmed3f(x0f, (float)(-OFF0), Wpf - (float)(NT + OFF0));
+  const float yc = __builtin_amdgcn_fmed3f(y0f, (float)(-OFF0), Hpf - (float)(NT + OFF0));
+  float rx = (xc + (float)OFF0) - wx0f;
+  const float ry = yc + (float)OFF0;
+  rx = rx < 0.f ? rx + Wf : (rx > WSf - (float)NT ? rx - Wf : rx);
+  const float rxc = __builtin_amdgcn_fmed3f(rx, 0.f, WSf - (float)NT);
+  const float ryc = __builtin_amdgcn_fmed3f(ry, rlof, rhif - (float)(NT - 1));
+  r0 = (int)ryc;
+  c0 = (int)rxc;
+  return xc == x0f && yc == y0f && rxc == rx && ryc == ry;
+}
+
+// geometry of the ring: rows resident while the arrival rows [8 s, 8 s + 8) are computed
+template <int MODE, int R>
+struct StripRing {
+  static constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
+  static constexpr int RW = R - STRIP_ROWS;                      // resident rows
+  static constexpr int HYL = (RW - (STRIP_ROWS - 1 + NT)) / 2;     // latitude halo below (rows); above: the rest
+  static __device__ __forceinline__ int lo(int s, int p) { return STRIP_ROWS * s + p + OFF0 - HYL; }
+};
+
+template <int MODE, int R>
+__global__ void __launch_bounds__(STRIP_THREADS)
+sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
+                    float* __restrict__ out, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                    const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
+                    int K, AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int hx, int strips) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using Ring = StripRing<MODE, R>;
+  constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
+  const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x / strips, strip = blockIdx.x - plane * strips;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
+  const int x0 = strip * STRIP_W, tw = min(STRIP_W, W - x0);
+  const int WS = STRIP_W + 2 * hx + NT, wx0 = x0 + p - hx, nch = (WS + 63) >> 6;
+  float* ring = smem;
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  const StripLane tl(wave & 1, lane, x0, tw, W);
+  const int rw = wave >> 1;                          // this wave's arrival rows of a step: rw and rw + 4
+  const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
+  const StripCols cs = strip_cols(wx0, WS, W, p, lane);
+
+  float qu[2], qv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = min(rw + 4 * j, H - 1) * W + tl.cbase;
+    qu[j] = srow(U + idx)[tl.lx]; qv[j] = srow(V + idx)[tl.lx];
+  }
+  const float lonc = lon_cells(srow(lon + tl.cbase)[tl.lx], g);
+
+  // initial window: rows [lo(0), lo(0) + RW), two rounds of eight rows in flight
+  float pre[STRIP_CH], pre2[STRIP_CH];
+  const int lo0 = Ring::lo(0, p);
+  for (int r8 = 0; r8 < RW; r8 += 2 * STRIP_ROWS) {
+    strip_load_row(F, lo0 + r8 + wave, H, W, p, cs, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_load_row(F, lo0 + r8 + STRIP_ROWS + wave, H, W, p, cs, nch, pre2);
+    strip_store_row(ring, lo0 + r8 + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_store_row(ring, lo0 + r8 + STRIP_ROWS + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre2);
+  }
+  strip_load_row(F, lo0 + RW + wave, H, W, p, cs, nch, pre);      // the rows that enter at step 1
+  __syncthreads();
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp, Wf = (float)W, wx0f = (float)wx0, WSf = (float)WS;
+  for (int s = 0; s < nsteps; ++s) {
+    const int lo = Ring::lo(s, p);
+    // rows [lo + RW, lo + R): ring slots nobody reads during this step
+    strip_store_row(ring, lo + RW + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (s + 1 < nsteps) strip_load_row(F, lo + R + wave, H, W, p, cs, nch, pre);
+    const float rlof = (float)lo, rhif = (float)(lo + RW - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int y = STRIP_ROWS * s + rw + 4 * j;          // wave-uniform
+      const float cu = qu[j], cv = qv[j];
+      {
+        const int idx = min(y + STRIP_ROWS, H - 1) * W + tl.cbase;
+        qu[j] = srow(U + idx)[tl.lx]; qv[j] = srow(V + idx)[tl.lx];
+      }
+      if (y < H) {
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+        float ix, iy, tx, ty;
+        departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
+        int r0, c0;
+        const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
+        float acc;
+        if (fast) {
+          float wx[NT], wy[NT];
+          Interp<MODE>::weights(tx, wx);
+          Interp<MODE>::weights(ty, wy);
+          acc = 0.f;
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            const float* base = ring + ((r0 + a) & RMASK) * WS + c0;
+            float rowacc = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[bb], wx[bb], rowacc);
+            acc = fmaf(rowacc, wy[a], acc);
+          }
+        } else {
+          acc = gather_global<MODE>(F, ix, iy, H, W, p, m0, m1);
+        }
+        if (tl.active) srow(O + y * W + tl.cbase)[tl.lx] = acc;
+      }
+    }
+    // raw barrier: __syncthreads() would also wait for this step's stores and the prefetches (s_waitcnt vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
+// field gradient and coordinate gradients of a point whose tap block leaves the window: global atomics on the field
+// gradient (float, or the integer plane of the deterministic mode), taps from global memory, one tap row at a time
+template <int MODE, bool DET>
+__device__ __forceinline__ void scatter_global(const float* __restrict__ F, float* __restrict__ GF,
+                                               unsigned long long* __restrict__ GA, float ix, float iy, int H, int W,
+                                               int p, float m0, float m1, float gval, float scale, float& gix, float& giy) {
+  constexpr int NT = Interp<MODE>::NT;
+  float tx, ty, wx[NT], wy[NT], dwx[NT], dwy[NT];
+  int bx, by, sx, sy;
+  tap_origin<MODE>(ix, iy, H + 2 * p, W + 2 * p, bx, by, sx, sy, tx, ty);
+  Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+  Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+  shift_weights<NT>(wx, sx); shift_weights<NT>(dwx, sx);
+  shift_weights<NT>(wy, sy); shift_weights<NT>(dwy, sy);
+  TapCols<NT> m;
+  tap_cols<NT>(bx, W, p, m);
+  gix = 0.f; giy = 0.f;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    bool mir;
+    int pole;
+    const int ro = tap_row(by + a, H, W, p, mir, pole);
+    float val[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) val[b] = F[ro + (mir ? m.colm[b] : m.col[b])];
+    float sxv = 0.f, sdx = 0.f;
+    const float gwy = gval * wy[a];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int cell = ro + (mir ? m.colm[b] : m.col[b]);
+      const float t = pole == 1 ? m0 : (pole == 2 ? m1 : val[b]);
+      if constexpr (DET) atomicAdd(&GA[cell], fixed_from_product((double)(gwy * scale), (double)wx[b]));
+      else atomicAdd(&GF[cell], gwy * wx[b]);
+      sxv = fmaf(t, wx[b], sxv);
+      sdx = fmaf(t, dwx[b], sdx);
+    }
+    gix = fmaf(wy[a], sdx, gix);
+    giy = fmaf(dwy[a], sxv, giy);
+    asm volatile("" ::: "memory");
+  }
+}
+
+// exponent e of the fixed-point scale 2^(40 - e) for a bound with bit pattern `bits` on |cotangent|: |g| < 2^e;
+// 255 = a non-finite cotangent (every sum becomes NaN), -128 = all zero so far
+__device__ __forceinline__ int fixed_exponent(unsigned bits) {
+  if (bits >= 0x7f800000u) return 255;
+  if (bits == 0) return -128;
+  int e = (int)(bits >> 23) - 126;                  // 2^(e-1) <= |g| < 2^e for normal numbers
+  return e < -80 ? -80 : (e > 80 ? 80 : e);
+}
+
+template <int MODE, int R, bool DET>
+__global__ void __launch_bounds__(STRIP_THREADS, 4)      // four waves per SIMD: <= 128 registers
+sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ field, const float* __restrict__ u,
+                    const float* __restrict__ v, float* __restrict__ gfield, float* __restrict__ gu,
+                    float* __restrict__ gv, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                    const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
+                    const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
+                    int64_t gf_bs, int64_t guv_bs, int hx, int strips, unsigned long long* __restrict__ gacc,
+                    const unsigned* __restrict__ pmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using Ring = StripRing<MODE, R>;
+  constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
+  const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x / strips, strip = blockIdx.x - plane * strips;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* GO = gout + (int64_t)b * go_bs + (int64_t)k * P;
+  float* GF = gfield + (int64_t)b * gf_bs + (int64_t)k * P;
+  float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
+  float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
+  unsigned long long* GA = DET ? gacc + (int64_t)plane * P : nullptr;
+  const int x0 = strip * STRIP_W, tw = min(STRIP_W, W - x0);
+  const int WS = STRIP_W + 2 * hx + NT, wx0 = x0 + p - hx, nch = (WS + 63) >> 6;
+  const int wn = R * WS;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);    // [R][WS] fixed-point sums
+  float* ring = smem + 2 * wn;                                               // [R][WS] field window
+  unsigned* stepmax = reinterpret_cast<unsigned*>(ring + wn);                // [3] max |cotangent| bits of a step
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
+  const StripLane tl(wave & 1, lane, x0, tw, W);
+  const int rw = wave >> 1;
+  const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
+  const StripCols cs = strip_cols(wx0, WS, W, p, lane);
+
+  float qu[2], qv[2], qg[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = min(rw + 4 * j, H - 1) * W + tl.cbase;
+    qu[j] = srow(U + idx)[tl.lx]; qv[j] = srow(V + idx)[tl.lx]; qg[j] = srow(GO + idx)[tl.lx];
+  }
+  const float lonc = lon_cells(srow(lon + tl.cbase)[tl.lx], g);
+
+  for (int i = tid; i < wn; i += STRIP_THREADS) acc[i] = 0ull;
+  if (tid < 3) stepmax[tid] = 0u;
+  float pre[STRIP_CH], pre2[STRIP_CH];
+  const int lo0 = Ring::lo(0, p);
+  for (int r8 = 0; r8 < RW; r8 += 2 * STRIP_ROWS) {
+    strip_load_row(F, lo0 + r8 + wave, H, W, p, cs, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_load_row(F, lo0 + r8 + STRIP_ROWS + wave, H, W, p, cs, nch, pre2);
+    strip_store_row(ring, lo0 + r8 + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_store_row(ring, lo0 + r8 + STRIP_ROWS + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre2);
+  }
+  strip_load_row(F, lo0 + RW + wave, H, W, p, cs, nch, pre);
+  __syncthreads();
+  // bound on |cotangent| of step 0 (the pole rows' means ride along: they are what pole rows scatter)
+  {
+    unsigned mb = max(abs_bits(gm0), abs_bits(gm1));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mb = max(mb, abs_bits(qg[j]));
+    mb = wave_umax_lane63(mb);
+    if (lane == 63) atomicMax(&stepmax[0], mb);
+  }
+  __syncthreads();
+
+  int ecur = DET ? fixed_exponent(pmax[plane]) : -128;      // exponent of the ring's accumulators (wave-uniform)
+  float scale = 0.f, inv_scale = 0.f;
+  auto set_scale = [&](int e) {
+    ecur = e;
+    if (e == 255) { scale = 0.f; inv_scale = NAN; }
+    else if (e == -128) { scale = 0.f; inv_scale = 0.f; }
+    else { scale = ldexpf(1.0f, 40 - e); inv_scale = ldexpf(1.0f, e - 40); }
+  };
+  set_scale(ecur);
+
+  // flush padded row pr of the ring (complete: no later arrival row reaches it) and clear its accumulators
+  auto flush_row = [&](int pr) {
+    const StripRow r = strip_row(pr, H, p);
+    unsigned long long* arow = acc + (pr & RMASK) * WS;
+    const double inv = (double)inv_scale;
+#pragma unroll
+    for (int i = 0; i < STRIP_CH; ++i)
+      if (i < nch) {
+        const int lc = (int)lane + 64 * i;
+        if (lc < WS) {
+          const long long sv = (long long)arow[lc];
+          if (sv != 0) {
+            arow[lc] = 0ull;
+            if (r.valid) {
+              const int cell = r.sr * W + (int)(r.mir ? (cs.pk[i] >> 16) : (cs.pk[i] & 0xffffu));
+              if constexpr (DET) atomicAdd(&GA[cell], (unsigned long long)sv);
+              else atomicAdd(&GF[cell], (float)((double)sv * inv));
+            }
+          }
+        }
+      }
+  };
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp, Wf = (float)W, wx0f = (float)wx0, WSf = (float)WS;
+  for (int s = 0; s < nsteps; ++s) {
+    const int lo = Ring::lo(s, p);
+    if constexpr (!DET) {
+      // the scale follows the running maximum of |cotangent|: a step that raises it shifts every accumulator of the
+      // ring down to the new exponent (rare: once per strip on smooth cotangents)
+      const int e = fixed_exponent(stepmax[s % 3]);
+      if (e > ecur) {
+        if (ecur != -128 && e != 255) {
+          const int sh = min(e - ecur, 63);
+          for (int i = tid; i < wn; i += STRIP_THREADS) acc[i] = (unsigned long long)((long long)acc[i] >> sh);
+        }
+        set_scale(e);
+        __syncthreads();
+      }
+      if (tid == 0) stepmax[(s + 2) % 3] = 0u;
+    }
+    // rows that left the window after step s - 1 go out; the rows entering at step s + 1 take their slots
+    if (s > 0) flush_row(lo - STRIP_ROWS + wave);
+    strip_store_row(ring, lo + RW + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (s + 1 < nsteps) strip_load_row(F, lo + R + wave, H, W, p, cs, nch, pre);
+    const float rlof = (float)lo, rhif = (float)(lo + RW - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int y = STRIP_ROWS * s + rw + 4 * j;          // wave-uniform
+      const float cu = qu[j], cv = qv[j], cgo = qg[j];
+      {
+        const int idx = min(y + STRIP_ROWS, H - 1) * W + tl.cbase;
+        qu[j] = srow(U + idx)[tl.lx]; qv[j] = srow(V + idx)[tl.lx]; qg[j] = srow(GO + idx)[tl.lx];
+      }
+      if (y < H) {
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+        float ix, iy, tx, ty;
+        DepState st;
+        departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, &st);
+        int r0, c0;
+        const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
+        const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
+        float gix = 0.f, giy = 0.f;
+        if (tl.active) {
+          if (fast) {
+            float wx[NT], wy[NT], dwx[NT], dwy[NT];
+            Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+            Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+            const float gs_ = gval * scale;
+            double wxd[NT];
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) wxd[bb] = (double)wx[bb];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+              const int rb = ((r0 + a) & RMASK) * WS + c0;
+              float sxv = 0.f, sdx = 0.f;
+              const double gwy = (double)(gs_ * wy[a]);
+#pragma unroll
+              for (int bb = 0; bb < NT; ++bb) {
+                const float val = ring[rb + bb];
+                atomicAdd(&acc[rb + bb], fixed_from_product(gwy, wxd[bb]));
+                sxv = fmaf(val, wx[bb], sxv);
+                sdx = fmaf(val, dwx[bb], sdx);
+              }
+              gix = fmaf(wy[a], sdx, gix);
+              giy = fmaf(dwy[a], sxv, giy);
+            }
+          } else {
+            scatter_global<MODE, DET>(F, GF, GA, ix, iy, H, W, p, m0, m1, gval, scale, gix, giy);
+          }
+          float guv, gvv;
+          departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
+          srow(GU + y * W + tl.cbase)[tl.lx] = guv;
+          srow(GV + y * W + tl.cbase)[tl.lx] = gvv;
+        }
+      }
+    }
+    if constexpr (!DET) {
+      // |cotangent| of the next step (prefetched above), published by the barrier
+      unsigned mb = max(abs_bits(qg[0]), abs_bits(qg[1]));
+      mb = wave_umax_lane63(mb);
+      if (lane == 63 && s + 1 < nsteps) atomicMax(&stepmax[(s + 1) % 3], mb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (raw: the stores and atomics stay in flight)
+  }
+  // what is still resident: the window of the last step
+  const int lo_last = Ring::lo(nsteps - 1, p);
+  for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) flush_row(lo_last + r8 + wave);
+}
+
 // ---- pole-row helpers of the tiled schedule ---------------------------------------------
 __global__ void __launch_bounds__(256)
 pole_row_means(const float* __restrict__ src, float* __restrict__ means, int planes, int K, int H,
@@ -1730,6 +2249,13 @@ bool separable(int flags, const float* lat_cells) {
   return (flags & PARADIS_ADVECT_SEPARABLE) && !(flags & PARADIS_ADVECT_GENERIC) && lat_cells != nullptr;
 }
 bool use_row64(int W, int flags, const float* lat_cells) { return W == 64 && separable(flags, lat_cells); }
+// strip schedule: packed 16-bit source columns; ring rows by grid height (latitude halo 6 / 22 rows: displacements in
+// the default model stay below 6 rows at 128 x 256 and below 22 rows for 99 % of the points at 721 x 1440,
+// tools/adv_disp_stats.py); longitude halos: what 3 (forward) / 2 (backward) workgroups per CU leave room for
+bool strip_ok(int W, int flags) { return W < 32768 && !(flags & PARADIS_ADVECT_TILES); }
+int strip_ring_rows(int H) { return H <= 160 ? 32 : 64; }
+int strip_halo_fwd(int W) { return W <= 512 ? 10 : 32; }
+int strip_halo_bwd(int W) { return W <= 512 ? 10 : 16; }
 
 }  // namespace
 
@@ -1817,7 +2343,29 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
         reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
       return 2;
   }
-  if (separable(flags, lat_cells)) {
+  if (separable(flags, lat_cells) && strip_ok(W, flags)) {
+    // strip schedule: ring of R padded rows, longitude halo hx (flags: PARADIS_ADVECT_HALO)
+    const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_fwd(W), false);
+    const int strips = (W + STRIP_W - 1) / STRIP_W;
+    const size_t slds = (size_t)ring * (STRIP_W + 2 * hx + NT) * sizeof(float);
+    PD_REQUIRE((int64_t)planes * strips < (1ll << 31), "sl_advect_fwd: too many strips");
+    PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_fwd: halo too wide");
+    static PerDeviceOnce once_row;
+    if (once_row.first()) {
+      if (reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 32>, "sl_advect_fwd: cannot reserve LDS") ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 32>, "sl_advect_fwd: cannot reserve LDS") ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 64>, "sl_advect_fwd: cannot reserve LDS") ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 64>, "sl_advect_fwd: cannot reserve LDS"))
+        return 2;
+    }
+#define LAUNCH_STRIP_FWD(M, R_)                                                                                   \
+    hipLaunchKernelGGL((sl_advect_fwd_strip<M, R_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS), slds, st, \
+                       field, u, v, out, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans, K, g, f_bs, uv_bs,   \
+                       o_bs, hx, strips)
+    if (mode == PARADIS_INTERP_BICUBIC) { if (ring == 32) LAUNCH_STRIP_FWD(PARADIS_INTERP_BICUBIC, 32); else LAUNCH_STRIP_FWD(PARADIS_INTERP_BICUBIC, 64); }
+    else { if (ring == 32) LAUNCH_STRIP_FWD(PARADIS_INTERP_BILINEAR, 32); else LAUNCH_STRIP_FWD(PARADIS_INTERP_BILINEAR, 64); }
+#undef LAUNCH_STRIP_FWD
+  } else if (separable(flags, lat_cells)) {      // (diagnostic A/B: the tile schedule of rounds 2-3)
     static PerDeviceOnce once_row;
     if (once_row.first()) {
       if (reserve_lds(&sl_advect_fwd_tilerow<PARADIS_INTERP_BICUBIC>, "sl_advect_fwd: cannot reserve LDS") ||
@@ -1919,7 +2467,33 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                      TILED_BWD_ARGS(gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon), vec4, gacc,         \
                      (const unsigned*)pmax)
   const bool cubic = mode == PARADIS_INTERP_BICUBIC;
-  if (separable(flags, lat_cells)) {
+  if (separable(flags, lat_cells) && strip_ok(W, flags)) {
+    const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_bwd(W), true);
+    const int strips = (W + STRIP_W - 1) / STRIP_W;
+    const size_t slds = ((size_t)ring * (STRIP_W + 2 * hx + NT) * 3 + 8) * sizeof(float);
+    PD_REQUIRE(slds <= 160 * 1024, "sl_advect_bwd: window does not fit LDS");
+    PD_REQUIRE((int64_t)planes * strips < (1ll << 31), "sl_advect_bwd: too many strips");
+    PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_bwd: halo too wide");
+    static PerDeviceOnce once_strip;
+    if (once_strip.first()) {
+#define RESERVE_STRIP(M, R_, D) reserve_lds(&sl_advect_bwd_strip<M, R_, D>, "sl_advect_bwd: cannot reserve LDS")
+      if (RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 32, false) || RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 32, true) ||
+          RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 64, false) || RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 64, true) ||
+          RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 32, false) || RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 32, true) ||
+          RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 64, false) || RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 64, true))
+        return 2;
+#undef RESERVE_STRIP
+    }
+#define LAUNCH_STRIP_BWD(M, R_, D)                                                                                  \
+    hipLaunchKernelGGL((sl_advect_bwd_strip<M, R_, D>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS), slds, st, \
+                       gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,      \
+                       (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, hx, strips, gacc, (const unsigned*)pmax)
+#define LAUNCH_STRIP_BWD_R(M, D) do { if (ring == 32) LAUNCH_STRIP_BWD(M, 32, D); else LAUNCH_STRIP_BWD(M, 64, D); } while (0)
+    if (gacc) { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, true); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, true); }
+    else { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, false); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, false); }
+#undef LAUNCH_STRIP_BWD_R
+#undef LAUNCH_STRIP_BWD
+  } else if (separable(flags, lat_cells)) {
     if (gacc) { if (cubic) LAUNCH_TILEROW(PARADIS_INTERP_BICUBIC, true); else LAUNCH_TILEROW(PARADIS_INTERP_BILINEAR, true); }
     else { if (cubic) LAUNCH_TILEROW(PARADIS_INTERP_BICUBIC, false); else LAUNCH_TILEROW(PARADIS_INTERP_BILINEAR, false); }
   } else {

@@ -586,6 +586,41 @@ constexpr int simg(int np) { return np * 2 * SCH; }      // chunks per operand p
 constexpr int simgp(int np) { return np * 2 * SCHP; }
 constexpr int SIMG = simg(3);
 
+// ---- sign checkerboard (round 4) ---------------------------------------------------------------------------------
+// What the bf16 / f16 MFMA does with its accumulator input (tools/mfma_round_probe.hip, gfx950): the sixteen products
+// are summed first; the smaller of {C, product sum} is then aligned to the larger one's exponent, and when the smaller
+// one is C its low bits are dropped by a two's-complement FLOOR (C = -2^-26 against a product sum of 1 - 1 comes out as
+// -2^-24).  Whenever a k-tile's product sum outweighs the running accumulator - the first tiles, and every later zero
+// crossing: ~5 times per K = 1024 dot product of zero-mean data - the result moves half a granule towards -infinity.
+// The f32 MFMA (an fma chain, round to nearest) has no such term.  Measured (tools/gemm_bias_check.py, N(0,1) data,
+// unit u = 2^-24 rms(C)): every output of the six-product GEMM carried the SAME offset, -0.9 u on top of 8.2 u of
+// zero-mean noise (f32 MFMA: +0.002 u on 9.6 u), -8 u on the weight gradient's 32,768-term sums.  Harmless per element,
+// but sums over pixels or channels of a GEMM output (bias / ChannelNorm parameter gradients over 32,768 points, the
+// per-pixel channel statistics) add the offset coherently where noise averages out: 0.9 u x 32,768 against 8.2 u x 181.
+// Remedy without a second accumulator set or VALU work per tile: run alternate 32 x 32 blocks of the output in the
+// NEGATED space.  The weight image holds the rows of odd 32-row blocks with the opposite sign (free: written once by
+// split_weights_kernel), the activation columns of odd 32-column blocks are negated while they are split in registers
+// (-x splits exactly into -h, -m, -l), so block (tm, tn) accumulates (-1)^(tm+tn) C: there the floor acts on -C, the
+// offset of C is +0.9 u, and the epilogue flips the two off-diagonal blocks of a wave tile back.  The offset is still
+// there per element; it alternates in sign every 32 rows and 32 columns and cancels in every sum over more than a
+// block.  The weight gradient alternates by K-range slab instead (odd slabs negate dY): there the offsets of an
+// element's slabs cancel in the slab sum.
+#ifndef SPLIT_SIGNED          // (-DSPLIT_SIGNED=0: the unsigned accumulation of rounds 1-3, for A/B runs)
+#define SPLIT_SIGNED 1
+#endif
+// sign bit of the staging thread's activation column (column = tid & 127 of a 128-column tile)
+__device__ __forceinline__ uint32_t split_flip_mask(int col) { return SPLIT_SIGNED && (col & 32) ? 0x80000000u : 0u; }
+__device__ __forceinline__ void flip8(float (&y)[8], const float (&x)[8], uint32_t mask) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[j] = __uint_as_float(__float_as_uint(x[j]) ^ mask);
+}
+// blocks (0,1) and (1,0) of a wave tile hold -C
+__device__ __forceinline__ void split_unflip(f32x16 (&acc)[2][2]) {
+  if (!SPLIT_SIGNED) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][1][r] = -acc[0][1][r]; acc[1][0][r] = -acc[1][0][r]; }
+}
+
 // ---- f16x2 scheme ------------------------------------------------------------------------------
 // x' = x 2^e with e chosen per TENSOR so that max |x'| lies in [2^14, 2^15) (fp16 holds 65504);
 // h = f16(x'), l = f16(x' - h): x' = h + l up to 2^-23 |x'|, and - fp16 being a fixed-point format below
@@ -705,6 +740,7 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
     for (int j = 0; j < 8; ++j) {
       const int k = kt * SBK + half * 8 + j;
       x[j] = (m < M && k < K) ? Wb[(int64_t)m * rs + (int64_t)k * cs] : 0.f;
+      if (SPLIT_SIGNED && (row & 32)) x[j] = -x[j];      // sign checkerboard: odd 32-row blocks hold -W
     }
     u32x4 h, mm, l;
     split8(x, h, mm, l);
@@ -734,7 +770,7 @@ split_weights_f16_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, in
       x[j] = (m < M && k < K) ? W[(int64_t)m * rs + (int64_t)k * cs] : 0.f;
     }
     u32x4 h, l;
-    split8_f16(x, sc, h, l);
+    split8_f16(x, (SPLIT_SIGNED && (row & 32)) ? -sc : sc, h, l);      // sign checkerboard
     u32x4* o = out + tile * simg(2) + half * SCH + row;
     o[0] = h; o[2 * SCH] = l;
   }
@@ -854,6 +890,8 @@ pw_gemm_split_kernel(GemmArgs g) {
     scale_from_amax(g.a_amax[0], sc_a, inv_a);
   }
 
+  const uint32_t flip = split_flip_mask(tid & 127);
+  if constexpr (NP == 2) sc_b = __uint_as_float(__float_as_uint(sc_b) ^ flip);
   float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
   auto issueA = [&](int t) __attribute__((always_inline)) {
     const u32x4* a = Ag + (int64_t)t * SIMG;
@@ -865,11 +903,13 @@ pw_gemm_split_kernel(GemmArgs g) {
   auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
     if constexpr (NP == 3) {
       u32x4 h, m, l;
-      split8(x, h, m, l);
+      float xs[8];
+      flip8(xs, x, flip);          // sign checkerboard: odd 32-column blocks are staged negated
+      split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
     } else {
       u32x4 h, l;
-      split8_f16(x, sc_b, h, l);
+      split8_f16(x, sc_b, h, l);   // (the column's sign rides on the scale)
       o[0] = h; o[2 * SCH] = l;
     }
   };
@@ -950,6 +990,7 @@ pw_gemm_split_kernel(GemmArgs g) {
     step(t, 0, xb[0], xb[1]);
     if (t + 1 < T) step(t + 1, 1, xb[1], xb[0]);
   }
+  split_unflip(acc);
   if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
@@ -1014,6 +1055,8 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
     scale_from_amax(g.a_amax[0], sc_a, inv_a);
   }
 
+  const uint32_t flip = split_flip_mask(ltid & 127);
+  if constexpr (NP == 2) sc_b = __uint_as_float(__float_as_uint(sc_b) ^ flip);
   float xb[2][8] = {};     // defined values: the surplus split of the last tile reads a set that was never loaded
   auto issueA = [&](int t) __attribute__((always_inline)) {
     if (doA)
@@ -1024,11 +1067,13 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
     if constexpr (NP == 3) {
       u32x4 h, m, l;
-      split8(x, h, m, l);
+      float xs[8];
+      flip8(xs, x, flip);          // sign checkerboard: odd 32-column blocks are staged negated
+      split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
     } else {
       u32x4 h, l;
-      split8_f16(x, sc_b, h, l);
+      split8_f16(x, sc_b, h, l);   // (the column's sign rides on the scale)
       o[0] = h; o[2 * SCH] = l;
     }
   };
@@ -1116,6 +1161,7 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   }
 #undef USE_X
   if (live) {
+    split_unflip(acc);
     if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
     gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
   }
@@ -1181,6 +1227,9 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     scale_from_amax(reduce_amax_partials(g.a_amax), sc_a, inv_a);
     scale_from_amax(reduce_amax_partials(g.b_amax), sc_b, inv_b);
   }
+  // the offset of the MFMA's accumulator alignment (see "sign checkerboard") cancels between an element's slabs
+  const uint32_t slab_flip = (SPLIT_SIGNED && (bz & 1)) ? 0x80000000u : 0u;      // workgroup-uniform
+  if constexpr (NP == 2) sc_a = __uint_as_float(__float_as_uint(sc_a) ^ slab_flip);
   auto split_store = [&](const Regs& r, int st, bool keep) __attribute__((always_inline)) {
     const float xa[8] = {r.a0.x, r.a0.y, r.a0.z, r.a0.w, r.a1.x, r.a1.y, r.a1.z, r.a1.w};
     const float xb[8] = {r.b0.x, r.b0.y, r.b0.z, r.b0.w, r.b1.x, r.b1.y, r.b1.z, r.b1.w};
@@ -1191,7 +1240,9 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     u32x4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
     if constexpr (NP == 3) {
       u32x4 ha, ma, la, hb, mb, lb;
-      split8(xa, ha, ma, la);
+      float xs[8];
+      flip8(xs, xa, slab_flip);    // sign alternation by slab: odd K-ranges accumulate -dW
+      split8(xs, ha, ma, la);
       split8(xb, hb, mb, lb);
       o[0] = ha; o[2 * SCHP] = ma; o[4 * SCHP] = la;
       o += SIMGP;
@@ -1248,6 +1299,14 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     rs += __shfl_xor(rs, 1, 64);
     const int m = m0 + srow;
     if (sh == 0 && m < g.M) g.rowsum[(int64_t)bz * g.M + m] = rs;
+  }
+  if (slab_flip) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
   }
   if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);

@@ -159,13 +159,25 @@ class GraphedTrainStep:
     (the graph's private pool under capture), and the optimiser's step count and learning rate live on the device
     (``optim.AdamW(capturable=True)``).
 
-    ``step`` must be a ``TrainStep(..., capturable=True)`` on one GPU (no DDP: its bucket hooks are not capturable),
-    ``example_batch`` fixes the shapes.  ``warmup`` eager steps run first on a side stream (they are real optimiser
-    steps: kernel attributes, optimiser state and the allocator's pools must exist before capture)."""
+    ``step`` must be a ``TrainStep(..., capturable=True)``; ``example_batch`` fixes the shapes.  ``warmup`` eager
+    steps run first on a side stream (they are real optimiser steps: kernel attributes, optimiser state and the
+    allocator's pools must exist before capture).
+
+    Data parallel: a model wrapped by ``wrap_ddp(..., capturable=True)`` is captured WITH its gradient all-reduces -
+    RCCL collectives are capturable, the Reducer launches them from its autograd hooks onto the process group's
+    stream, which forks from and joins the capturing stream inside the capture.  What that needs (PyTorch's CUDA-graph
+    notes for DDP): the wrapper constructed on a side stream, at least 11 eager DDP iterations before the capture (the
+    Reducer rebuilds its buckets after the first one and settles its bookkeeping over the next ones), and no
+    asynchronous NCCL error handling thread touching the captured work (TORCH_NCCL_ASYNC_ERROR_HANDLING=0, set by
+    ``init_distributed``)."""
+
+    DDP_WARMUP = 11
 
     def __init__(self, step: TrainStep, example_batch, warmup: int = 2):
         if not getattr(step.opt, "capturable", False):
             raise ValueError("GraphedTrainStep needs TrainStep(..., capturable=True)")
+        if isinstance(step.model, torch.nn.parallel.DistributedDataParallel):
+            warmup = max(warmup, self.DDP_WARMUP)
         self.step = step
         self.static_batch = tuple(t.clone() for t in example_batch)
         side = torch.cuda.Stream()
@@ -180,6 +192,10 @@ class GraphedTrainStep:
         step.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.static_loss = step(self.static_batch)
+        # the graph's optimiser nodes copy the pinned pointer tables of the capture on every replay: keep a snapshot
+        # (and the captured gradient tensors, which live in the graph's private pool) for eager_step()
+        self._tables = step.opt.snapshot_pointer_tables()
+        self._captured_grads = [p.grad for g in step.opt.param_groups for p in g["params"]]
         # the capture ran the Python side of one step (host step counts advanced) without executing it on the
         # device: bring the device-side count of the captured tick back in line on first replay
         self._first = True
@@ -193,7 +209,21 @@ class GraphedTrainStep:
         else:
             self.step.opt.note_replayed()
         self.graph.replay()
+        # the replay rewrites the parameters through raw pointers: no autograd version bump, no optimiser post-hook.
+        # Without this an eager forward between replays (validation) would keep using the split weight images it
+        # cached at the previous epoch.
+        from . import ops
+        ops.weights_updated()
         return self.static_loss
+
+    def eager_step(self, batch):
+        """A real (un-captured) optimiser step on ``batch`` - e.g. an odd-shaped last batch of an epoch.  The
+        captured graph reads the gradient / moment addresses of ITS step from the optimiser's pinned pointer table;
+        an eager step rewrites that table (its gradients are fresh allocations), so the table is restored afterwards
+        and the gradients of the capture stay alive (``TrainStep`` keeps them: see ``_captured_grads``)."""
+        loss = self.step(batch)
+        self.step.opt.restore_pointer_tables(self._tables)
+        return loss
 
 
 # ---------------------------------------------------------------------------------- data parallel
@@ -209,22 +239,40 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
                 ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+            # a captured step replays its RCCL kernels without the watchdog's bookkeeping (see GraphedTrainStep)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 
 def wrap_ddp(model, *, bucket_cap_mb: float = 32, device_ids: Optional[Sequence[int]] = None,
-             static_graph: bool = False):
+             static_graph: bool = False, force: bool = False, capturable: bool = False):
     """Batch-sharded data parallelism (the reference's only strategy, ``train.py:49``): full replica
     per GPU, bucketed gradient all-reduce (RCCL over xGMI) overlapped with backward.  Geometry
     buffers are deterministic functions of the grid, so buffer broadcast is disabled; the graph is
-    static, gradients alias the buckets."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    static, gradients alias the buckets.
+
+    ``force``: wrap even in a one-rank process group (a world_size = 1 ``nccl`` group initialises RCCL and runs
+    its all-reduce kernels: the one-GPU stand-in for the N > 1 path, tests/test_hip_ddp.py and the ``ddp_overhead_ms``
+    leg of bench.py).  ``capturable``: construct the wrapper on a side stream, which is what capturing a DDP step
+    into a HIP graph requires (``GraphedTrainStep``; the Reducer's bucket views and streams must not belong to the
+    capturing stream)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return model
-    return torch.nn.parallel.DistributedDataParallel(
-        model, device_ids=list(device_ids) if device_ids is not None else None,
-        broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
-        static_graph=bool(static_graph))
+
+    def build():
+        return torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=list(device_ids) if device_ids is not None else None,
+            broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
+            static_graph=bool(static_graph))
+    if capturable and torch.cuda.is_available():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ddp = build()
+        torch.cuda.current_stream().wait_stream(side)
+        return ddp
+    return build()
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -65,6 +65,9 @@ class ParadisLoss(torch.nn.Module):
         fw[self.num_atmospheric_vars:] = self.var_loss_weights[self.num_atmospheric_vars:]
         return fw
 
+    # The two methods below are the reference's per-variable validation metric (utils/loss.py:105-127): a [C] vector for
+    # logging, off the training hot path, a handful of ATen elementwise ops on whatever device the tensors live on.
+    # The training loss itself (forward) has one implementation only, the fused HIP kernel.
     def _pointwise_loss(self, pred, target):
         if self.kind == "mse":
             return (pred - target) ** 2
@@ -83,15 +86,11 @@ class ParadisLoss(torch.nn.Module):
         return loss.mean(dim=(0, 2, 3))
 
     def forward(self, pred, target):
-        if pred.is_cuda:
-            from . import ops
-            lw = self.lat_weights_buf.reshape(-1) if self.apply_latitude_weights else None
-            return ops.paradis_loss(pred, target, self.feature_weights_buf.reshape(-1), lw, self.kind,
-                                    self.delta)
-        loss = self._pointwise_loss(pred, target) * self.feature_weights_buf
-        if self.apply_latitude_weights:
-            loss = loss * self.lat_weights_buf
-        return loss.mean()
+        """Fused HIP kernel (value and d/dpred in one pass); like every module of this package it refuses CPU tensors -
+        the CPU evaluation of the loss is ``oracle.paradis_oracle.paradis_loss`` (tests only)."""
+        from . import ops
+        lw = self.lat_weights_buf.reshape(-1) if self.apply_latitude_weights else None
+        return ops.paradis_loss(pred, target, self.feature_weights_buf.reshape(-1), lw, self.kind, self.delta)
 
 
 def build_loss(cfg, lat_deg: torch.Tensor) -> ParadisLoss:

@@ -322,16 +322,17 @@ def _advv_backward(ctx, gout):
 _autograd("sl_advect_vel", _advv_setup, _advv_backward)
 
 
-ADVECT_GENERIC, ADVECT_TILED, ADVECT_SEPARABLE = 1, 2, 4     # include/paradis_hip.h PARADIS_ADVECT_*
+ADVECT_GENERIC, ADVECT_TILED, ADVECT_SEPARABLE, ADVECT_TILES = 1, 2, 4, 8     # include/paradis_hip.h PARADIS_ADVECT_*
 # schedule hints applied when a call passes none (diagnostics: tools/advect_halo_sweep.py)
 ADVECT_FLAGS = int(os.environ.get("PARADIS_ADVECT_FLAGS", "0"), 0)
 
 
 def advect_flags(tiled: bool = False, halo: Optional[int] = None, halo_bwd: Optional[int] = None,
-                 generic: bool = False) -> int:
-    """``flags`` of the advection ops: force the tiled schedule and/or its window halo (padded cells;
-    ``halo_bwd`` overrides it for the backward kernel), or the generic whole-plane kernel."""
-    return ((ADVECT_TILED if tiled else 0) | (ADVECT_GENERIC if generic else 0)
+                 generic: bool = False, tiles: bool = False) -> int:
+    """``flags`` of the advection ops: force the windowed schedule and/or its longitude halo (padded cells;
+    ``halo_bwd`` overrides it for the backward kernel), the generic whole-plane kernel, or (``tiles``, diagnostic)
+    the tile schedule of rounds 2-3 in place of the strips."""
+    return ((ADVECT_TILED if tiled else 0) | (ADVECT_GENERIC if generic else 0) | (ADVECT_TILES if tiles else 0)
             | (((int(halo) + 1) << 8) if halo is not None else 0)
             | (((int(halo_bwd) + 1) << 16) if halo_bwd is not None else 0))
 

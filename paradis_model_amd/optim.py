@@ -89,6 +89,19 @@ class AdamW(torch.optim.Optimizer):
         ops.weights_updated()     # the kernels write through raw pointers: no version-counter bump
         return loss
 
+    def snapshot_pointer_tables(self):
+        """copies of the pinned address tables of the fused groups (``harness.GraphedTrainStep``: a captured step
+        re-reads them on every replay)"""
+        return {gi: c["host"].clone() for gi, c in self.__dict__.get("_fused_cache", {}).items()}
+
+    def restore_pointer_tables(self, tables) -> None:
+        for gi, t in tables.items():
+            c = self.__dict__.get("_fused_cache", {}).get(gi)
+            if c is not None and c["host"].numel() == t.numel():
+                if c.get("pending") is not None:
+                    c["pending"].synchronize()
+                c["host"].copy_(t)
+
     def _step_group_fused(self, gi, group, params, step, st):
         """One launch for the group (``paradis_adamw_multi``).  Only the chunk list (a function of the
         parameter sizes) is cached; the four address rows (parameter, gradient, both moments) are

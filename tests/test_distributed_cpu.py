@@ -33,6 +33,22 @@ class OracleReplica(torch.nn.Module):
         return self.O.paradis_forward(p, self.spec, x, self.lg, self.og, interp_impl="aten_ref")
 
 
+class OracleLoss(torch.nn.Module):
+    """ParadisLoss on the CPU = the oracle's restatement with the product's weight assembly (the product module
+    itself launches the fused HIP kernel and refuses CPU tensors)."""
+
+    def __init__(self, cfg, lat_deg):
+        super().__init__()
+        from oracle import paradis_oracle as O
+        from paradis_model_amd.loss import build_loss
+        fn = build_loss(cfg, lat_deg)
+        self.fw, self.lw = fn.feature_weights, (fn.lat_weights if fn.apply_latitude_weights else None)
+        self.kind, self.delta, self.O = fn.kind, fn.delta, O
+
+    def forward(self, pred, target):
+        return self.O.paradis_loss(pred, target, self.fw, self.lw, self.kind, self.delta)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -47,13 +63,12 @@ def _worker(rank, world, port, out_dir):
     from paradis_model_amd.config import reduced_config
     from paradis_model_amd.harness import (TrainStep, barrier, init_distributed, make_grids,
                                            max_over_ranks, synthetic_batch, wrap_ddp)
-    from paradis_model_amd.loss import build_loss
     r, _, w = init_distributed("gloo")
     assert (r, w) == (rank, world)
     cfg = reduced_config()
     lat_deg, lg, og = make_grids(16, 32, False)
     model = wrap_ddp(OracleReplica(cfg, lg, og), bucket_cap_mb=1)
-    step = TrainStep(model, build_loss(cfg, lat_deg), cfg, fused=False)
+    step = TrainStep(model, OracleLoss(cfg, lat_deg), cfg, fused=False)
     full = synthetic_batch(16, 32, False, 2 * world, 1, seed=5)
     shard = tuple(t[rank * 2:(rank + 1) * 2] for t in full)       # batch sharding
     barrier()
@@ -75,12 +90,11 @@ def test_two_rank_ddp_equals_single_process_large_batch(tmp_path):
     sys.path.insert(0, ROOT)
     from paradis_model_amd.config import reduced_config
     from paradis_model_amd.harness import TrainStep, make_grids, synthetic_batch
-    from paradis_model_amd.loss import build_loss
     cfg = reduced_config()
     lat_deg, lg, og = make_grids(16, 32, False)
     torch.set_num_threads(4)
     model = OracleReplica(cfg, lg, og)
-    step = TrainStep(model, build_loss(cfg, lat_deg), cfg, fused=False)
+    step = TrainStep(model, OracleLoss(cfg, lat_deg), cfg, fused=False)
     loss = step(synthetic_batch(16, 32, False, 2 * world, 1, seed=5))
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     assert abs(float(loss) - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5 * abs(float(loss))

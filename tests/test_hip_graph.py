@@ -81,3 +81,55 @@ def test_graphed_step_host_time_is_one_launch():
     torch.cuda.synchronize()
     print("host time per step: eager %.2f ms, graph replay %.2f ms" % (1e3 * t_eager, 1e3 * t_graph))
     assert t_graph < 0.5 * t_eager
+
+
+def test_eager_forward_between_replays_sees_current_weights():
+    """A validation forward between two replays must run on the weights the replay just wrote: the replay updates the
+    parameters through raw pointers (no autograd version bump, no optimiser post-hook), so the cached bf16x3 weight
+    images have to be invalidated by GraphedTrainStep itself.  Twin: the same steps and forwards eagerly."""
+    from paradis_model_amd.harness import GraphedTrainStep, assemble_model_input
+    model_e, step_e, batches = _setup(False)
+    model_g, step_g, _ = _setup(True)
+
+    def fwd(model, batch):
+        inp, tgt, forc, const = batch
+        mi = assemble_model_input(inp, forc.permute(0, 1, 4, 2, 3)[:, 0].unsqueeze(1), const[:, :1].permute(0, 1, 4, 2, 3))
+        with torch.no_grad():
+            return model(mi)
+
+    warm = 2
+    g = GraphedTrainStep(step_g, batches[0], warmup=warm)
+    for _ in range(warm):
+        step_e(batches[0])
+    outs_e, outs_g = [], []
+    for i in range(3):
+        step_e(batches[i % 2]); outs_e.append(fwd(model_e, batches[1]))
+        g(batches[i % 2]); outs_g.append(fwd(model_g, batches[1]))
+    torch.cuda.synchronize()
+    for a, b in zip(outs_e, outs_g):
+        assert max_rel(b, a) <= 2e-6, max_rel(b, a)
+    # the forwards differ from step to step (the weights moved), so a stale image would have shown
+    assert max_rel(outs_g[2], outs_g[0]) > 1e-5
+
+
+def test_eager_step_after_capture_keeps_the_graph_valid():
+    """An un-captured step between replays (an odd-shaped last batch) rewrites the optimiser's pinned pointer table
+    with its own gradient addresses; GraphedTrainStep.eager_step restores the captured table."""
+    from paradis_model_amd.harness import GraphedTrainStep
+    model_e, step_e, batches = _setup(False)
+    model_g, step_g, _ = _setup(True)
+    warm = 2
+    g = GraphedTrainStep(step_g, batches[0], warmup=warm)
+    for _ in range(warm):
+        step_e(batches[0])
+    small = tuple(t[:1].contiguous() for t in batches[1])
+    for batch, graphed in ((batches[0], True), (small, False), (batches[1], True), (batches[0], True)):
+        step_e(batch)
+        if graphed:
+            g(batch)
+        else:
+            g.eager_step(batch)
+    torch.cuda.synchronize()
+    pe = torch.cat([p.detach().flatten() for p in model_e.parameters()])
+    pg = torch.cat([p.detach().flatten() for p in model_g.parameters()])
+    assert max_rel(pg, pe) <= 1e-6, max_rel(pg, pe)
