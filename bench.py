@@ -203,7 +203,8 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=32, help="DDP gradient bucket size (N>1)")
     ap.add_argument("--static-graph", action="store_true", help="DDP static_graph=True (N>1)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole training step from a captured HIP graph (harness.GraphedTrainStep; N = 1); "
+                    help="replay the whole training step from a captured HIP graph (harness.GraphedTrainStep; with N > 1 "
+                         "the DDP step including its RCCL bucket all-reduces); "
                          "implies --no-kernel-events and skips the extra legs")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
@@ -250,11 +251,14 @@ def main():
     torch.manual_seed(cfg.init.seed)
     model = Paradis(stub_datamodule(cfg), cfg, lg, og).to(dev)
     loss_fn = build_loss(cfg, lat_deg).to(dev)
-    ddp = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, static_graph=args.static_graph)
     if args.graph:
-        if world > 1 or args.optimizer != "adamw":
-            raise SystemExit("--graph: single GPU, AdamW only")
+        if args.optimizer != "adamw":
+            raise SystemExit("--graph: AdamW only")
         args.no_kernel_events = args.no_extra_legs = True
+    # --graph with N > 1: the DDP step, bucket all-reduces included, is captured (wrapper built on a side stream,
+    # 11 eager warm-up iterations inside GraphedTrainStep)
+    ddp = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, static_graph=args.static_graph,
+                   capturable=args.graph)
     step = TrainStep(ddp, loss_fn, cfg, num_common=lay.num_common_features,
                      n_inputs=cfg.dataset.n_time_inputs, capturable=args.graph)
     batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234 + rank, device=dev)
@@ -350,6 +354,55 @@ def main():
             del gstep
         except Exception as exc:   # never lose the headline line over the extra leg
             legs["hip_graph_replay"] = {"error": repr(exc)[:300]}
+
+    # What the data-parallel wrapper costs on ONE GPU: the same step through DistributedDataParallel over a
+    # world_size = 1 nccl (RCCL) group - Reducer hooks, bucket copies and the RCCL all-reduce kernels of 240 MB of
+    # gradients, no wire - eager and replayed from a captured graph.  (The 1 -> 8 curve needs a node; this leg is the
+    # part of it a one-GPU box can measure.)
+    if (not args.no_extra_legs and not args.graph and world == 1 and not args.forward_only
+            and args.optimizer == "adamw" and not torch.distributed.is_initialized()):
+        try:
+            import socket
+            from paradis_model_amd.harness import GraphedTrainStep
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            d1 = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, force=True, capturable=True)
+            dstep = TrainStep(d1, loss_fn, cfg, num_common=lay.num_common_features,
+                              n_inputs=cfg.dataset.n_time_inputs, capturable=True)
+
+            def timed(fn, n):
+                for _ in range(3):
+                    fn(batch)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn(batch)
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t) / n
+            ms_plain = timed(step, args.steps)
+            ms_ddp = timed(dstep, args.steps)
+            rec = {"ms_per_step_plain": ms_plain, "ms_per_step_ddp_nccl_world1": ms_ddp,
+                   "ddp_overhead_ms": ms_ddp - ms_plain, "bucket_cap_mb": args.bucket_mb,
+                   "what": "TrainStep through DistributedDataParallel over a 1-rank nccl (RCCL) group vs the plain step, "
+                           "same process, same box"}
+            try:
+                gd = GraphedTrainStep(dstep, batch)           # 11 eager DDP iterations, then the capture
+                rec["ms_per_step_ddp_graph_replay"] = timed(gd, args.steps)
+                t2 = time.perf_counter()
+                gd(batch)
+                rec["host_ms_one_ddp_replay"] = 1e3 * (time.perf_counter() - t2)
+                torch.cuda.synchronize()
+                del gd
+            except Exception as exc:
+                rec["ddp_graph_error"] = repr(exc)[:300]
+            legs["ddp_overhead"] = rec
+            del dstep, d1
+            torch.distributed.destroy_process_group()
+        except Exception as exc:
+            legs["ddp_overhead"] = {"error": repr(exc)[:300]}
 
     metric = "training samples/sec (whole node) on 5.625deg ERA5 grid, 1/2/4/8 MI355X"
     try:   # use BASELINE.json's exact wording when the file travels with the repo

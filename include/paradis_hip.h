@@ -42,6 +42,7 @@ extern "C" {
  *   bit 2  PARADIS_ADVECT_SEPARABLE the caller vouches that sin_lat/cos_lat are constant along a row and
  *                                   lon along a column (every regular lat-lon grid)
  *   bit 3  PARADIS_ADVECT_TILES     diagnostic: the 64 x 128 / 16 x 128 tile schedule of rounds 2-3 instead of strips
+ *   bit 4  PARADIS_ADVECT_STRIPS    backward: 128-column strips even where the full-circle ring (W <= 256) would run
  *   bits 8-15  window halo in longitude of the windowed schedules (0 = built-in default, else halo + 1)
  *   bits 16-23 the same for the backward kernel only */
 #define PARADIS_ADVECT_AUTO 0
@@ -49,11 +50,12 @@ extern "C" {
 #define PARADIS_ADVECT_TILED 2
 #define PARADIS_ADVECT_SEPARABLE 4
 #define PARADIS_ADVECT_TILES 8
+#define PARADIS_ADVECT_STRIPS 16
 #define PARADIS_ADVECT_HALO_SHIFT 8
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -76,9 +78,11 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
                           float dt, float min_lat, float min_lon, float d_lat, float d_lon,
                           int mode, int flags, void* workspace, void* stream);
 /* gfield [B,K,H,W] (batch stride gf_bs), gu/gv with batch stride guv_bs.
- * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W) bytes (with PARADIS_DETERMINISTIC=1 this includes the
- * 64-bit integer plane the tiled backward accumulates into: 8 bytes per gather point). */
-size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W);
+ * workspace (fwd and bwd): >= paradis_sl_advect_ws_bytes(B,K,H,W,flags) bytes for the `flags` of the call (with
+ * PARADIS_DETERMINISTIC=1 this includes the 64-bit integer plane the windowed backward accumulates into: 8 bytes per
+ * gather point; for the strip schedule it includes the lists of points whose taps leave the window: 12 bytes per gather
+ * point). */
+size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W, int flags);
 int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u, const float* v,
                           float* gfield, float* gu, float* gv,
                           const float* sin_lat, const float* cos_lat, const float* lat_cells, const float* lon,

@@ -226,6 +226,54 @@ __device__ __forceinline__ void departure(float u, float v, float sa, float ca, 
   }
 }
 
+// The map evaluated per lane, without the wave-uniform branches of the elementary functions above: the branch a point
+// takes there depends on the other 63 points of its wave, which is harmless where the assignment of points to waves is
+// fixed by the launch geometry, but not for the deferred points of the strip schedule - the order in which waves
+// append to a strip's list varies from run to run, and with it a point's wave mates (a polar point amplifies the
+// difference between two sin/cos tiers to 2e-4 of its velocity gradient).
+__device__ __forceinline__ void departure_lane(float u, float v, float sa, float ca, float lonc,
+                                               const AdvGeom& g, float& ix, float& iy, DepState* st) {
+  const float lam = u * g.ndt;
+  const float phi = v * g.ndt;
+  float sp, cp, sl, cl;
+  sincos_reduced(phi, sp, cp);
+  sincos_reduced(lam, sl, cl);
+  const float cc = cp * cl;
+  const float s = fmaf(sp, ca, cc * sa);
+  const float sc = __builtin_amdgcn_fmed3f(s, -CLAMP_HI, CLAMP_HI);
+  // asin: one polynomial behind selects (the mixed case of asin_wave)
+  float lat_d;
+  {
+    const float ax = fabsf(sc);
+    const bool big = ax >= 0.5f;
+    const float t = fmaf(ax, -0.5f, 0.5f);
+    const float r = __builtin_amdgcn_sqrtf(t);
+    const float y = big ? t : ax * ax;
+    const float a = big ? r : ax;
+    const float yy = fmaf(a, y * asin_poly(y), a);
+    lat_d = copysignf(big ? fmaf(-2.0f, yy, 0x1.921fb6p+0f) : yy, sc);
+  }
+  const float n = cp * sl;
+  const float d = fmaf(cc, ca, -(sp * sa));
+  float a;
+  {   // the octant form of atan2_wave
+    const float ax = fabsf(d), ay = fabsf(n);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    a = atan_poly(mn * __builtin_amdgcn_rcpf(mx));
+    a = (ay > ax) ? 0x1.921fb6p+0f - a : a;
+    a = (d < 0.f) ? 0x1.921fb6p+1f - a : a;
+    a = (n == 0.f) ? ((__float_as_int(d) < 0) ? 0x1.921fb6p+1f : 0.f) : a;
+    a = copysignf(a, n);
+  }
+  const float t = fmaf(a, g.cx, lonc);
+  const float q = floorf(fmaf(t, g.inv_per, g.qoff));
+  ix = fmaf(-q, g.per, t);
+  iy = fmaf(lat_d, g.cy, g.c0y);
+  if (st) {
+    st->sp = sp; st->cp = cp; st->sl = sl; st->cl = cl; st->s = s; st->n = n; st->d = d;
+  }
+}
+
 // The same map for a wave that is ONE LATITUDE ROW (separable schedules): sa, ca and iya - the arrival latitude
 // in padded cells, p + (lat_a - min_lat) cy - are wave-uniform scalars.  The small-displacement regime is decided
 // ONCE per row by a single vector condition - both rotation angles below 0.125 rad, departure less than 45 degrees
@@ -1628,15 +1676,16 @@ sl_advect_bwd_tilerow(const float* __restrict__ gout, const float* __restrict__ 
 //     (4 + 4 index computations instead of 16).
 constexpr int STRIP_W = 128, STRIP_ROWS = 8, STRIP_THREADS = 512, STRIP_CH = 4;   // CH: 64-column chunks of a window row
 constexpr int STRIP_MAX_WS = 64 * STRIP_CH;
+constexpr int STRIP_LDS_MAX = 160 * 1024 - 1024;   // dynamic LDS a strip kernel may ask for (it also holds a static counter word)
 
 // lane's source columns of the window columns lane, lane + 64, ...: image column in the low half, the column of the
 // over-the-pole rows (shifted by W / 2) in the high half
 struct StripCols { unsigned pk[STRIP_CH]; };
-__device__ __forceinline__ StripCols strip_cols(int wx0, int WS, int W, int p, unsigned lane) {
+__device__ __forceinline__ StripCols strip_cols(int wx0, int WS, int W, int p, unsigned lane, int cfirst = 0) {
   StripCols c;
 #pragma unroll
   for (int i = 0; i < STRIP_CH; ++i) {
-    const int lc = min((int)lane + 64 * i, WS - 1);
+    const int lc = min((int)lane + 64 * (cfirst + i), WS - 1);
     int jj = (wx0 + lc - p) % W;
     if (jj < 0) jj += W;
     int jm = jj + (W >> 1);
@@ -1668,7 +1717,8 @@ __device__ __forceinline__ void strip_load_row(const float* __restrict__ F, int 
 }
 
 __device__ __forceinline__ void strip_store_row(float* __restrict__ ring, int pr, int RMASK, int WS, int H, int p, float m0,
-                                                float m1, unsigned lane, int nch, const float (&pre)[STRIP_CH]) {
+                                                float m1, unsigned lane, int nch, const float (&pre)[STRIP_CH],
+                                                int cfirst = 0) {
   const StripRow r = strip_row(pr, H, p);
   float* dst = ring + (pr & RMASK) * WS;
 #pragma unroll
@@ -1678,7 +1728,7 @@ __device__ __forceinline__ void strip_store_row(float* __restrict__ ring, int pr
       if (r.sr == 0) v = m0;                 // rows 0 and H-1 enter as their longitudinal means (advection.py:100-114)
       if (r.sr == H - 1) v = m1;
       if (!r.valid) v = 0.f;
-      const int lc = (int)lane + 64 * i;
+      const int lc = (int)lane + 64 * (cfirst + i);
       if (lc < WS) dst[lc] = v;
     }
 }
@@ -1784,6 +1834,26 @@ __device__ __forceinline__ bool tap_block_ring(float ix, float iy, float Hpf, fl
   return xc == x0f && yc == y0f && rxc == rx && ryc == ry;
 }
 
+// append this lane's point to the strip's list of deferred points: one LDS atomic per wave that holds any
+// (forward: the sample coordinates ride along in two more lists of the same length behind the first, cap entries each)
+__device__ __forceinline__ void strip_defer(bool defer, unsigned idx, unsigned* __restrict__ q, unsigned* qcount,
+                                            unsigned lane, size_t cap = 0, float ix = 0.f, float iy = 0.f) {
+  const unsigned long long m = __ballot(defer);
+  if (m == 0ull) return;                                  // wave-uniform
+  const int leader = __ffsll((long long)m) - 1;
+  unsigned base = 0;
+  if ((int)lane == leader) base = atomicAdd(qcount, (unsigned)__popcll(m));
+  base = __shfl((int)base, leader, 64);
+  if (defer) {
+    const unsigned slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    q[slot] = idx;
+    if (cap) {
+      reinterpret_cast<float*>(q)[cap + slot] = ix;
+      reinterpret_cast<float*>(q)[2 * cap + slot] = iy;
+    }
+  }
+}
+
 // geometry of the ring: rows resident while the arrival rows [8 s, 8 s + 8) are computed
 template <int MODE, int R>
 struct StripRing {
@@ -1793,13 +1863,23 @@ struct StripRing {
   static __device__ __forceinline__ int lo(int s, int p) { return STRIP_ROWS * s + p + OFF0 - HYL; }
 };
 
+// waves per SIMD the strip kernels are compiled for: the forward's 19 KB ring of the 128-row grids admits four
+// 8-wave workgroups per CU (64 registers, no scratch), its 50 KB ring of the large grids three (74 registers)
+#ifndef STRIP_FWD_WAVES
+#define STRIP_FWD_WAVES (R == 32 ? 8 : 6)
+#endif
+#ifndef STRIP_BWD_WAVES
+#define STRIP_BWD_WAVES 4
+#endif
 template <int MODE, int R>
-__global__ void __launch_bounds__(STRIP_THREADS)
+__global__ void __launch_bounds__(STRIP_THREADS, STRIP_FWD_WAVES)
 sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
                     float* __restrict__ out, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
-                    int K, AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int hx, int strips) {
+                    int K, AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int hx, int strips,
+                    unsigned* __restrict__ queue, unsigned* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned qcount;
   using Ring = StripRing<MODE, R>;
   constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -1820,6 +1900,9 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
   const int rw = wave >> 1;                          // this wave's arrival rows of a step: rw and rw + 4
   const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
   const StripCols cs = strip_cols(wx0, WS, W, p, lane);
+  const size_t qcap = (size_t)H * STRIP_W;
+  unsigned* const q = queue + (size_t)blockIdx.x * 3 * qcap;    // this strip's lists of deferred points: index, ix, iy
+  if (tid == 0) qcount = 0u;
 
   float qu[2], qv[2];
 #pragma unroll
@@ -1862,29 +1945,53 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
         departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
         int r0, c0;
         const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
-        float acc;
-        if (fast) {
-          float wx[NT], wy[NT];
-          Interp<MODE>::weights(tx, wx);
-          Interp<MODE>::weights(ty, wy);
-          acc = 0.f;
+        // (a tap block outside the window reads a clamped, valid address; its value is dropped)
+        float wx[NT], wy[NT];
+        Interp<MODE>::weights(tx, wx);
+        Interp<MODE>::weights(ty, wy);
+        float acc = 0.f;
 #pragma unroll
-          for (int a = 0; a < NT; ++a) {
-            const float* base = ring + ((r0 + a) & RMASK) * WS + c0;
-            float rowacc = 0.f;
+        for (int a = 0; a < NT; ++a) {
+          const float* base = ring + ((r0 + a) & RMASK) * WS + c0;
+          float rowacc = 0.f;
 #pragma unroll
-            for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[bb], wx[bb], rowacc);
-            acc = fmaf(rowacc, wy[a], acc);
-          }
-        } else {
-          acc = gather_global<MODE>(F, ix, iy, H, W, p, m0, m1);
+          for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[bb], wx[bb], rowacc);
+          acc = fmaf(rowacc, wy[a], acc);
         }
-        if (tl.active) srow(O + y * W + tl.cbase)[tl.lx] = acc;
+        if (tl.active && fast) srow(O + y * W + tl.cbase)[tl.lx] = acc;
+        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane, qcap, ix, iy);
       }
     }
     // raw barrier: __syncthreads() would also wait for this step's stores and the prefetches (s_waitcnt vmcnt(0))
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  if (tid == 0) counts[blockIdx.x] = qcount;
+}
+
+// Deferred points of the strips (tap block outside the ring window: the polar rows, and whatever moved further than the
+// halos): every lane takes one point - the divergent slow path of rounds 1-3 ran the sixteen global loads of a point
+// for every WAVE that held one; here the points of a strip are processed densely, in a launch of their own.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+sl_advect_fwd_strip_fixup(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
+                          float* __restrict__ out, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                          const float* __restrict__ lon, const float* __restrict__ fmeans, int K, AdvGeom g, int64_t f_bs,
+                          int64_t uv_bs, int64_t o_bs, int strips, const unsigned* __restrict__ queue,
+                          const unsigned* __restrict__ counts) {
+  const int H = g.H, W = g.W, p = g.p, P = H * W;
+  const unsigned n = counts[blockIdx.x];
+  if (n == 0) return;
+  const int plane = blockIdx.x / strips;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
+  const size_t qcap = (size_t)H * STRIP_W;
+  const unsigned* q = queue + (size_t)blockIdx.x * 3 * qcap;
+  const float* qx = reinterpret_cast<const float*>(q) + qcap;
+  const float* qy = qx + qcap;
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  for (unsigned i = threadIdx.x; i < n; i += 256)
+    O[q[i]] = gather_global<MODE>(F, qx[i], qy[i], H, W, p, m0, m1);
 }
 
 // field gradient and coordinate gradients of a point whose tap block leaves the window: global atomics on the field
@@ -1939,15 +2046,16 @@ __device__ __forceinline__ int fixed_exponent(unsigned bits) {
 }
 
 template <int MODE, int R, bool DET>
-__global__ void __launch_bounds__(STRIP_THREADS, 4)      // four waves per SIMD: <= 128 registers
+__global__ void __launch_bounds__(STRIP_THREADS, STRIP_BWD_WAVES)
 sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ field, const float* __restrict__ u,
                     const float* __restrict__ v, float* __restrict__ gfield, float* __restrict__ gu,
                     float* __restrict__ gv, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
                     const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                     int64_t gf_bs, int64_t guv_bs, int hx, int strips, unsigned long long* __restrict__ gacc,
-                    const unsigned* __restrict__ pmax) {
+                    const unsigned* __restrict__ pmax, unsigned* __restrict__ queue, unsigned* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned qcount;
   using Ring = StripRing<MODE, R>;
   constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -1976,6 +2084,8 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
   const int rw = wave >> 1;
   const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
   const StripCols cs = strip_cols(wx0, WS, W, p, lane);
+  unsigned* const q = queue + (size_t)blockIdx.x * 3 * (size_t)(H * STRIP_W);    // deferred points (see the forward)
+  if (tid == 0) qcount = 0u;
 
   float qu[2], qv[2], qg[2];
 #pragma unroll
@@ -2079,8 +2189,9 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
         const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
         float gix = 0.f, giy = 0.f;
-        if (tl.active) {
-          if (fast) {
+        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane);
+        if (tl.active && fast) {
+          {
             float wx[NT], wy[NT], dwx[NT], dwy[NT];
             Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
             Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
@@ -2103,8 +2214,6 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
               gix = fmaf(wy[a], sdx, gix);
               giy = fmaf(dwy[a], sxv, giy);
             }
-          } else {
-            scatter_global<MODE, DET>(F, GF, GA, ix, iy, H, W, p, m0, m1, gval, scale, gix, giy);
           }
           float guv, gvv;
           departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
@@ -2124,6 +2233,266 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
   // what is still resident: the window of the last step
   const int lo_last = Ring::lo(nsteps - 1, p);
   for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) flush_row(lo_last + r8 + wave);
+  if (tid == 0) counts[blockIdx.x] = qcount;
+}
+
+// Backward on grids of at most 256 longitudes (configs[3]): the ring spans the WHOLE latitude circle (window column lc
+// holds image column lc mod W, the first NT columns repeated behind the last), one workgroup per plane.  No tap leaves
+// the window in longitude - the polar rows, whose departure points lie anywhere on their circle, stay on the LDS path -
+// and no other workgroup writes this plane: the rows leaving the ring are folded onto their source cells IN LDS (the
+// wrap columns onto columns 0..NT-1, the rows beyond a pole onto their mirror rows, half a circle away) and go out as
+// plain 256-byte stores.  Against the 128-column strips: no float atomics (the strips' flush ran at the chip's
+// 1.3 TB/s atomic rate), no zero fill of the gradient, 1.02 instead of 1.19 window cells per point.
+// 4 WPR waves: WPR 64-column segments per row, two rows per wave and step.
+template <int MODE, int R, int WPR>
+__global__ void __launch_bounds__(256 * WPR)
+sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ field, const float* __restrict__ u,
+                     const float* __restrict__ v, float* __restrict__ gfield, float* __restrict__ gu,
+                     float* __restrict__ gv, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                     const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
+                     const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
+                     int64_t gf_bs, int64_t guv_bs, int strips, unsigned* __restrict__ queue, unsigned* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned qcount;
+  using Ring = StripRing<MODE, R>;
+  constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1, NTHREADS = 256 * WPR, SUBS = WPR / 2;
+  const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
+  const int tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* GO = gout + (int64_t)b * go_bs + (int64_t)k * P;
+  float* GF = gfield + (int64_t)b * gf_bs + (int64_t)k * P;
+  float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
+  float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
+  const int WS = W + NT, wx0 = p;
+  const int wn = R * WS;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);    // [R][WS] fixed-point sums
+  float* ring = smem + 2 * wn;                                               // [R][WS] field window
+  unsigned* stepmax = reinterpret_cast<unsigned*>(ring + wn);                // [3] max |cotangent| bits of a step
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
+  const StripLane tl(wave % WPR, lane, 0, W, W);
+  const int rw = wave / WPR;                         // rows rw and rw + 4 of a step
+  const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
+  // staging / flushing: wave -> ring row (wave & 7), 64-column chunks [cfirst, cfirst + nch) of the window row
+  const int srw = wave & 7, sub = wave >> 3;
+  const int nch_all = (WS + 63) >> 6, per = (nch_all + SUBS - 1) / SUBS;
+  const int cfirst = sub * per, nch = max(0, min(per, nch_all - cfirst));
+  const StripCols cs = strip_cols(wx0, WS, W, p, lane, cfirst);
+  unsigned* const q = queue + (size_t)plane * strips * 3 * (size_t)(H * STRIP_W);   // deferred points: |dy| beyond the ring
+  if (tid == 0) qcount = 0u;
+
+  float qu[2], qv[2], qg[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = min(rw + 4 * j, H - 1) * W + tl.cbase;
+    qu[j] = srow(U + idx)[tl.lx]; qv[j] = srow(V + idx)[tl.lx]; qg[j] = srow(GO + idx)[tl.lx];
+  }
+  const float lonc = lon_cells(srow(lon + tl.cbase)[tl.lx], g);
+
+  for (int i = tid; i < wn; i += NTHREADS) acc[i] = 0ull;
+  if (tid < 3) stepmax[tid] = 0u;
+  float pre[STRIP_CH];
+  const int lo0 = Ring::lo(0, p);
+  for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) {
+    strip_load_row(F, lo0 + r8 + srw, H, W, p, cs, nch, pre);
+    strip_store_row(ring, lo0 + r8 + srw, RMASK, WS, H, p, m0, m1, lane, nch, pre, cfirst);
+  }
+  strip_load_row(F, lo0 + RW + srw, H, W, p, cs, nch, pre);
+  __syncthreads();
+  {
+    unsigned mb = max(abs_bits(gm0), abs_bits(gm1));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mb = max(mb, abs_bits(qg[j]));
+    mb = wave_umax_lane63(mb);
+    if (lane == 63) atomicMax(&stepmax[0], mb);
+  }
+  __syncthreads();
+
+  int ecur = -128;
+  float scale = 0.f, inv_scale = 0.f;
+  auto set_scale = [&](int e) {
+    ecur = e;
+    if (e == 255) { scale = 0.f; inv_scale = NAN; }
+    else if (e == -128) { scale = 0.f; inv_scale = 0.f; }
+    else { scale = ldexpf(1.0f, 40 - e); inv_scale = ldexpf(1.0f, e - 40); }
+  };
+
+  // a row beyond a pole: its sums belong to the mirror row, half a circle away, which is still in the ring
+  auto fold_row = [&](int pr) {
+    const StripRow r = strip_row(pr, H, p);
+    if (!(r.valid && r.mir)) return;                       // wave-uniform
+    unsigned long long* arow = acc + (pr & RMASK) * WS;
+    unsigned long long* trow = acc + ((r.sr + p) & RMASK) * WS;
+#pragma unroll
+    for (int i = 0; i < STRIP_CH; ++i)
+      if (i < nch) {
+        const int lc = (int)lane + 64 * (cfirst + i);
+        if (lc < WS) {
+          const unsigned long long sv = arow[lc];
+          if (sv != 0ull) {
+            arow[lc] = 0ull;
+            atomicAdd(&trow[cs.pk[i] >> 16], sv);
+          }
+        }
+      }
+  };
+  // a source row leaves complete: wrap columns folded in, plain stores (every cell of the plane is written once)
+  auto flush_row = [&](int pr) {
+    const StripRow r = strip_row(pr, H, p);
+    if (!r.valid || r.mir) return;                          // wave-uniform
+    unsigned long long* arow = acc + (pr & RMASK) * WS;
+    const double inv = (double)inv_scale;
+    const global_ptr<float> dst = srow(GF + (int64_t)r.sr * W);
+#pragma unroll
+    for (int i = 0; i < STRIP_CH; ++i)
+      if (i < nch) {
+        const int j = (int)lane + 64 * (cfirst + i);
+        if (j < W) {
+          long long sv = (long long)arow[j];
+          arow[j] = 0ull;
+          if (j < NT) { sv += (long long)arow[j + W]; arow[j + W] = 0ull; }
+          dst[j] = (float)((double)sv * inv);
+        }
+      }
+  };
+
+  const float Hpf = (float)Hp, Wpf = (float)Wp, Wf = (float)W, wx0f = (float)wx0, WSf = (float)WS;
+  for (int s = 0; s < nsteps; ++s) {
+    const int lo = Ring::lo(s, p);
+    {
+      const int e = fixed_exponent(stepmax[s % 3]);
+      if (e > ecur) {
+        if (ecur != -128 && e != 255) {
+          const int sh = min(e - ecur, 63);
+          for (int i = tid; i < wn; i += NTHREADS) acc[i] = (unsigned long long)((long long)acc[i] >> sh);
+        }
+        set_scale(e);
+        __syncthreads();
+      }
+      if (tid == 0) stepmax[(s + 2) % 3] = 0u;
+    }
+    if (s > 0) {
+      // (a row beyond the south pole and its mirror row never leave in the same group of eight: lo(s) = -5 mod 8)
+      fold_row(lo - STRIP_ROWS + srw);
+      flush_row(lo - STRIP_ROWS + srw);
+    }
+    strip_store_row(ring, lo + RW + srw, RMASK, WS, H, p, m0, m1, lane, nch, pre, cfirst);
+    if (s + 1 < nsteps) strip_load_row(F, lo + R + srw, H, W, p, cs, nch, pre);
+    const float rlof = (float)lo, rhif = (float)(lo + RW - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int y = STRIP_ROWS * s + rw + 4 * j;          // wave-uniform
+      const float cu = qu[j], cv = qv[j], cgo = qg[j];
+      {
+        const int idx = min(y + STRIP_ROWS, H - 1) * W + tl.cbase;
+        qu[j] = srow(U + idx)[tl.lx]; qv[j] = srow(V + idx)[tl.lx]; qg[j] = srow(GO + idx)[tl.lx];
+      }
+      if (y < H) {
+        const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+        float ix, iy, tx, ty;
+        DepState st;
+        departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, &st);
+        int r0, c0;
+        const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
+        const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
+        float gix = 0.f, giy = 0.f;
+        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane);
+        if (tl.active && fast) {
+          float wx[NT], wy[NT], dwx[NT], dwy[NT];
+          Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
+          Interp<MODE>::dweights(tx, dwx); Interp<MODE>::dweights(ty, dwy);
+          const float gs_ = gval * scale;
+          double wxd[NT];
+#pragma unroll
+          for (int bb = 0; bb < NT; ++bb) wxd[bb] = (double)wx[bb];
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            const int rb = ((r0 + a) & RMASK) * WS + c0;
+            float sxv = 0.f, sdx = 0.f;
+            const double gwy = (double)(gs_ * wy[a]);
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) {
+              const float val = ring[rb + bb];
+              atomicAdd(&acc[rb + bb], fixed_from_product(gwy, wxd[bb]));
+              sxv = fmaf(val, wx[bb], sxv);
+              sdx = fmaf(val, dwx[bb], sdx);
+            }
+            gix = fmaf(wy[a], sdx, gix);
+            giy = fmaf(dwy[a], sxv, giy);
+          }
+          float guv, gvv;
+          departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
+          srow(GU + y * W + tl.cbase)[tl.lx] = guv;
+          srow(GV + y * W + tl.cbase)[tl.lx] = gvv;
+        }
+      }
+    }
+    {
+      unsigned mb = max(abs_bits(qg[0]), abs_bits(qg[1]));
+      mb = wave_umax_lane63(mb);
+      if (lane == 63 && s + 1 < nsteps) atomicMax(&stepmax[(s + 1) % 3], mb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  // what is still resident: first the rows beyond the poles onto their mirror rows, then the source rows
+  const int lo_last = Ring::lo(nsteps - 1, p);
+  for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) fold_row(lo_last + r8 + srw);
+  __syncthreads();
+  for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) flush_row(lo_last + r8 + srw);
+  if (tid < strips) counts[(size_t)plane * strips + tid] = tid == 0 ? qcount : 0u;
+}
+
+// the deferred points of the backward strips, one per lane: field gradient by global atomics, velocity gradients
+template <int MODE, bool DET>
+__global__ void __launch_bounds__(256)
+sl_advect_bwd_strip_fixup(const float* __restrict__ gout, const float* __restrict__ field, const float* __restrict__ u,
+                          const float* __restrict__ v, float* __restrict__ gfield, float* __restrict__ gu,
+                          float* __restrict__ gv, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                          const float* __restrict__ lon, const float* __restrict__ fmeans, const float* __restrict__ gmeans,
+                          int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs, int64_t gf_bs, int64_t guv_bs,
+                          int strips, unsigned long long* __restrict__ gacc, const unsigned* __restrict__ pmax,
+                          const unsigned* __restrict__ queue, const unsigned* __restrict__ counts) {
+  const int H = g.H, W = g.W, p = g.p, P = H * W;
+  const unsigned n = counts[blockIdx.x];
+  if (n == 0) return;
+  const int plane = blockIdx.x / strips;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* GO = gout + (int64_t)b * go_bs + (int64_t)k * P;
+  float* GF = gfield + (int64_t)b * gf_bs + (int64_t)k * P;
+  float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
+  float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
+  unsigned long long* GA = DET ? gacc + (int64_t)plane * P : nullptr;
+  const unsigned* q = queue + (size_t)blockIdx.x * 3 * (size_t)(H * STRIP_W);
+  const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
+  const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
+  float scale = 0.f;
+  if constexpr (DET) {
+    float inv;
+    fixed_point_scale(__uint_as_float(pmax[plane]), scale, inv);
+  }
+  const unsigned last = (unsigned)(H - 1) * (unsigned)W;
+  for (unsigned i = threadIdx.x; i < n; i += 256) {
+    const unsigned idx = q[i];
+    const float sa = sin_lat[idx], ca = cos_lat[idx];
+    float ix, iy, gix, giy;
+    DepState st;
+    departure_lane(U[idx], V[idx], sa, ca, lon_cells(lon[idx], g), g, ix, iy, &st);      // (no wave-uniform branches)
+    const float gval = idx < (unsigned)W ? gm0 : (idx >= last ? gm1 : GO[idx]);
+    scatter_global<MODE, DET>(F, GF, GA, ix, iy, H, W, p, m0, m1, gval, scale, gix, giy);
+    float guv, gvv;
+    departure_backward(st, sa, ca, gix * gval, giy * gval, g, guv, gvv);
+    GU[idx] = guv;
+    GV[idx] = gvv;
+  }
 }
 
 // ---- pole-row helpers of the tiled schedule ---------------------------------------------
@@ -2211,9 +2580,9 @@ constexpr int HALO_BWD = ADV_HALO_BWD;   // two workgroups of 512 threads per CU
 constexpr int MAX_HALO = 32;
 
 template <typename K>
-int reserve_lds(K kernel, const char* what) {
+int reserve_lds(K kernel, const char* what, int bytes = 160 * 1024) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          160 * 1024) != hipSuccess) {
+                          bytes) != hipSuccess) {
     paradis_set_error(what);
     return 2;
   }
@@ -2261,10 +2630,32 @@ int strip_halo_bwd(int W) { return W <= 512 ? 10 : 16; }
 
 // pole-row means of field and cotangent (tiled schedule); in deterministic mode also the per-plane max |cotangent|
 // and the 64-bit integer plane the tiles accumulate into
-extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W) {
-  size_t n = (size_t)B * K * 4 * sizeof(float) + 256;
-  if (paradis_deterministic()) n += (size_t)B * K * sizeof(unsigned) + 16 + (size_t)B * K * H * W * 8;
+// layout: [pole means of field, cotangent: 4 floats per plane] [deterministic mode: per-plane max, integer plane]
+// [strip schedule: counts and deferred-point lists, one H x 128 region per strip]
+static size_t adv_ws_det_bytes(int B, int K, int H, int W) {
+  return paradis_deterministic() ? (size_t)B * K * sizeof(unsigned) + 16 + (size_t)B * K * H * W * 8 + 16 : 0;
+}
+static size_t adv_ws_base_bytes(int B, int K) { return (((size_t)B * K * 4 * sizeof(float) + 255) & ~(size_t)255) + 256; }
+static bool adv_uses_strips(int H, int W, int p, int flags) {
+  // (the backward's whole-plane footprint is the larger one: sized for whichever direction tiles)
+  return (flags & PARADIS_ADVECT_SEPARABLE) && !(flags & PARADIS_ADVECT_GENERIC) && strip_ok(W, flags) &&
+         use_tiled(bwd_whole_lds((size_t)(H + 2 * p) * (W + 2 * p)), flags);
+}
+extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W, int flags) {
+  size_t n = adv_ws_base_bytes(B, K) + adv_ws_det_bytes(B, K, H, W) + 256;
+  if (adv_uses_strips(H, W, 2, flags) || adv_uses_strips(H, W, 1, flags)) {
+    const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
+    n += 3 * strips * (size_t)H * STRIP_W * sizeof(unsigned) + ((strips * sizeof(unsigned) + 255) & ~(size_t)255) + 256;
+  }
   return n;
+}
+// the deferred-point lists behind the other regions
+static unsigned* adv_ws_queue(void* workspace, int B, int K, int H, int W, unsigned** counts) {
+  char* base = (char*)workspace + adv_ws_base_bytes(B, K) + adv_ws_det_bytes(B, K, H, W);
+  base = (char*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
+  const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
+  *counts = (unsigned*)base;
+  return (unsigned*)(base + ((strips * sizeof(unsigned) + 255) & ~(size_t)255));
 }
 inline int stream_blocks_adv(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 256 * 32); }
 
@@ -2352,19 +2743,30 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
     PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_fwd: halo too wide");
     static PerDeviceOnce once_row;
     if (once_row.first()) {
-      if (reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 32>, "sl_advect_fwd: cannot reserve LDS") ||
-          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 32>, "sl_advect_fwd: cannot reserve LDS") ||
-          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 64>, "sl_advect_fwd: cannot reserve LDS") ||
-          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 64>, "sl_advect_fwd: cannot reserve LDS"))
+      if (reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 32>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 32>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 64>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 64>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX))
         return 2;
     }
 #define LAUNCH_STRIP_FWD(M, R_)                                                                                   \
     hipLaunchKernelGGL((sl_advect_fwd_strip<M, R_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS), slds, st, \
                        field, u, v, out, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans, K, g, f_bs, uv_bs,   \
-                       o_bs, hx, strips)
+                       o_bs, hx, strips, queue, counts)
+    unsigned* counts = nullptr;
+    unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
     if (mode == PARADIS_INTERP_BICUBIC) { if (ring == 32) LAUNCH_STRIP_FWD(PARADIS_INTERP_BICUBIC, 32); else LAUNCH_STRIP_FWD(PARADIS_INTERP_BICUBIC, 64); }
     else { if (ring == 32) LAUNCH_STRIP_FWD(PARADIS_INTERP_BILINEAR, 32); else LAUNCH_STRIP_FWD(PARADIS_INTERP_BILINEAR, 64); }
 #undef LAUNCH_STRIP_FWD
+    // the points whose tap block left the window, densely
+    if (mode == PARADIS_INTERP_BICUBIC)
+      hipLaunchKernelGGL((sl_advect_fwd_strip_fixup<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * strips)), dim3(256), 0, st,
+                         field, u, v, out, sin_lat, cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, strips,
+                         (const unsigned*)queue, (const unsigned*)counts);
+    else
+      hipLaunchKernelGGL((sl_advect_fwd_strip_fixup<PARADIS_INTERP_BILINEAR>), dim3((unsigned)(planes * strips)), dim3(256), 0, st,
+                         field, u, v, out, sin_lat, cos_lat, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, strips,
+                         (const unsigned*)queue, (const unsigned*)counts);
   } else if (separable(flags, lat_cells)) {      // (diagnostic A/B: the tile schedule of rounds 2-3)
     static PerDeviceOnce once_row;
     if (once_row.first()) {
@@ -2435,7 +2837,8 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
         (reinterpret_cast<uintptr_t>(pmax + planes) + 15) & ~(uintptr_t)15);
     hipLaunchKernelGGL(plane_absmax_kernel, dim3(planes), dim3(256), 0, st, gout, pmax, K, P, go_bs);
   }
-  if (pd_zero_async(gacc ? (void*)gacc : (void*)gfield, (size_t)planes * P * (gacc ? 8 : 4), st) != hipSuccess) {
+  const bool circle = separable(flags, lat_cells) && strip_ok(W, flags) && W <= 256 && !gacc && !(flags & PARADIS_ADVECT_STRIPS);
+  if (!circle && pd_zero_async(gacc ? (void*)gacc : (void*)gfield, (size_t)planes * P * (gacc ? 8 : 4), st) != hipSuccess) {
     paradis_set_error("sl_advect_bwd: memset failed");
     return 2;
   }
@@ -2467,16 +2870,50 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                      TILED_BWD_ARGS(gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon), vec4, gacc,         \
                      (const unsigned*)pmax)
   const bool cubic = mode == PARADIS_INTERP_BICUBIC;
-  if (separable(flags, lat_cells) && strip_ok(W, flags)) {
+  if (circle) {
+    // full-circle ring, one workgroup per plane: plain stores (gfield needs no zero fill: the memset above is skipped)
+    const int ring = strip_ring_rows(H), strips = (W + STRIP_W - 1) / STRIP_W;
+    const size_t slds = ((size_t)ring * (W + NT) * 3 + 8) * sizeof(float);
+    PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
+    static PerDeviceOnce once_circle;
+    if (once_circle.first()) {
+#define RESERVE_CIRCLE(M, R_, WPR_) reserve_lds(&sl_advect_bwd_circle<M, R_, WPR_>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX)
+      if (RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 32, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 32, 4) ||
+          RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 64, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 64, 4) ||
+          RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 32, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 32, 4) ||
+          RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 64, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 64, 4))
+        return 2;
+#undef RESERVE_CIRCLE
+    }
+    unsigned* counts = nullptr;
+    unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
+#define LAUNCH_CIRCLE(M, R_, WPR_)                                                                                   \
+    hipLaunchKernelGGL((sl_advect_bwd_circle<M, R_, WPR_>), dim3((unsigned)planes), dim3(256 * WPR_), slds, st, gout,  \
+                       field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,            \
+                       (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips, queue, counts)
+#define LAUNCH_CIRCLE_M(M)                                                                                           \
+    do {                                                                                                               \
+      if (W <= 128) { if (ring == 32) LAUNCH_CIRCLE(M, 32, 2); else LAUNCH_CIRCLE(M, 64, 2); }                        \
+      else { if (ring == 32) LAUNCH_CIRCLE(M, 32, 4); else LAUNCH_CIRCLE(M, 64, 4); }                                 \
+      hipLaunchKernelGGL((sl_advect_bwd_strip_fixup<M, false>), dim3((unsigned)(planes * strips)), dim3(256), 0, st,   \
+                         gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans,               \
+                         (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips,                        \
+                         (unsigned long long*)nullptr, (const unsigned*)nullptr, (const unsigned*)queue,               \
+                         (const unsigned*)counts);                                                                     \
+    } while (0)
+    if (cubic) LAUNCH_CIRCLE_M(PARADIS_INTERP_BICUBIC); else LAUNCH_CIRCLE_M(PARADIS_INTERP_BILINEAR);
+#undef LAUNCH_CIRCLE_M
+#undef LAUNCH_CIRCLE
+  } else if (separable(flags, lat_cells) && strip_ok(W, flags)) {
     const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_bwd(W), true);
     const int strips = (W + STRIP_W - 1) / STRIP_W;
     const size_t slds = ((size_t)ring * (STRIP_W + 2 * hx + NT) * 3 + 8) * sizeof(float);
-    PD_REQUIRE(slds <= 160 * 1024, "sl_advect_bwd: window does not fit LDS");
+    PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
     PD_REQUIRE((int64_t)planes * strips < (1ll << 31), "sl_advect_bwd: too many strips");
     PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_bwd: halo too wide");
     static PerDeviceOnce once_strip;
     if (once_strip.first()) {
-#define RESERVE_STRIP(M, R_, D) reserve_lds(&sl_advect_bwd_strip<M, R_, D>, "sl_advect_bwd: cannot reserve LDS")
+#define RESERVE_STRIP(M, R_, D) reserve_lds(&sl_advect_bwd_strip<M, R_, D>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX)
       if (RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 32, false) || RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 32, true) ||
           RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 64, false) || RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 64, true) ||
           RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 32, false) || RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 32, true) ||
@@ -2487,8 +2924,18 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
 #define LAUNCH_STRIP_BWD(M, R_, D)                                                                                  \
     hipLaunchKernelGGL((sl_advect_bwd_strip<M, R_, D>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS), slds, st, \
                        gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,      \
-                       (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, hx, strips, gacc, (const unsigned*)pmax)
-#define LAUNCH_STRIP_BWD_R(M, D) do { if (ring == 32) LAUNCH_STRIP_BWD(M, 32, D); else LAUNCH_STRIP_BWD(M, 64, D); } while (0)
+                       (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, hx, strips, gacc, (const unsigned*)pmax, \
+                       queue, counts)
+#define LAUNCH_STRIP_BWD_R(M, D)                                                                                     \
+    do {                                                                                                               \
+      if (ring == 32) LAUNCH_STRIP_BWD(M, 32, D); else LAUNCH_STRIP_BWD(M, 64, D);                                    \
+      hipLaunchKernelGGL((sl_advect_bwd_strip_fixup<M, D>), dim3((unsigned)(planes * strips)), dim3(256), 0, st, gout, \
+                         field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, \
+                         K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips, gacc, (const unsigned*)pmax,                 \
+                         (const unsigned*)queue, (const unsigned*)counts);                                            \
+    } while (0)
+    unsigned* counts = nullptr;
+    unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
     if (gacc) { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, true); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, true); }
     else { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, false); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, false); }
 #undef LAUNCH_STRIP_BWD_R

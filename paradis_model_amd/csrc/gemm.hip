@@ -605,6 +605,9 @@ constexpr int SIMG = simg(3);
 // there per element; it alternates in sign every 32 rows and 32 columns and cancels in every sum over more than a
 // block.  The weight gradient alternates by K-range slab instead (odd slabs negate dY): there the offsets of an
 // element's slabs cancel in the slab sum.
+#ifndef SPLIT_STAGGER         // (-DSPLIT_STAGGER=1: A/B build of the staggered 128 x 256 kernel)
+#define SPLIT_STAGGER 0
+#endif
 #ifndef SPLIT_SIGNED          // (-DSPLIT_SIGNED=0: the unsigned accumulation of rounds 1-3, for A/B runs)
 #define SPLIT_SIGNED 1
 #endif
@@ -1123,20 +1126,38 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
       // three planes at 128 registers: the B fragments of ONE plane at a time (8 registers instead of 24), planes
       // in the order l, m, h so that the products still arrive roughly smallest first:
       //   ah.bl | am.bm, ah.bm | al.bh, am.bh, ah.bh
-      u32x4 a[3][2], b[2];
+      auto mfma_block = [&]() __attribute__((always_inline)) {
+        u32x4 a[3][2], b[2];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) { a[pl][0] = As[pl * 2 * SCH]; a[pl][1] = As[pl * 2 * SCH + 32]; }
+        for (int pl = 0; pl < 3; ++pl) { a[pl][0] = As[pl * 2 * SCH]; a[pl][1] = As[pl * 2 * SCH + 32]; }
 #pragma unroll
-      for (int pb = 2; pb >= 0; --pb) {
-        b[0] = Bs[pb * 2 * SCH]; b[1] = Bs[pb * 2 * SCH + 32];
+        for (int pb = 2; pb >= 0; --pb) {
+          b[0] = Bs[pb * 2 * SCH]; b[1] = Bs[pb * 2 * SCH + 32];
 #pragma unroll
-        for (int pa = 2 - pb; pa >= 0; --pa)
+          for (int pa = 2 - pb; pa >= 0; --pa)
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) SPLIT_MFMA(a[pa][tm], b[tn], acc[tm][tn]);
+              for (int tn = 0; tn < 2; ++tn) SPLIT_MFMA(a[pa][tm], b[tn], acc[tm][tn]);
+        }
+      };
+#if SPLIT_STAGGER
+      // SIMD partners out of phase (MI355X_MICROARCH.md, two waves per SIMD, item 9): waves 4-7 (sub 1) split and store
+      // tile t+1 FIRST and multiply afterwards, waves 0-3 the other way round - one half of a SIMD's waves is on the
+      // vector unit and the LDS store path while the other half feeds the matrix pipe
+      if (sub == 1) {
+        split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block();
+      } else {
+        mfma_block();
+        __builtin_amdgcn_sched_barrier(0);
+        split_store(xsplit, Bst + (cur ^ 1) * SIMG);
       }
+#else
+      mfma_block();
       split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+#endif
       // (no sched_group_barrier pinning here: the 1 MFMA : 3 VALU pattern of the 128 x 128 kernel measured 0.7 % slower
       //  on the step than the compiler's own order, three rounds on one box)
     } else {

@@ -209,7 +209,7 @@ def _sl_advect(field, u, v, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lon, 
         u, v = u.contiguous(), v.contiguous()
         u_bs = K * H * W
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
-    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W, flags), field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W,   # algorithmic bytes: 16 B / gather point
               dptr(field), dptr(u), dptr(v), dptr(out), dptr(sl), dptr(cl), dptr(lc), dptr(lo), B, K, H, W,
               f_bs, u_bs, K * H * W, dt, min_lat, min_lon, d_lat, d_lon, mode, flags, dptr(ws), stream_ptr())
@@ -236,7 +236,7 @@ def _sl_advect_backward(gout, field, u, v, sl, cl, lc, lo, dt, min_lat, min_lon,
         u_bs = P
     gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
     gu, gv = torch.empty_like(gfield), torch.empty_like(gfield)
-    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W, flags), gout.device)
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W,   # algorithmic bytes: 28 B / gather point
               dptr(gout), dptr(field), dptr(u), dptr(v), dptr(gfield), dptr(gu), dptr(gv), dptr(sl),
               dptr(cl), dptr(lc), dptr(lo), B, K, H, W, P, f_bs, u_bs, P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
@@ -273,7 +273,7 @@ def _sl_advect_vel(field, vel, sl, cl, lc, lo, dt, min_lat, min_lon, d_lat, d_lo
     vel = vel.contiguous()
     P = K * H * W
     out = torch.empty(B, K, H, W, dtype=field.dtype, device=field.device)
-    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), field.device)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W, flags), field.device)
     _lib.call("sl_advect_fwd", 16.0 * B * K * H * W, dptr(field), dptr(vel[:, :K]), dptr(vel[:, K:]), dptr(out),
               dptr(sl), dptr(cl), dptr(lc), dptr(lo), B, K, H, W, f_bs, 2 * P, P, dt, min_lat, min_lon, d_lat, d_lon, mode,
               flags, dptr(ws), stream_ptr())
@@ -296,7 +296,7 @@ def _sl_advect_vel_backward(gout, field, vel, sl, cl, lc, lo, dt, min_lat, min_l
     vel = vel.contiguous()
     gfield = torch.empty(B, K, H, W, dtype=gout.dtype, device=gout.device)
     gvel = torch.empty_like(vel)
-    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W), gout.device)
+    ws = _ws(lib.paradis_sl_advect_ws_bytes(B, K, H, W, flags), gout.device)
     _lib.call("sl_advect_bwd", 28.0 * B * K * H * W, dptr(gout), dptr(field), dptr(vel[:, :K]),
               dptr(vel[:, K:]), dptr(gfield), dptr(gvel[:, :K]), dptr(gvel[:, K:]), dptr(sl), dptr(cl),
               dptr(lc), dptr(lo), B, K, H, W, P, f_bs, 2 * P, P, 2 * P, dt, min_lat, min_lon, d_lat, d_lon, mode,
@@ -322,17 +322,19 @@ def _advv_backward(ctx, gout):
 _autograd("sl_advect_vel", _advv_setup, _advv_backward)
 
 
-ADVECT_GENERIC, ADVECT_TILED, ADVECT_SEPARABLE, ADVECT_TILES = 1, 2, 4, 8     # include/paradis_hip.h PARADIS_ADVECT_*
+ADVECT_GENERIC, ADVECT_TILED, ADVECT_SEPARABLE, ADVECT_TILES, ADVECT_STRIPS = 1, 2, 4, 8, 16     # include/paradis_hip.h PARADIS_ADVECT_*
 # schedule hints applied when a call passes none (diagnostics: tools/advect_halo_sweep.py)
 ADVECT_FLAGS = int(os.environ.get("PARADIS_ADVECT_FLAGS", "0"), 0)
 
 
 def advect_flags(tiled: bool = False, halo: Optional[int] = None, halo_bwd: Optional[int] = None,
-                 generic: bool = False, tiles: bool = False) -> int:
+                 generic: bool = False, tiles: bool = False, strips: bool = False) -> int:
     """``flags`` of the advection ops: force the windowed schedule and/or its longitude halo (padded cells;
     ``halo_bwd`` overrides it for the backward kernel), the generic whole-plane kernel, or (``tiles``, diagnostic)
-    the tile schedule of rounds 2-3 in place of the strips."""
+    the tile schedule of rounds 2-3 in place of the strips; ``strips``: the backward's 128-column strips where the
+    full-circle ring (W <= 256) would run."""
     return ((ADVECT_TILED if tiled else 0) | (ADVECT_GENERIC if generic else 0) | (ADVECT_TILES if tiles else 0)
+            | (ADVECT_STRIPS if strips else 0)
             | (((int(halo) + 1) << 8) if halo is not None else 0)
             | (((int(halo_bwd) + 1) << 16) if halo_bwd is not None else 0))
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/paradis_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.lib.paradis_abi_version() == 5
+    assert _lib.lib.paradis_abi_version() == 6
 
 
 def test_argument_validation_without_gpu():
@@ -56,7 +56,7 @@ def test_argument_validation_without_gpu():
     assert L.paradis_normalize_features(None, None, None, None, 0, 5, 1e-12, 0, None) == 0
     # zero-sized batches are accepted and do nothing
     assert L.paradis_geocyclic_pad_fwd(None, None, 0, 8, 8, 1, None) == 0
-    assert L.paradis_sl_advect_ws_bytes(2, 3, 8, 16) >= 2 * 3 * 4 * 4
+    assert L.paradis_sl_advect_ws_bytes(2, 3, 8, 16, 0) >= 2 * 3 * 4 * 4
 
 
 def test_ops_refuse_cpu_tensors():

@@ -43,11 +43,14 @@ def test_pad_rejects_bad_input(ops):
         ops.geocyclic_pad(torch.randn(1, 1, 8, 8), 1)  # CPU tensor: no fallback
 
 
-def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6, generic=False):
-    """force_gmem: use the tiled schedule (window + global fallback) regardless of plane size;
-    a small halo forces most taps through the fallback path.  generic: the whole-plane kernel with
-    per-point table loads instead of the one-wave-per-row kernel of W == 64 grids."""
-    flags = ops.advect_flags(tiled=force_gmem, halo=halo if force_gmem else None, generic=generic)
+def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6, generic=False, strips=False, tiles=False):
+    """force_gmem: use the windowed schedules (ring / tile window + deferred points through global memory)
+    regardless of plane size; a small longitude halo sends most points of the 128-column strips through the
+    deferred path.  generic: the whole-plane kernel with per-point table loads instead of the one-wave-per-row
+    kernel of W == 64 grids (with force_gmem: the generic tile kernel).  strips: the backward's 128-column strips
+    where the full-circle ring would run (W <= 256).  tiles: the separable tile kernels of rounds 2-3."""
+    flags = ops.advect_flags(tiled=force_gmem, halo=halo if force_gmem else None, generic=generic, strips=strips,
+                             tiles=tiles)
     geom = ops.AdvectGeometry(lg, og)
     fd, ud, vd = (t.cuda().requires_grad_(True) for t in (f, u, v))
     y = ops.sl_advect(fd, ud, vd, geom, dt, mode, flags=flags)
@@ -56,9 +59,13 @@ def _run_advect(ops, f, u, v, ct, lg, og, dt, mode, force_gmem, halo=6, generic=
     return y.detach().cpu(), fd.grad.cpu(), ud.grad.cpu(), vd.grad.cpu()
 
 
-@pytest.mark.parametrize("force_gmem,halo,generic", [(False, 6, False), (False, 6, True), (True, 6, False),
-                                                     (True, 0, False), (True, 6, True), (True, 0, True)])
-def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic):
+@pytest.mark.parametrize("force_gmem,halo,generic,strips,tiles",
+                         [(False, 6, False, False, False), (False, 6, True, False, False),
+                          (True, 6, False, False, False), (True, 0, False, False, False),      # ring: strips fwd, circle bwd
+                          (True, 6, False, True, False), (True, 0, False, True, False),        # ring: strips fwd and bwd
+                          (True, 6, False, False, True), (True, 0, False, False, True),        # tile kernels (rounds 2-3)
+                          (True, 6, True, False, False), (True, 0, True, False, False)])
+def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic, strips, tiles):
     """Tolerance protocol of SURVEY.md 8c(iii): rms-rel vs CPU fp32 <= 1e-5 and error vs the fp64
     golden <= 1.5x the CPU-fp32 golden's own error vs fp64 (+ a small absolute floor)."""
     g = load_golden("g2_advect.pt")
@@ -72,7 +79,8 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic):
         v = seeded(s + 2, B, K, H, W, scale=rec["scale"])
         ct = seeded(s + 3, B, K, H, W)
         assert_chk([f, u, v, ct], rec["chk"])
-        y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, rec["dt"], rec["mode"], force_gmem, halo, generic)
+        y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, rec["dt"], rec["mode"], force_gmem, halo, generic,
+                                    strips, tiles)
         e_cpu = rms_rel(rec["out_f32"], rec["out_f64"])
         e_gpu = rms_rel(y, rec["out_f64"])
         r32 = rms_rel(y, rec["out_f32"])
@@ -98,9 +106,11 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic):
         print("  %-24s %s %.2e %.2e" % r)
 
 
-@pytest.mark.parametrize("H,W,poles,mode", [(32, 64, False, "bicubic"), (33, 64, True, "bilinear"),
-                                            (128, 256, False, "bicubic"), (65, 130, True, "bicubic")])
-def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode):
+@pytest.mark.parametrize("H,W,poles,mode,strips", [(32, 64, False, "bicubic", False), (33, 64, True, "bilinear", False),
+                                                   (128, 256, False, "bicubic", False), (65, 130, True, "bicubic", False),
+                                                   (128, 256, False, "bicubic", True), (65, 130, True, "bilinear", True),
+                                                   (181, 360, True, "bicubic", False)])
+def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode, strips):
     """Gradients against fp64 autograd through the oracle (the formula check)."""
     B, K = 2, 4
     _, lg, og = make_grid(H, W, poles)
@@ -109,7 +119,7 @@ def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode):
     fd, ud, vd = (t.double().requires_grad_(True) for t in (f, u, v))
     yr = O.sl_advect_core(fd, ud, vd, 0.196887, geo, mode)
     yr.backward(ct.double())
-    y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, 0.196887, mode, False)
+    y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, 0.196887, mode, False, strips=strips)
     # fp32 coordinate rounding is amplified by the grid size: judge against the CPU fp32 oracle's
     # own distance to fp64 (SURVEY.md 8c iii)
     f32, u32, v32 = (t.clone().requires_grad_(True) for t in (f, u, v))
