@@ -59,36 +59,32 @@ class Paradis(nn.Module):
 
     def __init__(self, datamodule, cfg, lat_grid, lon_grid):
         super().__init__()
-        self.nlat, self.nlon = lat_grid.shape[0], lat_grid.shape[1]
+        # --- what the configuration fixes (reference model/paradis.py:37-83; the attribute names are the ones the
+        #     trainer reads: num_vels, num_layers, dt, num_common_features, n_inputs, gradient_checkpoint, step_fn)
+        mcfg, pb = cfg.model, cfg.model.physblock
+        self.nlat, self.nlon = (int(n) for n in lat_grid.shape)
         mesh_size = (self.nlat, self.nlon)
-
-        hidden_dim = cfg.model.get("latent_size")
-        self.num_vels = cfg.model.get("velocity_vectors")
-        adv_interpolation = cfg.model.get("adv_interpolation")
-        bias_channels = cfg.model.get("bias_channels", 4)
-        self.num_layers = max(1, cfg.model.num_layers)
-        self.dt = get_scaled_timestep(cfg.model.get("base_dt")) / self.num_layers
-        self.activation_function = _get_activation_cls(cfg.model.activation)
-
-        input_dim = (datamodule.dataset.num_in_dyn_features
-                     + datamodule.dataset.num_in_static_features)
-        self.num_common_features = datamodule.num_common_features
-        self.n_inputs = cfg.dataset.n_time_inputs
-
-        self.step_fn = self._layer_step
-        self.gradient_checkpoint = cfg.compute.get("gradient_checkpointing", False)
-        if self.gradient_checkpoint:
-            self.step_fn = self._checkpointed_step
-
-        pb = cfg.model.physblock
-        static_dim = 128
-        stride = cfg.model.get("coarsening_factor", 1)
+        stride = mcfg.get("coarsening_factor", 1)
         if stride < 1:
             raise ValueError("Coarsening factor must be >=1")
-        self.nlat_coarse = (self.nlat - 1) // stride + 1
-        self.nlon_coarse = self.nlon // stride
+        self.nlat_coarse, self.nlon_coarse = (self.nlat - 1) // stride + 1, self.nlon // stride
         mesh_coarse = (self.nlat_coarse, self.nlon_coarse)
-        act = self.activation_function
+
+        self.num_layers = max(1, mcfg.num_layers)
+        self.num_vels = mcfg.get("velocity_vectors")
+        self.dt = get_scaled_timestep(mcfg.get("base_dt")) / self.num_layers      # one ADR layer's share of the step
+        self.activation_function = act = _get_activation_cls(mcfg.activation)
+        hidden_dim, bias_channels = mcfg.get("latent_size"), mcfg.get("bias_channels", 4)
+        adv_interpolation = mcfg.get("adv_interpolation")
+        static_dim = 128                                                          # (hard-wired upstream, paradis.py:83)
+
+        ds = datamodule.dataset
+        input_dim = ds.num_in_dyn_features + ds.num_in_static_features
+        self.num_common_features, self.n_inputs = datamodule.num_common_features, cfg.dataset.n_time_inputs
+        self.n_static = len(cfg.features.input.constants)
+
+        self.gradient_checkpoint = bool(cfg.compute.get("gradient_checkpointing", False))
+        self.step_fn = self._checkpointed_step if self.gradient_checkpoint else self._layer_step
 
         # construction order = the reference's, so a fixed seed yields identical initial weights
         self.input_proj = GMBlock(layers=pb.input_proj.layers, input_dim=input_dim,
@@ -124,7 +120,6 @@ class Paradis(nn.Module):
 
         self.alpha_adv = nn.Parameter(torch.full((self.num_layers, hidden_dim), -1.0))
         self.downsample = PhysicalDownsample(stride=stride)
-        self.n_static = len(cfg.features.input.constants)
         self.static_encoder = StaticEncoder(self.n_static, static_dim, mesh_size)
 
     # ------------------------------------------------------------------ helpers

@@ -259,6 +259,28 @@ def test_downsample_upsample_golden(ops):
     assert torch.equal(ops.upsample_lonp(x.cuda(), 8, 16).cpu(), x)   # identity at stride 1
 
 
+@pytest.mark.parametrize("Hc,Wc,H,W", [(16, 32, 32, 64), (9, 16, 33, 64), (11, 22, 32, 66), (8, 16, 32, 64), (5, 7, 5, 28)])
+def test_upsample_backward_gather_vs_oracle(ops, Hc, Wc, H, W):
+    """The adjoint of the lon-periodic upsampling (reference model/paradis.py:208-220) as a gather over the fine points
+    that reference a coarse cell: equal to fp64 autograd through the oracle for strides 2, 3, 4 (incl. the wrap of the
+    last fine columns onto coarse column 0 and grids with pole rows), and bitwise reproducible - no atomics."""
+    from oracle import paradis_oracle as O
+    x = torch.randn(2, 3, Hc, Wc)
+    ct = torch.randn(2, 3, H, W)
+    xr = x.double().requires_grad_(True)
+    O.upsample_lon_periodic(xr, H, W).backward(ct.double())
+    grads = []
+    for _ in range(2):
+        xd = x.cuda().requires_grad_(True)
+        y = ops.upsample_lonp(xd, H, W)
+        y.backward(ct.cuda())
+        grads.append(xd.grad.cpu())
+    assert torch.equal(grads[0], grads[1])
+    err = float((grads[0].double() - xr.grad).abs().max() / xr.grad.abs().max())
+    assert err <= 2e-6, err
+    assert float((y.detach().cpu().double() - O.upsample_lon_periodic(x.double(), H, W)).abs().max()) <= 1e-5
+
+
 # ----------------------------------------------------------------------------------- elementwise
 @pytest.mark.parametrize("act", ["SiLU", "GELU"])
 def test_activation_and_blend(ops, act):

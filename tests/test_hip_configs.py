@@ -183,56 +183,73 @@ def _oracle_grads_ckpt(model, spec, x, ct, lg, og, dtype):
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
 
-@pytest.mark.parametrize("num_layers,arithmetic", [(1, "bf16x3"), (2, "exact")])
-def test_cfg3_default_width_model_128x256_gradients_fp64_protocol(num_layers, arithmetic, monkeypatch):
+def test_cfg3_default_width_model_128x256_gradients_fp64_protocol():
     """configs[3]'s per-sample work inside the full-width model (latent 1024, 768 velocity planes, every block of the
-    default configuration): forward AND every parameter gradient at 128x256, B=1 - the tile-row advection scatter
-    with its window flush, the GlobalBias projection adjoint behind the GEMM epilogue, split-k weight gradients over
-    32,768 points - by the fp64 protocol of SURVEY 8c(iii) with the bounds of the 32x64 default-model test
-    (tests/test_hip_model.py): the HIP gradient's distance to the fp64 oracle against the CPU-fp32 oracle's own.
+    default configuration): forward AND every parameter gradient at 128x256, B=1 - the ring-window advection scatter,
+    the GlobalBias projection adjoint behind the GEMM epilogue, split-k weight gradients over 32,768 points - on the
+    DEFAULT arithmetic (bf16x3), two ADR layers (the second layer's advection differentiates through the first's),
+    by the fp64 protocol of SURVEY 8c(iii): the HIP gradient's distance to the fp64 oracle against the CPU-fp32
+    oracle's own, as a DISTRIBUTION over three (input, cotangent) seeds.
 
-    Smooth inputs, and one or two ADR layers instead of eight.  What was measured (round 3, tools/cfg3_grad_probe.py):
-      * eight layers: the CPU-fp32 oracle's own gradients are 8e-5 (median over the 335 parameters) to 7e-2
-        (velocity_nets.3) off the fp64 oracle, with white-noise inputs 1-20 % off - every layer's semi-Lagrangian
-        displacement amplifies fp32 coordinate rounding (4 x more cells per radian than at 32x64) and the product
-        over the layers is chaotic;
-      * two layers (the second layer's advection differentiates through the first's): CPU-fp32 still up to 4.1e-2 off,
-        i.e. rounding is amplified ~1e5-fold on the velocity networks, and the RATIO to the CPU error becomes a
-        lottery between arithmetics of the same class: f32-MFMA GEMMs worst 4.05 x the CPU error (norm-wise median
-        2.5, max 3.95); the bf16x3 GEMMs on 128x128 tiles 0.57 x (median 0.61), the same six bf16 products on the
-        128x256 tile - equal GEMM-level accuracy on every layer shape, tools/gemm_wide_check.py: 1.5e-6 vs 1.5e-6
-        of max |C|, only the order of the partial products differs - 8.9 x (median 7.0).  So the two-layer chain is
-        asserted on the f32-MFMA arithmetic, whose summation is the CPU's up to ordering;
-      * one layer: CPU-fp32 1.2e-6 in the median (max 7e-3 on velocity_nets.0.0-GlobalBias.V); the shipped bf16x3
-        path is at most 6.5 x that on max-abs (that same parameter) and 2.0 x norm-wise in the median - asserted
-        on the default arithmetic.
-    The eight-layer model at this grid is covered forward-only (above, 1e-5) and by the B = 8 training-step
-    properties (below)."""
-    from paradis_model_amd import ops
+    Why a distribution (round 4, tools/cfg3_grad_dist.py, profiles/r04_cfg3_grad_dist.json: 8 seeds): the chain
+    amplifies rounding ~1e5-fold (CPU-fp32 itself up to 1e-1 off fp64 on single parameters), every parameter's error
+    of one seed is the same few amplified roundings, so the per-seed median of the norm-wise ratio GPU / CPU-fp32
+    moves between 1.3 and 3.3 for EVERY arithmetic:
+        CPU-fp32 with permuted GEMM summation order (control)   median of medians 1.01   (0.60 .. 1.36)
+        f32-MFMA GEMMs (exact)                                    2.23   (1.26 .. 2.35), one seed of eight fails the
+                                                                         single-seed bounds below (11 parameters)
+        bf16x3 (default, sign checkerboard)                       2.04   (1.28 .. 3.25), one seed of eight (42)
+        bf16x3 of rounds 1-3 (no checkerboard)                    2.02   (1.17 .. 4.09), and 24-25 x on
+                                                                         reaction.1.0-ChannelNorm.bias in EVERY seed
+    - the GPU GEMMs carry 8-10 u of zero-mean noise where oneDNN's blocked sums carry 3 (tools/gemm_bias_check.py), hence
+    ~2 for both GPU arithmetics; what set the old bf16x3 apart was not its noise but an OFFSET shared by all outputs
+    (the bf16 MFMA floors its accumulator when a k-tile's product sum outweighs it), which sums over pixels added up
+    coherently.  The checkerboard of negated-space blocks (csrc/gemm.hip) removes it; this test would catch its return.
+
+    Asserted: forward <= 1e-5 per seed; median over the seeds of the per-seed median ratio <= 3 and every per-seed
+    median <= 4.5; at least two of the three seeds pass the single-seed bounds of tests/test_hip_model.py for EVERY
+    parameter (8 x max-abs, 5 x norm-wise); no parameter of any seed beyond 12 x norm-wise and the pixel-sum gradient
+    that exposed the offset (reaction.1.0-ChannelNorm.bias) within 6 x in every seed."""
     from tests.test_hip_model import _check_grads_by_fp64_protocol
-    monkeypatch.setattr(ops, "GEMM_SCHEME", {"bf16x3": ops.GEMM_BF16X3, "exact": ops.GEMM_EXACT}[arithmetic])
     cfg = default_config()
-    cfg.model.num_layers = num_layers
+    cfg.model.num_layers = 2
     H, W = 128, 256
     _, lg, og = make_grid(H, W, False)
-    model = _build(cfg, lg, og, bias_scale=0.05)
     spec = _spec(cfg, H, W)
-    x = _smooth(seeded(23, 1, 186, H, W)) * 4.0
-    x[:, -2], x[:, -1] = lg, og
-    ct = _smooth(seeded(24, 1, 97, H, W)) * 4.0
-    y32, g32 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float32)
-    y64, g64 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float64)
-    got = model(x.cuda())
-    (got * ct.cuda()).sum().backward()
-    e, e_cpu = max_rel(got.detach().cpu(), y32), max_rel(y32, y64)
-    print("cfg3 128x256 L=%d %s: forward max-rel vs cpu32 %.2e (cpu32 vs fp64 %.2e)" % (num_layers, arithmetic, e, e_cpu))
-    assert e <= 1e-5, e
-    ratios = sorted(rms_rel(p.grad.cpu().double(), g64[n]) / max(rms_rel(g32[n].double(), g64[n]), 1e-12)
-                    for n, p in model.named_parameters() if n in g64 and float(g64[n].abs().max()) > 0)
-    print("cfg3 128x256 L=%d %s: norm-wise error ratio gpu / cpu32: median %.2f max %.2f"
-          % (num_layers, arithmetic, ratios[len(ratios) // 2], ratios[-1]))
-    worst = _check_grads_by_fp64_protocol(model, g32, g64)
-    print("cfg3 128x256 L=%d %s: worst grad max-rel vs fp64 (gpu, cpu32)" % (num_layers, arithmetic), worst)
+    medians, passed, worst_all, sentinel = [], 0, 0.0, []
+    for seed in range(3):
+        model = _build(cfg, lg, og, bias_scale=0.05)
+        x = _smooth(seeded(23 + 10 * seed, 1, 186, H, W)) * 4.0
+        x[:, -2], x[:, -1] = lg, og
+        ct = _smooth(seeded(24 + 10 * seed, 1, 97, H, W)) * 4.0
+        y32, g32 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float32)
+        y64, g64 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float64)
+        got = model(x.cuda())
+        (got * ct.cuda()).sum().backward()
+        e, e_cpu = max_rel(got.detach().cpu(), y32), max_rel(y32, y64)
+        assert e <= 1e-5, (seed, e)
+        ratios = {n: rms_rel(p.grad.cpu().double(), g64[n]) / max(rms_rel(g32[n].double(), g64[n]), 1e-12)
+                  for n, p in model.named_parameters() if n in g64 and float(g64[n].abs().max()) > 0}
+        rs = sorted(ratios.values())
+        medians.append(rs[len(rs) // 2])
+        worst_all = max(worst_all, rs[-1])
+        sentinel.append(ratios["reaction.1.0-ChannelNorm.bias"])
+        try:
+            _check_grads_by_fp64_protocol(model, g32, g64)
+            ok = True
+        except AssertionError as exc:
+            ok = False
+            print("seed %d: outside the single-seed bounds: %d parameters" % (seed, len(exc.args[0])))
+        passed += ok
+        print("cfg3 128x256 L=2 bf16x3 seed %d: forward %.2e (cpu32 vs fp64 %.2e); norm-wise ratio gpu / cpu32 median %.2f "
+              "max %.2f; ChannelNorm.bias %.2f; single-seed bounds %s" % (seed, e, e_cpu, medians[-1], rs[-1], sentinel[-1], ok))
+        del model, got
+        torch.cuda.empty_cache()
+    med = sorted(medians)[1]
+    assert med <= 3.0 and max(medians) <= 4.5, medians
+    assert passed >= 2, (passed, medians)
+    assert worst_all <= 12.0, worst_all
+    assert max(sentinel) <= 6.0, sentinel
 
 
 def test_cfg3_train_step_b8_properties():
