@@ -597,13 +597,14 @@ constexpr int SIMG = simg(3);
 // zero-mean noise (f32 MFMA: +0.002 u on 9.6 u), -8 u on the weight gradient's 32,768-term sums.  Harmless per element,
 // but sums over pixels or channels of a GEMM output (bias / ChannelNorm parameter gradients over 32,768 points, the
 // per-pixel channel statistics) add the offset coherently where noise averages out: 0.9 u x 32,768 against 8.2 u x 181.
-// Remedy without a second accumulator set or VALU work per tile: run alternate 32 x 32 blocks of the output in the
-// NEGATED space.  The weight image holds the rows of odd 32-row blocks with the opposite sign (free: written once by
-// split_weights_kernel), the activation columns of odd 32-column blocks are negated while they are split in registers
-// (-x splits exactly into -h, -m, -l), so block (tm, tn) accumulates (-1)^(tm+tn) C: there the floor acts on -C, the
-// offset of C is +0.9 u, and the epilogue flips the two off-diagonal blocks of a wave tile back.  The offset is still
-// there per element; it alternates in sign every 32 rows and 32 columns and cancels in every sum over more than a
-// block.  The weight gradient alternates by K-range slab instead (odd slabs negate dY): there the offsets of an
+// Remedy without a second accumulator set or VALU work per tile: run alternate 32-row x 64-column blocks of the output
+// in the NEGATED space.  The weight image holds the rows of odd 32-row blocks with the opposite sign (free: written once
+// by split_weights_kernel), the activation columns of odd 64-column blocks - the columns ONE wave stages - are negated
+// while they are split in registers (-x splits exactly into -h, -m, -l; in the 128 x 256 kernel the sign is a
+// compile-time property of the code path a staging wave takes, so it rides on source modifiers), so block (tm) of
+// compute wave (wm, wn) accumulates (-1)^(tm+wn) C: there the floor acts on -C, the offset of C is +0.9 u, and the
+// epilogue flips those blocks back.  The offset is still there per element; it alternates in sign every 32 rows and
+// 64 columns and cancels in every sum over more than a block.  The weight gradient alternates by K-range slab instead (odd slabs negate dY): there the offsets of an
 // element's slabs cancel in the slab sum.
 #ifndef SPLIT_STAGGER         // (-DSPLIT_STAGGER=1: A/B build of the staggered 128 x 256 kernel)
 #define SPLIT_STAGGER 0
@@ -611,17 +612,23 @@ constexpr int SIMG = simg(3);
 #ifndef SPLIT_SIGNED          // (-DSPLIT_SIGNED=0: the unsigned accumulation of rounds 1-3, for A/B runs)
 #define SPLIT_SIGNED 1
 #endif
+#ifndef SPLIT_SIGNED_WGRAD    // (the slab alternation of the weight gradient alone)
+#define SPLIT_SIGNED_WGRAD SPLIT_SIGNED
+#endif
 // sign bit of the staging thread's activation column (column = tid & 127 of a 128-column tile)
-__device__ __forceinline__ uint32_t split_flip_mask(int col) { return SPLIT_SIGNED && (col & 32) ? 0x80000000u : 0u; }
+__device__ __forceinline__ uint32_t split_flip_mask(int col) { return SPLIT_SIGNED && (col & 64) ? 0x80000000u : 0u; }
 __device__ __forceinline__ void flip8(float (&y)[8], const float (&x)[8], uint32_t mask) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) y[j] = __uint_as_float(__float_as_uint(x[j]) ^ mask);
 }
-// blocks (0,1) and (1,0) of a wave tile hold -C
-__device__ __forceinline__ void split_unflip(f32x16 (&acc)[2][2]) {
+// the row blocks tm with (tm + wn) odd hold -C (wn = the wave's 64-column half: the sign of its activation columns)
+__device__ __forceinline__ void split_unflip(f32x16 (&acc)[2][2], int wn) {
   if (!SPLIT_SIGNED) return;
+  const float s0 = wn ? -1.f : 1.f, s1 = -s0;          // wave-uniform
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][1][r] = -acc[0][1][r]; acc[1][0][r] = -acc[1][0][r]; }
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][tn][r] *= s0; acc[1][tn][r] *= s1; }
 }
 
 // ---- f16x2 scheme ------------------------------------------------------------------------------
@@ -689,6 +696,16 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, 
   h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
   m = (u32x4){mm[0], mm[1], mm[2], mm[3]};
   l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+// -x splits exactly into -h, -m, -l: with a compile-time sign the negation rides on the source modifiers of the
+// conversion and the first subtraction (no instruction of its own)
+template <bool NEG>
+__device__ __forceinline__ void split8_signed(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  float y[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[j] = NEG ? -x[j] : x[j];
+  split8(y, h, m, l);
 }
 
 __device__ __forceinline__ void split8_f16(const float (&x)[8], float s, u32x4& h, u32x4& l) {
@@ -907,7 +924,7 @@ pw_gemm_split_kernel(GemmArgs g) {
     if constexpr (NP == 3) {
       u32x4 h, m, l;
       float xs[8];
-      flip8(xs, x, flip);          // sign checkerboard: odd 32-column blocks are staged negated
+      flip8(xs, x, flip);          // sign checkerboard: odd 64-column blocks are staged negated
       split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
     } else {
@@ -993,7 +1010,7 @@ pw_gemm_split_kernel(GemmArgs g) {
     step(t, 0, xb[0], xb[1]);
     if (t + 1 < T) step(t + 1, 1, xb[1], xb[0]);
   }
-  split_unflip(acc);
+  split_unflip(acc, wn);
   if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
@@ -1070,8 +1087,11 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   auto split_store = [&](const float (&x)[8], u32x4* o) __attribute__((always_inline)) {
     if constexpr (NP == 3) {
       u32x4 h, m, l;
+      // sign checkerboard: odd 64-column blocks are staged negated.  (Two code paths behind a wave-uniform branch
+      // with the sign folded into source modifiers - no v_xor - measured SLOWER, 154.8 against 153.0 ms per step: the
+      // branch takes the split out of the MFMA block's schedule.)
       float xs[8];
-      flip8(xs, x, flip);          // sign checkerboard: odd 32-column blocks are staged negated
+      flip8(xs, x, flip);
       split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
     } else {
@@ -1145,15 +1165,12 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
       // SIMD partners out of phase (MI355X_MICROARCH.md, two waves per SIMD, item 9): waves 4-7 (sub 1) split and store
       // tile t+1 FIRST and multiply afterwards, waves 0-3 the other way round - one half of a SIMD's waves is on the
       // vector unit and the LDS store path while the other half feeds the matrix pipe
-      if (sub == 1) {
-        split_store(xsplit, Bst + (cur ^ 1) * SIMG);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block();
-      } else {
-        mfma_block();
-        __builtin_amdgcn_sched_barrier(0);
-        split_store(xsplit, Bst + (cur ^ 1) * SIMG);
-      }
+      // (ONE copy of the MFMA block: a second copy behind the branch spills the accumulators)
+      if (sub == 1) split_store(xsplit, Bst + (cur ^ 1) * SIMG);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block();
+      __builtin_amdgcn_sched_barrier(0);
+      if (sub == 0) split_store(xsplit, Bst + (cur ^ 1) * SIMG);
 #else
       mfma_block();
       split_store(xsplit, Bst + (cur ^ 1) * SIMG);
@@ -1182,7 +1199,7 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
   }
 #undef USE_X
   if (live) {
-    split_unflip(acc);
+    split_unflip(acc, wn);
     if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
     gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
   }
@@ -1249,7 +1266,7 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     scale_from_amax(reduce_amax_partials(g.b_amax), sc_b, inv_b);
   }
   // the offset of the MFMA's accumulator alignment (see "sign checkerboard") cancels between an element's slabs
-  const uint32_t slab_flip = (SPLIT_SIGNED && (bz & 1)) ? 0x80000000u : 0u;      // workgroup-uniform
+  const uint32_t slab_flip = (SPLIT_SIGNED_WGRAD && (bz & 1)) ? 0x80000000u : 0u;      // workgroup-uniform
   if constexpr (NP == 2) sc_a = __uint_as_float(__float_as_uint(sc_a) ^ slab_flip);
   auto split_store = [&](const Regs& r, int st, bool keep) __attribute__((always_inline)) {
     const float xa[8] = {r.a0.x, r.a0.y, r.a0.z, r.a0.w, r.a1.x, r.a1.y, r.a1.z, r.a1.w};

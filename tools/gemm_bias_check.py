@@ -18,14 +18,14 @@ SHAPES = [(1024, 1024), (896, 1152), (384, 1024), (1024, 768)]
 
 def stats(got, ref, checker=True):
     """(mean, rms, mean of err * checkerboard sign) in units of u; the checkerboard is the sign pattern of the
-    library's negated-space blocks: (-1)^(row / 32 + column / 32) over (channel, pixel) of a [B, C, H, W] output"""
+    library's negated-space blocks: (-1)^(row / 32 + column / 64) over (channel, pixel) of a [B, C, H, W] output"""
     err = got.double() - ref
     u = float(ref.pow(2).mean().sqrt()) * 2.0 ** -24
     chk = float("nan")
     if checker and err.dim() == 4:
         Bn, C, Hh, Ww = err.shape
         rs = 1.0 - 2.0 * ((torch.arange(C, device=err.device) >> 5) & 1).double()
-        cs = 1.0 - 2.0 * ((torch.arange(Hh * Ww, device=err.device) >> 5) & 1).double()
+        cs = 1.0 - 2.0 * ((torch.arange(Hh * Ww, device=err.device) >> 6) & 1).double()
         chk = float((err.reshape(Bn, C, Hh * Ww) * rs[None, :, None] * cs[None, None, :]).mean()) / u
     return float(err.mean()) / u, float(err.pow(2).mean().sqrt()) / u, chk
 
