@@ -210,6 +210,12 @@ def main():
                     help="skip the HIP-event timing of the GEMM/advection launches")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write to the C-level stdout behind Python's back (RCCL
+    # announces "Librccl path : ..." when a process group initialises): everything but the final line goes to stderr.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     from paradis_model_amd import _lib, ops
     from paradis_model_amd.config import default_config, feature_layout, stub_datamodule
     from paradis_model_amd.harness import (TrainStep, barrier, init_distributed, make_grids,
@@ -480,10 +486,12 @@ def main():
     out.update(legs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=8)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

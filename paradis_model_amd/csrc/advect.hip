@@ -2244,14 +2244,15 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
 // plain 256-byte stores.  Against the 128-column strips: no float atomics (the strips' flush ran at the chip's
 // 1.3 TB/s atomic rate), no zero fill of the gradient, 1.02 instead of 1.19 window cells per point.
 // 4 WPR waves: WPR 64-column segments per row, two rows per wave and step.
-template <int MODE, int R, int WPR>
+template <int MODE, int R, int WPR, bool FLDS>
 __global__ void __launch_bounds__(256 * WPR)
 sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ field, const float* __restrict__ u,
                      const float* __restrict__ v, float* __restrict__ gfield, float* __restrict__ gu,
                      float* __restrict__ gv, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                      const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
                      const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
-                     int64_t gf_bs, int64_t guv_bs, int strips, unsigned* __restrict__ queue, unsigned* __restrict__ counts) {
+                     int64_t gf_bs, int64_t guv_bs, int strips, unsigned* __restrict__ queue, unsigned* __restrict__ counts,
+                     const unsigned* __restrict__ wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ unsigned qcount;
   using Ring = StripRing<MODE, R>;
@@ -2261,6 +2262,9 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
   const unsigned lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int plane = blockIdx.x;
+  // two variants of this kernel are launched back to back; a plane runs in the one its displacement class names
+  // (adv_dy_class_kernel: sampled max |v dt| in rows), the other one returns at once
+  if ((wide[plane] != 0u) == FLDS) return;
   const int b = plane / K, k = plane - b * K;
   const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
   const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
@@ -2272,8 +2276,8 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
   const int WS = W + NT, wx0 = p;
   const int wn = R * WS;
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);    // [R][WS] fixed-point sums
-  float* ring = smem + 2 * wn;                                               // [R][WS] field window
-  unsigned* stepmax = reinterpret_cast<unsigned*>(ring + wn);                // [3] max |cotangent| bits of a step
+  float* ring = smem + 2 * wn;                                               // [R][WS] field window (FLDS only)
+  unsigned* stepmax = reinterpret_cast<unsigned*>(ring + (FLDS ? wn : 0));   // [3] max |cotangent| bits of a step
   const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
   const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
   const StripLane tl(wave % WPR, lane, 0, W, W);
@@ -2299,11 +2303,13 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
   if (tid < 3) stepmax[tid] = 0u;
   float pre[STRIP_CH];
   const int lo0 = Ring::lo(0, p);
-  for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) {
-    strip_load_row(F, lo0 + r8 + srw, H, W, p, cs, nch, pre);
-    strip_store_row(ring, lo0 + r8 + srw, RMASK, WS, H, p, m0, m1, lane, nch, pre, cfirst);
+  if constexpr (FLDS) {
+    for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) {
+      strip_load_row(F, lo0 + r8 + srw, H, W, p, cs, nch, pre);
+      strip_store_row(ring, lo0 + r8 + srw, RMASK, WS, H, p, m0, m1, lane, nch, pre, cfirst);
+    }
+    strip_load_row(F, lo0 + RW + srw, H, W, p, cs, nch, pre);
   }
-  strip_load_row(F, lo0 + RW + srw, H, W, p, cs, nch, pre);
   __syncthreads();
   {
     unsigned mb = max(abs_bits(gm0), abs_bits(gm1));
@@ -2382,8 +2388,10 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
       fold_row(lo - STRIP_ROWS + srw);
       flush_row(lo - STRIP_ROWS + srw);
     }
-    strip_store_row(ring, lo + RW + srw, RMASK, WS, H, p, m0, m1, lane, nch, pre, cfirst);
-    if (s + 1 < nsteps) strip_load_row(F, lo + R + srw, H, W, p, cs, nch, pre);
+    if constexpr (FLDS) {
+      strip_store_row(ring, lo + RW + srw, RMASK, WS, H, p, m0, m1, lane, nch, pre, cfirst);
+      if (s + 1 < nsteps) strip_load_row(F, lo + R + srw, H, W, p, cs, nch, pre);
+    }
     const float rlof = (float)lo, rhif = (float)(lo + RW - 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -2411,14 +2419,35 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
           double wxd[NT];
 #pragma unroll
           for (int bb = 0; bb < NT; ++bb) wxd[bb] = (double)wx[bb];
+          int fcol[NT], fcolm[NT];           // !FLDS: the field taps come from global memory (L1 / L2)
+          if constexpr (!FLDS) {
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) {
+              int j = c0 + bb;                // window column = image column (wx0 = p), wrap columns behind W
+              j -= j >= W ? W : 0;
+              int jm = j + (W >> 1);
+              jm -= jm >= W ? W : 0;
+              fcol[bb] = j; fcolm[bb] = jm;
+            }
+          }
 #pragma unroll
           for (int a = 0; a < NT; ++a) {
             const int rb = ((r0 + a) & RMASK) * WS + c0;
             float sxv = 0.f, sdx = 0.f;
             const double gwy = (double)(gs_ * wy[a]);
+            float fval[NT];
+            if constexpr (!FLDS) {
+              bool mir;
+              int pole;
+              const int ro = tap_row(r0 + a, H, W, p, mir, pole);
+#pragma unroll
+              for (int bb = 0; bb < NT; ++bb) fval[bb] = F[ro + (mir ? fcolm[bb] : fcol[bb])];
+#pragma unroll
+              for (int bb = 0; bb < NT; ++bb) fval[bb] = pole == 1 ? m0 : (pole == 2 ? m1 : fval[bb]);
+            }
 #pragma unroll
             for (int bb = 0; bb < NT; ++bb) {
-              const float val = ring[rb + bb];
+              const float val = FLDS ? ring[rb + bb] : fval[bb];
               atomicAdd(&acc[rb + bb], fixed_from_product(gwy, wxd[bb]));
               sxv = fmaf(val, wx[bb], sxv);
               sdx = fmaf(val, dwx[bb], sdx);
@@ -2446,6 +2475,30 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
   __syncthreads();
   for (int r8 = 0; r8 < RW; r8 += STRIP_ROWS) flush_row(lo_last + r8 + srw);
   if (tid < strips) counts[(size_t)plane * strips + tid] = tid == 0 ? qcount : 0u;
+}
+
+// displacement class of a plane for the full-circle backward: 1 when more than 1/16 of the sampled points (every fourth
+// row) move further in latitude than the ring of the field-in-LDS variant covers.  Such points are deferred to sixteen
+// global float atomics each (~60 ps per point against ~14 in the ring): beyond ~9 % of them the 64-row variant, 35 %
+// slower per point, wins.  A heuristic that only selects between two correct kernels.
+__global__ void __launch_bounds__(256)
+adv_dy_class_kernel(const float* __restrict__ v, unsigned* __restrict__ wide, int K, int H, int W, int64_t bs,
+                    float thresh) {
+  __shared__ unsigned red[4];
+  const int plane = blockIdx.x, b = plane / K, k = plane - b * K;
+  const float* V = v + (int64_t)b * bs + (int64_t)k * H * W;
+  unsigned far = 0;
+  for (int y = 0; y < H; y += 4)
+    for (int x = threadIdx.x; x < W; x += 256) far += !(fabsf(V[y * W + x]) <= thresh) ? 1u : 0u;   // (a NaN counts as far)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) far += (unsigned)__shfl_xor((int)far, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = far;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned f = red[0] + red[1] + red[2] + red[3];
+    const unsigned t = (unsigned)((H + 3) / 4) * (unsigned)W;      // points sampled
+    wide[plane] = 16ull * f > t ? 1u : 0u;
+  }
 }
 
 // the deferred points of the backward strips, one per lane: field gradient by global atomics, velocity gradients
@@ -2645,7 +2698,7 @@ extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W, int fla
   size_t n = adv_ws_base_bytes(B, K) + adv_ws_det_bytes(B, K, H, W) + 256;
   if (adv_uses_strips(H, W, 2, flags) || adv_uses_strips(H, W, 1, flags)) {
     const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
-    n += 3 * strips * (size_t)H * STRIP_W * sizeof(unsigned) + ((strips * sizeof(unsigned) + 255) & ~(size_t)255) + 256;
+    n += 3 * strips * (size_t)H * STRIP_W * sizeof(unsigned) + (((strips + (size_t)B * K) * sizeof(unsigned) + 255) & ~(size_t)255) + 256;
   }
   return n;
 }
@@ -2655,7 +2708,7 @@ static unsigned* adv_ws_queue(void* workspace, int B, int K, int H, int W, unsig
   base = (char*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
   const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
   *counts = (unsigned*)base;
-  return (unsigned*)(base + ((strips * sizeof(unsigned) + 255) & ~(size_t)255));
+  return (unsigned*)(base + (((strips + (size_t)B * K) * sizeof(unsigned) + 255) & ~(size_t)255));   // counts, class words, lists
 }
 inline int stream_blocks_adv(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 256 * 32); }
 
@@ -2871,30 +2924,46 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                      (const unsigned*)pmax)
   const bool cubic = mode == PARADIS_INTERP_BICUBIC;
   if (circle) {
-    // full-circle ring, one workgroup per plane: plain stores (gfield needs no zero fill: the memset above is skipped)
+    // full-circle ring, one workgroup per plane: plain stores (gfield needs no zero fill: the memset above is skipped).
+    // Two variants, chosen per plane on the device (adv_dy_class_kernel): field + sums in a ring of strip_ring_rows(H)
+    // rows, or - displacements of many rows - the sums alone in a ring of 64 rows with the field taps from L2.
     const int ring = strip_ring_rows(H), strips = (W + STRIP_W - 1) / STRIP_W;
     const size_t slds = ((size_t)ring * (W + NT) * 3 + 8) * sizeof(float);
-    PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
+    const size_t slds_wide = ((size_t)64 * (W + NT) * 2 + 8) * sizeof(float);
+    PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX && slds_wide <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
     static PerDeviceOnce once_circle;
     if (once_circle.first()) {
-#define RESERVE_CIRCLE(M, R_, WPR_) reserve_lds(&sl_advect_bwd_circle<M, R_, WPR_>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX)
-      if (RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 32, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 32, 4) ||
-          RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 64, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BICUBIC, 64, 4) ||
-          RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 32, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 32, 4) ||
-          RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 64, 2) || RESERVE_CIRCLE(PARADIS_INTERP_BILINEAR, 64, 4))
-        return 2;
+#define RESERVE_CIRCLE(M, R_, WPR_, F_) reserve_lds(&sl_advect_bwd_circle<M, R_, WPR_, F_>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX)
+#define RESERVE_CIRCLE_M(M)                                                                                         \
+      (RESERVE_CIRCLE(M, 32, 2, true) || RESERVE_CIRCLE(M, 32, 4, true) || RESERVE_CIRCLE(M, 64, 2, true) ||        \
+       RESERVE_CIRCLE(M, 64, 4, true) || RESERVE_CIRCLE(M, 64, 2, false) || RESERVE_CIRCLE(M, 64, 4, false))
+      if (RESERVE_CIRCLE_M(PARADIS_INTERP_BICUBIC) || RESERVE_CIRCLE_M(PARADIS_INTERP_BILINEAR)) return 2;
+#undef RESERVE_CIRCLE_M
 #undef RESERVE_CIRCLE
     }
     unsigned* counts = nullptr;
     unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
-#define LAUNCH_CIRCLE(M, R_, WPR_)                                                                                   \
-    hipLaunchKernelGGL((sl_advect_bwd_circle<M, R_, WPR_>), dim3((unsigned)planes), dim3(256 * WPR_), slds, st, gout,  \
-                       field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,            \
-                       (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips, queue, counts)
+    unsigned* wide = counts + (size_t)planes * strips;      // class word per plane: behind the counts (adv_ws_queue)
+    {
+      // rows the field-in-LDS ring covers below an arrival row, in radians of v dt
+      const int hyl = ring == 32 ? (mode == PARADIS_INTERP_BICUBIC ? 6 : 7) : (mode == PARADIS_INTERP_BICUBIC ? 22 : 23);
+      const float thresh = ring == 64 ? INFINITY : (float)hyl / (g.cy * fabsf(dt));
+      hipLaunchKernelGGL(adv_dy_class_kernel, dim3(planes), dim3(256), 0, st, v, wide, K, H, W, uv_bs, thresh);
+    }
+#define LAUNCH_CIRCLE(M, R_, WPR_, F_, LDS_)                                                                         \
+    hipLaunchKernelGGL((sl_advect_bwd_circle<M, R_, WPR_, F_>), dim3((unsigned)planes), dim3(256 * WPR_), LDS_, st,    \
+                       gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,      \
+                       (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips, queue, counts,           \
+                       (const unsigned*)wide)
 #define LAUNCH_CIRCLE_M(M)                                                                                           \
     do {                                                                                                               \
-      if (W <= 128) { if (ring == 32) LAUNCH_CIRCLE(M, 32, 2); else LAUNCH_CIRCLE(M, 64, 2); }                        \
-      else { if (ring == 32) LAUNCH_CIRCLE(M, 32, 4); else LAUNCH_CIRCLE(M, 64, 4); }                                 \
+      if (W <= 128) {                                                                                                  \
+        if (ring == 32) LAUNCH_CIRCLE(M, 32, 2, true, slds); else LAUNCH_CIRCLE(M, 64, 2, true, slds);                 \
+        if (ring == 32) LAUNCH_CIRCLE(M, 64, 2, false, slds_wide);                                                     \
+      } else {                                                                                                         \
+        if (ring == 32) LAUNCH_CIRCLE(M, 32, 4, true, slds); else LAUNCH_CIRCLE(M, 64, 4, true, slds);                 \
+        if (ring == 32) LAUNCH_CIRCLE(M, 64, 4, false, slds_wide);                                                     \
+      }                                                                                                                \
       hipLaunchKernelGGL((sl_advect_bwd_strip_fixup<M, false>), dim3((unsigned)(planes * strips)), dim3(256), 0, st,   \
                          gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans,               \
                          (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips,                        \
