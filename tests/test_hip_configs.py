@@ -88,19 +88,19 @@ def test_cfg2_six_step_rollout_default_model_vs_oracle():
     errs = [max_rel(g.cpu(), w) for g, w in zip(outs, want_outs)]
     print("cfg2 per-step forward max-rel", ["%.1e" % e for e in errs])
     # every one of the six steps at the 1e-5 bar (measured 2.0-2.4e-6 at each step)
-    assert max(errs) <= 1e-5, errs
+    assert max(errs) <= 5e-6, errs           # measured 1.9-2.3e-6 at each step (north star: 1e-5)
     assert abs(float(got_total) - float(total)) <= 5e-6 * abs(float(total))
     ga = model.alpha_adv.grad.cpu()
     e_alpha = max_rel(ga, P["alpha_adv"].grad)
     print("cfg2 alpha_adv grad max-rel", e_alpha)
-    assert e_alpha <= 1e-4, e_alpha          # measured 2e-6
+    assert e_alpha <= 2e-6, e_alpha          # measured 7.3e-7 (round 3 asserted 1e-4)
     worst = ("", 0.0)
     for n, p in model.named_parameters():
         want = float(P[n].grad.norm())
         rel = abs(float(p.grad.norm()) - want) / (want + 1e-30)
         if rel > worst[1]:
             worst = (n, rel)
-        assert abs(float(p.grad.norm()) - want) <= 5e-4 * want + 1e-9, (n, rel)
+        assert abs(float(p.grad.norm()) - want) <= 1.4e-4 * want + 1e-9, (n, rel)      # measured 6.7e-5 (round 3 asserted 5e-4)
     print("cfg2 worst parameter-gradient norm deviation", worst)
 
 
@@ -235,7 +235,7 @@ def test_cfg3_default_width_model_128x256_gradients_fp64_protocol():
         worst_all = max(worst_all, rs[-1])
         sentinel.append(ratios["reaction.1.0-ChannelNorm.bias"])
         try:
-            _check_grads_by_fp64_protocol(model, g32, g64)
+            _check_grads_by_fp64_protocol(model, g32, g64, factor=8.0, rms_factor=5.0)
             ok = True
         except AssertionError as exc:
             ok = False
@@ -326,7 +326,7 @@ def test_cfg4_advect_721x1440_vs_oracle(mode):
     e_cpu, e_gpu, r32 = rms_rel(want32, want64), rms_rel(got, want64), rms_rel(got, want32)
     print("cfg4 advect %s: rms vs cpu32 %.2e, vs fp64 gpu %.2e cpu %.2e" % (mode, r32, e_gpu, e_cpu))
     assert e_gpu <= 1.5 * e_cpu + 2e-7, (e_gpu, e_cpu)
-    assert r32 <= 3.0 * e_cpu + 2e-7, (r32, e_cpu)
+    assert r32 <= 1.5 * e_cpu + 2e-7, (r32, e_cpu)      # measured 0.77 x (round 3 asserted 3 x)
     # pole rows carry their longitudinal mean
     assert float((got[..., 0, :] - got[..., 0, :1]).abs().max()) == 0.0
     assert float((got[..., -1, :] - got[..., -1, :1]).abs().max()) == 0.0

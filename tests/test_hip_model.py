@@ -48,7 +48,9 @@ def test_reduced_model_vs_reference_golden(variant, fuse_projection, gemm, monke
     loss = loss_fn(y, tgt.cuda())
     assert abs(float(loss) - float(rec["loss"])) <= 2e-6 * abs(float(rec["loss"]))
     loss.backward()
-    assert max_rel(xd.grad.cpu()[:, ::9], rec["gx_sub"]) <= 5e-4
+    e_gx = max_rel(xd.grad.cpu()[:, ::9], rec["gx_sub"])
+    print("MEASURED reduced model %s %s: forward %.2e, input gradient %.2e" % (variant, gemm, e, e_gx))
+    assert e_gx <= GX_BOUND[variant], e_gx
     worst = ("", 0.0)
     for n, p in model.named_parameters():
         gref = rec["grads"][n]
@@ -58,9 +60,18 @@ def test_reduced_model_vs_reference_golden(variant, fuse_projection, gemm, monke
         if err > worst[1]:
             worst = (n, err)
     print("worst grad", worst)
-    # measured 4-6e-5 (variants b, c) and 4.4-5.2e-4 (variant a: one bias of the velocity network, whose
-    # gradient is a sum over the ill-conditioned points next to the poles; same figure in both GEMM arithmetics)
-    assert worst[1] <= (8e-4 if variant == "a" else 1.5e-4), worst
+    # measured (round 4): variant a 4.4-5.0e-4 (one bias of the velocity network, whose gradient is a sum over the
+    # ill-conditioned points next to the poles; same figure in all three GEMM arithmetics), b 1.1-1.2e-4, c 2.5-5.3e-5
+    assert worst[1] <= {"a": 8e-4, "b": 2e-4, "c": 1e-4}[variant], worst
+
+
+# Bounds = at most 2 x what the shipped library measures against the REFERENCE's own CPU-fp32 goldens (round 4, the
+# MEASURED lines these tests print; INTEGRATION.md "Tolerances" quotes the same figures):
+#   input gradient of the reduced models 2.7e-7 .. 7.4e-7 in all three arithmetics (rounds 1-3 asserted 5e-4);
+#   two-step rollout: outputs 7.8e-7 / 1.0e-6, alpha_adv gradient 5.9e-7, largest gradient-norm deviation 8.6e-6
+#   (rounds 1-3: 2e-5 / 1e-3 / 2e-3).
+GX_BOUND = {"a": 1.5e-6, "b": 1.5e-6, "c": 1.5e-6}
+ROLLOUT_BOUNDS = {"outputs": 2.0e-6, "alpha": 1.2e-6, "norms": 1.7e-5}
 
 
 def test_two_step_rollout_vs_reference_golden():
@@ -79,13 +90,17 @@ def test_two_step_rollout_vs_reference_golden():
     from paradis_model_amd.harness import rollout_loss
     total, outs = rollout_loss(model, loss_fn, (inp, tgt, forc, const), num_common=83, n_inputs=2,
                                keep_outputs=True)
-    for got, want in zip(outs, rec["outputs"]):
-        assert max_rel(got.detach().cpu(), want) <= 2e-5
+    e_out = [max_rel(got.detach().cpu(), want) for got, want in zip(outs, rec["outputs"])]
+    e_alpha = max_rel(model.alpha_adv.grad.cpu(), rec["grad_alpha"])
+    e_norm = max((abs(float(p.grad.norm()) - rec["grad_norms"][n]) / max(rec["grad_norms"][n], 1e-30), n)
+                 for n, p in model.named_parameters())
+    print("MEASURED two-step rollout: outputs %s, alpha_adv gradient %.2e, worst gradient-norm deviation %.2e (%s)"
+          % (["%.2e" % x for x in e_out], e_alpha, e_norm[0], e_norm[1]))
+    # bounds = 2 x what the shipped library measures ("Tolerances"): see ROLLOUT_BOUNDS
+    assert max(e_out) <= ROLLOUT_BOUNDS["outputs"], e_out
     assert abs(float(total) - float(rec["loss"])) <= 2e-6 * abs(float(rec["loss"]))
-    assert max_rel(model.alpha_adv.grad.cpu(), rec["grad_alpha"]) <= 1e-3
-    for n, p in model.named_parameters():
-        gn = rec["grad_norms"][n]
-        assert abs(float(p.grad.norm()) - gn) <= 2e-3 * gn + 1e-9, n
+    assert e_alpha <= ROLLOUT_BOUNDS["alpha"], e_alpha
+    assert e_norm[0] <= ROLLOUT_BOUNDS["norms"], e_norm
 
 
 def test_default_config_forward_vs_oracle():
@@ -127,7 +142,7 @@ def _oracle_grads(model, spec, x, ct, lg, og, dtype):
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
 
-def _check_grads_by_fp64_protocol(model, g32, g64, factor=8.0, floor=2e-5, rms_factor=5.0, rms_floor=5e-5):
+def _check_grads_by_fp64_protocol(model, g32, g64, factor=5.0, floor=2e-5, rms_factor=4.0, rms_floor=5e-5):
     """the HIP gradient's distance to the fp64 oracle against the CPU fp32 oracle's own
     distance (the velocity path amplifies fp32 coordinate rounding; a few ill-conditioned points
     near the poles decide the maximum of a weight gradient).  Measured on the default model
@@ -135,9 +150,14 @@ def _check_grads_by_fp64_protocol(model, g32, g64, factor=8.0, floor=2e-5, rms_f
     median; the largest ratios (up to 10) belong to gradients whose absolute error is below 2e-5 (the
     floor), the largest ratio among the others is 5 (velocity networks: 3.6e-4 where the CPU has 7e-5).  The factor is the accumulation order: an MFMA accumulator takes the K
     products of a dot product one after the other (512 updates for K = 1024), the CPU's vector units
-    keep 16 partial sums per accumulator - sqrt(512/64) = 2.8."""
+    keep 16 partial sums per accumulator - sqrt(512/64) = 2.8.
+    Round 4: with the sign checkerboard of the bf16x3 GEMMs (the offset every output shared is gone from the sums over
+    pixels and channels) the largest ratios above the floors are 2.8 (max-abs) and 2.1 (norm-wise) on the default
+    model at 32x64, 1.8 / 1.2 on the reduced model at 128x256 and 65x130 - the factors are now 5 and 4 (rounds 2-3: 8
+    and 5, with 5.0-6.8 measured)."""
     worst = ("", 0.0, 0.0)
     bad = []
+    top_m, top_r = (0.0, ""), (0.0, "")
     for n, p in model.named_parameters():
         ref = g64.get(n)
         if ref is None or float(ref.abs().max()) == 0:
@@ -155,6 +175,13 @@ def _check_grads_by_fp64_protocol(model, g32, g64, factor=8.0, floor=2e-5, rms_f
             bad.append((n, e_gpu, e_cpu, r_gpu, r_cpu))
         if e_gpu > worst[1]:
             worst = (n, e_gpu, e_cpu)
+        # what the bounds are measured against: the largest ratios among the gradients above the floors
+        if e_gpu > floor:
+            top_m = max(top_m, ((e_gpu - floor) / max(e_cpu, 1e-30), n))
+        if r_gpu > rms_floor:
+            top_r = max(top_r, ((r_gpu - rms_floor) / max(r_cpu, 1e-30), n))
+    print("MEASURED fp64 protocol: largest (max-abs error - floor) / cpu32 error %.2f (%s); largest (norm-wise error - "
+          "floor) / cpu32 error %.2f (%s); bounds %.0f / %.0f" % (top_m[0], top_m[1], top_r[0], top_r[1], factor, rms_factor))
     assert not bad, bad
     return worst
 
