@@ -422,6 +422,8 @@ dwconv_geo_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
   float gsum = 0.f;
+  // (tile cells no staging path writes meet zero cotangents: keep 0 x NaN out, see the planes kernel below)
+  for (int i = threadIdx.x; i < (TH + K - 1) * (TW + K - 1); i += 256) tile[i] = 0.f;
   for (int item = chunk; item < items; item += chunks) {
     const int n = item / tiles, t = item - n * tiles;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
@@ -495,6 +497,10 @@ dwconv_geo_wgrad_planes_kernel(const float* __restrict__ gy, const float* __rest
 #pragma unroll
     for (int o = 0; o < RPT; ++o) gn[o] = (r0l + o < H) ? load_at<float>(gb + o * W * 4, g0) : 0.f;
   };
+  // rows of the tile beyond the padded plane (H < 32: a wave's strip may overshoot) are never staged: they meet
+  // cotangent rows that are zero, and 0 x uninitialised LDS could be 0 x NaN - define them once
+  for (int i = threadIdx.x; i < (TH + K - 1) * (TW + K - 1); i += 256) tile[i] = 0.f;
+  __syncthreads();
   if (chunk < B) fetch(chunk);
   for (int item = chunk; item < B; item += chunks) {
     sg.store(tile, q, hv);

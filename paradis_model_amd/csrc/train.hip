@@ -111,11 +111,20 @@ adamw_multi_kernel(const int64_t* __restrict__ ptrs /* [4][T]: p, g, m, v */, co
                    const int* __restrict__ chunk_tensor, const int64_t* __restrict__ chunk_off, int T,
                    float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                    const int* __restrict__ dev) {
-  if (dev) {
-    const int step = dev[0];
+  if (dev) {     // (workgroup-uniform)
+    // one thread forms the bias corrections (two double pow + a sqrt), the workgroup reads them from LDS.  Same formula
+    // in double as the host path; the device's pow is not guaranteed to round like the host's libm, so the two paths
+    // agree to ~1 ulp of the fp32 corrections, not bit for bit (tests/test_hip_train_rows.py checks 1e-6).
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+      const int step = dev[0];
+      bc[0] = (float)(1.0 - pow((double)b1, (double)step));
+      bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    }
+    __syncthreads();
     lr = __int_as_float(dev[1]);
-    bc1 = (float)(1.0 - pow((double)b1, (double)step));
-    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    bc1 = bc[0];
+    bc2_sqrt = bc[1];
   }
   const int t = chunk_tensor[blockIdx.x];
   const int64_t off = chunk_off[blockIdx.x];

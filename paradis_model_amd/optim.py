@@ -13,7 +13,8 @@ from ._lib import check, dptr, lib, require_hip, stream_ptr
 class AdamW(torch.optim.Optimizer):
     """``capturable=True``: the step count and the learning rate of every group also live on the device
     (``paradis_adamw_multi(..., dev_state)``), so a HIP graph captured around ``step()`` stays valid from replay to
-    replay (``harness.GraphedTrainStep``); the update is the same to the last bit."""
+    replay (``harness.GraphedTrainStep``); same formula, the bias corrections formed in double on the device (agrees with the
+    host-side path to ~1 ulp of the fp32 corrections: the device pow is not the host libm, test bound 1e-6)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
