@@ -1871,6 +1871,9 @@ struct StripRing {
 #ifndef STRIP_BWD_WAVES
 #define STRIP_BWD_WAVES 4
 #endif
+#ifndef STRIP_FWD_INLINE_FIXUP     // 1: a strip's workgroup processes its own deferred points; 0: a second launch does
+#define STRIP_FWD_INLINE_FIXUP 1
+#endif
 template <int MODE, int R>
 __global__ void __launch_bounds__(STRIP_THREADS, STRIP_FWD_WAVES)
 sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
@@ -1965,7 +1968,25 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
     // raw barrier: __syncthreads() would also wait for this step's stores and the prefetches (s_waitcnt vmcnt(0))
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  if (tid == 0) counts[blockIdx.x] = qcount;
+  if constexpr (STRIP_FWD_INLINE_FIXUP && R == 64) {
+  // (large grids only: with the 32-row ring the extra code costs the kernel its 64-register fit, and the few deferred
+  //  points of the 128-row grids are cheap in the second launch: 0.93 vs 0.96 ms per launch in the model)
+  // The deferred points of this strip, densely, by the workgroup that listed them: while the other workgroups of the CU
+  // are still in their row loops the scattered 4-byte loads of this phase overlap with their arithmetic, and the rows
+  // it touches were streamed through the caches moments ago.  (The lists were written by this workgroup's own waves:
+  // __syncthreads() drains the stores; no line of a list has been read before, so no stale L1 copy exists.)
+  __syncthreads();
+  {
+    const unsigned n = qcount;
+    const float* qx = reinterpret_cast<const float*>(q) + qcap;
+    const float* qy = qx + qcap;
+    for (unsigned i = tid; i < n; i += STRIP_THREADS)
+      O[q[i]] = gather_global<MODE>(F, qx[i], qy[i], H, W, p, m0, m1);
+  }
+  if (tid == 0) counts[blockIdx.x] = 0u;
+  } else {
+    if (tid == 0) counts[blockIdx.x] = qcount;
+  }
 }
 
 // Deferred points of the strips (tap block outside the ring window: the polar rows, and whatever moved further than the
