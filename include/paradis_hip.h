@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 7: paradis_dwconv_geo_dgrad_add, paradis_pw_gemm_split_weights_pair; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -98,6 +98,11 @@ int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, fl
                            int B, int C, int H, int W, int k, void* stream);
 int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx,
                              int B, int C, int H, int W, int k, void* stream);
+/* gx = dgrad(gy) + addend: the stencil's input has a second consumer (the block input that the gated blend of
+ * reference model/paradis.py:239-240 reads next to the advection's down-projection); its gradient enters here
+ * instead of through an accumulation pass.  addend [B,C,H,W], must not alias gx.  (ABI 7) */
+int paradis_dwconv_geo_dgrad_add(const float* gy, const float* w, const float* addend, float* gx,
+                                 int B, int C, int H, int W, int k, void* stream);
 size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k);
 int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* gw, float* gbias,
                              int B, int C, int H, int W, int k, void* workspace, void* stream);
@@ -139,6 +144,8 @@ size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme);   /* bytes of the 
 /* split image of A = W[M,K] (transpose 0; out: split_bytes(M,K,scheme)) or of A = W^T (transpose 1; out:
  * split_bytes(K,M,scheme)) from row-major W[M,K]; scheme = PARADIS_GEMM_BF16X3 or PARADIS_GEMM_F16X2 */
 int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, int scheme, void* out, void* stream);
+/* PARADIS_GEMM_BF16X3 images of W (-> out) and of W^T (-> out_t) in one launch: a training step needs both (ABI 7) */
+int paradis_pw_gemm_split_weights_pair(const float* W, int M, int K, void* out, void* out_t, void* stream);
 int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
                         const void* Wsplit /* split image of Wt for `scheme`, NULL for PARADIS_GEMM_EXACT */,
                         int scheme, const uint32_t* x_amax /* amax partials of X: PARADIS_GEMM_F16X2 only */,

@@ -38,6 +38,7 @@ SIGNATURES = {
                                   F, F, F, F, F, I, I, P, P]),
     "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
+    "paradis_dwconv_geo_dgrad_add": (I, [P, P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_wgrad_ws_bytes": (S, [I, I, I, I, I]),
     "paradis_dwconv_geo_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_avgpool_geo_fwd": (I, [P, P, L, I, I, I, P]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "paradis_amax_partials": (I, [P, I, L, L, P, P]),
     "paradis_pw_gemm_split_bytes": (S, [I, I, I]),
     "paradis_pw_gemm_split_weights": (I, [P, I, I, I, I, P, P]),
+    "paradis_pw_gemm_split_weights_pair": (I, [P, I, I, P, P, P]),
     "paradis_pw_gemm_fwd": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
     "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I, I]),
     "paradis_forcings": (I, [P, P, P, I, I, I, I, I, I, P, I, ctypes.c_double, ctypes.c_double, P, P, P]),

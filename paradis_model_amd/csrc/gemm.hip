@@ -745,11 +745,8 @@ amax_partials_kernel(const float* __restrict__ x, int B, int64_t inner, int64_t 
 
 // Image of A[m,k] = W[m*rs + k*cs] (rs/cs select W or W^T), zero padded to [MT*128, KT*16]:
 // out[((mt*KT + kt)*3 + s)*256 + half*128 + row] ; one thread per (mt, kt, half, row).
-__global__ void __launch_bounds__(256)
-split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
-                     int64_t w_bs, int64_t out_bs, u32x4* __restrict__ out) {
-  const float* Wb = W + (int64_t)blockIdx.y * w_bs;
-  u32x4* ob = out + (int64_t)blockIdx.y * out_bs;
+__device__ __forceinline__ void split_weights_body(const float* __restrict__ Wb, int64_t rs, int64_t cs, int M, int K,
+                                                   int KT, int64_t units, u32x4* __restrict__ ob) {
   for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
     const int row = (int)(u & 127), half = (int)((u >> 7) & 1);
     const int64_t tile = u >> 8;
@@ -767,6 +764,21 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
     u32x4* o = ob + tile * SIMG + half * SCH + row;
     o[0] = h; o[2 * SCH] = mm; o[4 * SCH] = l;
   }
+}
+
+__global__ void __launch_bounds__(256)
+split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
+                     int64_t w_bs, int64_t out_bs, u32x4* __restrict__ out) {
+  split_weights_body(W + (int64_t)blockIdx.y * w_bs, rs, cs, M, K, KT, units, out + (int64_t)blockIdx.y * out_bs);
+}
+
+// both images of one row-major W[M,K] in ONE launch (a training step needs W for the forward GEMM and W^T for the
+// data gradient: 78 launches of a few microseconds per step instead of 155): blockIdx.y = 0 -> W, 1 -> W^T
+__global__ void __launch_bounds__(256)
+split_weights_pair_kernel(const float* __restrict__ W, int M, int K, int KT, int KTt, int64_t units, int64_t units_t,
+                          u32x4* __restrict__ out, u32x4* __restrict__ out_t) {
+  if (blockIdx.y == 0) split_weights_body(W, K, 1, M, K, KT, units, out);
+  else split_weights_body(W, 1, K, K, M, KTt, units_t, out_t);
 }
 
 // f16x2 image: out[((mt*KT + kt)*2 + s)*256 + half*128 + row]; `tail` = the words behind the image:
@@ -1586,6 +1598,19 @@ extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int t
                        (int64_t)0, (int64_t)0, (u32x4*)out);
   }
   PD_CHECK_LAUNCH("pw_gemm_split_weights");
+  return 0;
+}
+
+// bf16x3 images of W[M,K] (-> out, split_bytes(M,K)) and of W^T (-> out_t, split_bytes(K,M)) in one launch
+extern "C" int paradis_pw_gemm_split_weights_pair(const float* W, int M, int K, void* out, void* out_t, void* stream) {
+  PD_REQUIRE(W != nullptr && out != nullptr && out_t != nullptr && out != out_t && M >= 1 && K >= 1,
+             "pw_gemm_split_weights_pair: bad arguments");
+  const int KT = (K + SBK - 1) / SBK, KTt = (M + SBK - 1) / SBK;
+  const int64_t units = (int64_t)((M + BM - 1) / BM) * KT * 256, units_t = (int64_t)((K + BM - 1) / BM) * KTt * 256;
+  const int blocks = (int)std::min<int64_t>((std::max(units, units_t) + 255) / 256, 4096);
+  hipLaunchKernelGGL(split_weights_pair_kernel, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, W, M, K, KT, KTt,
+                     units, units_t, (u32x4*)out, (u32x4*)out_t);
+  PD_CHECK_LAUNCH("pw_gemm_split_weights_pair");
   return 0;
 }
 

@@ -240,9 +240,11 @@ dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
 //   the pole row itself seen through the mirror (dr = -y resp. H-1-y) needs the W/2-shifted pole
 //   row, which differs from E's unshifted row: K extra taps read from global memory.
 // Longitude wrap is implied by E's periodic columns.
+// `addend` (nullable): gx = dgrad + addend - the other gradient of the stencil's input (a consumer around the block:
+// the gated blend's share of the advection input), added here instead of by a separate pass of the autograd engine.
 template <int K>
 __global__ void __launch_bounds__(256)
-dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w, const float* __restrict__ addend,
                         float* __restrict__ gx, int C, int H, int W, int tiles_x, int tiles,
                         int whole_vec4) {
   constexpr int P = (K - 1) / 2, LW = TW + K - 1;
@@ -294,7 +296,6 @@ dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
   }
   const int xx = tx0 + xl;
   if (xx >= W) return;
-  float* gp = gx + plane * (int64_t)H * W;
   const int half = W >> 1;
 #pragma unroll
   for (int o = 0; o < RPT; ++o) {
@@ -316,15 +317,17 @@ dwconv_geo_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ 
         extra += wc[a * K + b] * pv;   // (wc, not the register copy: a is not a compile-time index)
       }
     }
-    gp[(int64_t)yy * W + xx] = acc[o] + extra;
+    const int64_t at = plane * (int64_t)H * W + (int64_t)yy * W + xx;
+    gx[at] = acc[o] + extra + (addend ? addend[at] : 0.f);
   }
 }
 
 // whole-plane path of the data gradient: PLANE_CHUNK planes per workgroup, next plane's loads in flight (see
 // dwconv_geo_fwd_planes_kernel); the mirrored pole rows come from the tile
-template <int K>
+template <int K, bool ADD>
 __global__ void __launch_bounds__(256, 5)
-dwconv_geo_dgrad_planes_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+dwconv_geo_dgrad_planes_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                               const float* __restrict__ addend, float* __restrict__ gx,
                                int C, int H, int64_t planes) {
   constexpr int P = (K - 1) / 2, LW = TW + K - 1, W = TW;
   __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
@@ -342,6 +345,13 @@ dwconv_geo_dgrad_planes_kernel(const float* __restrict__ gy, const float* __rest
     sg.store(tile, q, hv);
     __syncthreads();
     if (i + 1 < n) sg.load(gy + (plane + 1) * (int64_t)H * W, q, hv);
+    const unsigned o0 = (unsigned)(r0 * W + xl) * 4u;
+    float av[RPT];                  // this plane's addend values: in flight under the stencil arithmetic
+    if (ADD) {
+      const ubase_t ab = uniform_base(addend + plane * (int64_t)H * W);
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) av[o] = (r0 + o < H) ? load_at<float>(ab + o * W * 4, o0) : 0.f;
+    }
     float wr[K * K];
 #pragma unroll
     for (int j = 0; j < K * K; ++j) wr[j] = wc[j];
@@ -380,7 +390,6 @@ dwconv_geo_dgrad_planes_kernel(const float* __restrict__ gy, const float* __rest
       __builtin_amdgcn_sched_barrier(0);
     }
     const ubase_t gp = uniform_base(gx + plane * (int64_t)H * W);
-    const unsigned o0 = (unsigned)(r0 * W + xl) * 4u;
     constexpr int half = W >> 1;
 #pragma unroll
     for (int o = 0; o < RPT; ++o) {
@@ -399,7 +408,7 @@ dwconv_geo_dgrad_planes_kernel(const float* __restrict__ gy, const float* __rest
             extra += wc[a * K + b] * tile[(prow + P) * LW + col + P];
           }
         }
-        store_at<float>(gp + o * W * 4, o0, acc[o] + extra);
+        store_at<float>(gp + o * W * 4, o0, ADD ? (acc[o] + extra) + av[o] : acc[o] + extra);   // (= the two-pass sum, bit for bit)
       }
     }
     __syncthreads();
@@ -750,24 +759,42 @@ extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const floa
   return 0;
 }
 
-extern "C" int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx, int B, int C,
-                                        int H, int W, int k, void* stream) {
+static int dwconv_geo_dgrad_launch(const float* gy, const float* w, const float* addend, float* gx, int B, int C,
+                                   int H, int W, int k, void* stream) {
   if (int e = check_dw("dwconv_geo_dgrad", B, C, H, W, k)) return e;
   if (B == 0) return 0;
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
-  if (DWCONV_PLANES && whole_plane_vec4(gy, H, W, k) && (reinterpret_cast<uintptr_t>(gx) & 3) == 0) {
+  if (DWCONV_PLANES && whole_plane_vec4(gy, H, W, k) && (reinterpret_cast<uintptr_t>(gx) & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(addend) & 3) == 0) {
     const int64_t planes = (int64_t)B * C;
-    hipLaunchKernelGGL(dwconv_geo_dgrad_planes_kernel<5>, dim3((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK)),
-                       dim3(256), 0, (hipStream_t)stream, gy, w, gx, C, H, planes);
+    const dim3 grid((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK));
+    if (addend)
+      hipLaunchKernelGGL((dwconv_geo_dgrad_planes_kernel<5, true>), grid, dim3(256), 0, (hipStream_t)stream, gy, w,
+                         addend, gx, C, H, planes);
+    else
+      hipLaunchKernelGGL((dwconv_geo_dgrad_planes_kernel<5, false>), grid, dim3(256), 0, (hipStream_t)stream, gy, w,
+                         addend, gx, C, H, planes);
     PD_CHECK_LAUNCH("dwconv_geo_dgrad");
     return 0;
   }
   const unsigned grid = (unsigned)((int64_t)B * C * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_dgrad_kernel<KK>, dim3(grid), dim3(256), 0,
-                                   (hipStream_t)stream, gy, w, gx, C, H, W, tx, tiles,
+                                   (hipStream_t)stream, gy, w, addend, gx, C, H, W, tx, tiles,
                                    whole_plane_vec4(gy, H, W, k)));
   PD_CHECK_LAUNCH("dwconv_geo_dgrad");
   return 0;
+}
+
+extern "C" int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx, int B, int C,
+                                        int H, int W, int k, void* stream) {
+  return dwconv_geo_dgrad_launch(gy, w, nullptr, gx, B, C, H, W, k, stream);
+}
+
+// gx = dgrad(gy) + addend (addend [B,C,H,W], not aliasing gx)
+extern "C" int paradis_dwconv_geo_dgrad_add(const float* gy, const float* w, const float* addend, float* gx, int B,
+                                            int C, int H, int W, int k, void* stream) {
+  PD_REQUIRE(addend != nullptr && addend != gx, "dwconv_geo_dgrad_add: addend must be a tensor other than gx");
+  return dwconv_geo_dgrad_launch(gy, w, addend, gx, B, C, H, W, k, stream);
 }
 
 extern "C" size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k) {

@@ -63,12 +63,18 @@ class NeuralSemiLagrangian(torch.nn.Module):
         return self.up_projection(interpolated)
 
     def forward_velocities(self, hidden_features: torch.Tensor, velocities: torch.Tensor,
-                           dt: float) -> torch.Tensor:
+                           dt: float, return_skip: bool = False):
         """Same as ``forward`` with u = velocities[:, :K], v = velocities[:, K:] passed as one tensor
-        (what ``Paradis._layer_step`` has at hand): saves the slice/zero-fill/copy passes of autograd."""
-        projected = self.down_projection(hidden_features)
+        (what ``Paradis._layer_step`` has at hand): saves the slice/zero-fill/copy passes of autograd.
+        ``return_skip``: also hand back ``hidden_features`` for the caller's gated blend (``(advected, hidden)``), so
+        the blend's gradient enters the down-projection's first backward kernel (``GMBlock.forward``)."""
+        if return_skip:
+            projected, skip = self.down_projection(hidden_features, return_skip=True)
+        else:
+            projected = self.down_projection(hidden_features)
         interpolated = ops.sl_advect_vel(projected, velocities, self._geom, dt, self.interpolation)
-        return self.up_projection(interpolated)
+        out = self.up_projection(interpolated)
+        return (out, skip) if return_skip else out
 
 
 # north_star spelling

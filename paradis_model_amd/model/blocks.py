@@ -97,10 +97,18 @@ class SepConv(nn.Module):
         self.depthwise = nn.Conv2d(input_dim, input_dim, kernel_size, groups=input_dim, bias=False)
         self.pointwise = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
-    def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, bias_proj=None):
-        x = ops.dwconv_geo(x, self.depthwise.weight, self.depthwise.bias)
-        return ops.pointwise(x, self.pointwise.weight, self.pointwise.bias, bias_map, residual, act,
-                             bias_proj=bias_proj)
+    def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, bias_proj=None,
+                with_skip: bool = False):
+        """``with_skip``: also hand back the input for a consumer around the block (``(out, x)``): its gradient is
+        then added inside the stencil's data-gradient kernel (``ops.dwconv_geo_skip``)."""
+        skip = None
+        if with_skip:
+            x, skip = ops.dwconv_geo_skip(x, self.depthwise.weight, self.depthwise.bias)
+        else:
+            x = ops.dwconv_geo(x, self.depthwise.weight, self.depthwise.bias)
+        out = ops.pointwise(x, self.pointwise.weight, self.pointwise.bias, bias_map, residual, act,
+                            bias_proj=bias_proj)
+        return (out, skip) if with_skip else out
 
 
 class ChannelNorm(nn.Module):
@@ -246,6 +254,9 @@ class GMBlock(nn.Sequential):
         skip, x_in = None, x
         fuse_skip = (n > 0 and isinstance(mods[0], ChannelNorm) and torch.is_grad_enabled()
                      and x.requires_grad and (return_skip or residual is x))
+        # a block that starts with a depthwise stencil: the other consumers' gradients enter its data-gradient kernel
+        stencil_skip = (n > 0 and isinstance(mods[0], SepConv) and torch.is_grad_enabled() and x.requires_grad
+                        and return_skip and residual is None and x_extra is None)
         if x_extra is not None and not (n and isinstance(mods[0], ChannelNorm)):
             x = torch.cat([x, x_extra], dim=1)
             x_extra = None
@@ -279,6 +290,8 @@ class GMBlock(nn.Sequential):
                 if isinstance(m, CLinear):
                     out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
                             defer_act_grad=hand_off, bias_proj=bias_proj)
+                elif i == 0 and stencil_skip:
+                    out, skip = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj, with_skip=True)
                 else:
                     out = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj)
                 if hand_off:

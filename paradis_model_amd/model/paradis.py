@@ -157,7 +157,9 @@ class Paradis(nn.Module):
         velocities, hidden = self.velocity_nets[i](hidden, return_skip=True)
 
         # transport, gated per latent channel:  h + sigmoid(alpha_i) * (A(h) - h)
-        advected = self.advection[i].forward_velocities(hidden, velocities, self.dt)
+        # (the advection hands its input back: the blend's gradient of `hidden` enters the down-projection's
+        #  first backward kernel instead of an accumulation pass)
+        advected, hidden = self.advection[i].forward_velocities(hidden, velocities, self.dt, return_skip=True)
         hidden = ops.gated_blend(hidden, advected, self.alpha_adv[i])
 
         # mixing: h + D(h)      (residual add fused in the last GEMM epilogue)

@@ -401,6 +401,23 @@ def _(gy, weight):
     return gy.new_empty(gy.shape)
 
 
+@_define("dwconv_geo_dgrad_add(Tensor gy, Tensor weight, Tensor addend) -> Tensor")
+def _dwconv_geo_dgrad_add(gy, weight, addend):
+    _f32(gy, weight, addend)
+    gy, w, addend = gy.contiguous(), weight.contiguous(), addend.contiguous()
+    assert addend.shape == gy.shape
+    B, C, H, W = gy.shape
+    gx = torch.empty_like(gy)
+    check(lib.paradis_dwconv_geo_dgrad_add(dptr(gy), dptr(w), dptr(addend), dptr(gx), B, C, H, W, w.shape[-1],
+                                           stream_ptr()), "dwconv_geo_dgrad_add")
+    return gx
+
+
+@_fake("dwconv_geo_dgrad_add")
+def _(gy, weight, addend):
+    return gy.new_empty(gy.shape)
+
+
 @_define("dwconv_geo_wgrad(Tensor gy, Tensor x, int k, bool has_bias) -> (Tensor, Tensor)")
 def _dwconv_geo_wgrad(gy, x, k, has_bias):
     _f32(gy, x)
@@ -444,6 +461,43 @@ _autograd("dwconv_geo", _dw_setup, _dw_backward)
 def dwconv_geo(x, weight, bias=None):
     require_hip(x, weight, bias)
     return _dwconv_geo(x, weight, bias)
+
+
+class _DwconvSkip(torch.autograd.Function):
+    """``(dwconv_geo(x), x)``: the second output is ``x`` itself for a consumer around the block (the gated blend next
+    to the advection's down-projection), so both gradients of ``x`` arrive at this node and the data-gradient kernel
+    adds the other one as it stores (``paradis_dwconv_geo_dgrad_add``) - no accumulation pass of the autograd engine
+    over the tensor.  Eager only, like ``_ChannelNormSkip``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = _dwconv_geo(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
+        return y, x
+
+    @staticmethod
+    def backward(ctx, gy, gskip):
+        x, w = ctx.saved_tensors
+        if gy is None:          # only the skip path was used
+            return gskip, None, None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _dwconv_geo_dgrad(gy, w) if gskip is None else _dwconv_geo_dgrad_add(gy, w, gskip)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _dwconv_geo_wgrad(gy, x, w.shape[-1], ctx.has_bias)
+            if not ctx.has_bias:
+                gb = None
+        return gx, gw, gb
+
+
+def dwconv_geo_skip(x, weight, bias=None):
+    """``(dwconv_geo(x), x)`` for a stencil whose input has another consumer (see ``_DwconvSkip``)."""
+    require_hip(x, weight, bias)
+    if torch.compiler.is_compiling():
+        return _dwconv_geo(x, weight, bias), x
+    return _DwconvSkip.apply(x, weight, bias)
 
 
 # ---------------------------------------------------------------------------
@@ -852,6 +906,7 @@ def gemm_scheme_name() -> str:
 # post-hook covers both).  Raw writes outside an optimiser step (a user kernel, ``p.data.copy_``) must be
 # followed by ``ops.weights_updated()``.
 WEIGHT_EPOCH = 0
+_WANT_WT_IMAGE = False   # set by ``pointwise`` around the op call: autograd is recording and x needs a gradient
 _IMAGES = {}     # (id(weight), transpose, scheme) -> (weakref, data_ptr, version, epoch, image)
 
 
@@ -894,13 +949,24 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int)
     nbytes = lib.paradis_pw_gemm_split_bytes(Ci, Co, scheme) if transpose else \
         lib.paradis_pw_gemm_split_bytes(Co, Ci, scheme)
     out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, scheme, dptr(out),
-                                            stream_ptr()), "pw_gemm_split_weights")
-    if isinstance(weight, torch.nn.Parameter) or weight.is_leaf:
+    cacheable = isinstance(weight, torch.nn.Parameter) or weight.is_leaf
+    out_t = None
+    if not transpose and scheme == GEMM_BF16X3 and cacheable and _WANT_WT_IMAGE:
+        # a recorded forward whose input needs a gradient: the dgrad GEMM will ask for the image of W^T - both in
+        # one launch (the public wrapper sets the hint: grad mode is off inside the op's own forward)
+        out_t = torch.empty(lib.paradis_pw_gemm_split_bytes(Ci, Co, scheme), dtype=torch.uint8, device=weight.device)
+        check(lib.paradis_pw_gemm_split_weights_pair(dptr(w2), Co, Ci, dptr(out), dptr(out_t), stream_ptr()),
+              "pw_gemm_split_weights_pair")
+    else:
+        check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, scheme, dptr(out),
+                                                stream_ptr()), "pw_gemm_split_weights")
+    if cacheable:
         wid = id(weight)
         try:
             ref = weakref.ref(weight, lambda _r, wid=wid: _drop_images(wid))
             _IMAGES[key] = (ref, weight.data_ptr(), ver, WEIGHT_EPOCH, out)
+            if out_t is not None:
+                _IMAGES[(wid, True, scheme)] = (ref, weight.data_ptr(), ver, WEIGHT_EPOCH, out_t)
         except TypeError:
             pass
     return out
@@ -1170,8 +1236,17 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     save_z = bool(defer_act_grad)
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
-    y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad),
-                         m8, pw, save_z, GEMM_SCHEME if scheme is None else int(scheme))
+    args = (x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw, save_z,
+            GEMM_SCHEME if scheme is None else int(scheme))
+    if torch.compiler.is_compiling():
+        y, z, _ = _pointwise(*args)
+    else:
+        global _WANT_WT_IMAGE
+        _WANT_WT_IMAGE = torch.is_grad_enabled() and (x.requires_grad or (x_pre is not None and x_pre.requires_grad))
+        try:
+            y, z, _ = _pointwise(*args)
+        finally:
+            _WANT_WT_IMAGE = False
     return (y, z) if defer_act_grad else y
 
 

@@ -99,6 +99,35 @@ def test_clinear_golden(ops):
     _cmp(b.grad, rec["grads"]["conv.bias"], BWD, "gb")
 
 
+@pytest.mark.parametrize("M,K", [(7, 10), (130, 258), (1024, 1068), (97, 512)])
+def test_weight_images_pair_launch_equals_the_two_single_launches(ops, M, K):
+    """paradis_pw_gemm_split_weights_pair: the bf16x3 images of W and W^T from one launch are byte-identical to the
+    two single launches; the recorded forward of ``pointwise`` caches both (one launch), a no-grad forward only W's."""
+    from paradis_model_amd._lib import lib
+    w = seeded(7, M, K).cuda()
+    n, nt = lib.paradis_pw_gemm_split_bytes(M, K, ops.GEMM_BF16X3), lib.paradis_pw_gemm_split_bytes(K, M, ops.GEMM_BF16X3)
+    a, at = torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(nt, dtype=torch.uint8, device="cuda")
+    b, bt = torch.zeros_like(a), torch.zeros_like(at)
+    st = ops.stream_ptr()
+    assert lib.paradis_pw_gemm_split_weights(ops.dptr(w), M, K, 0, ops.GEMM_BF16X3, ops.dptr(a), st) == 0
+    assert lib.paradis_pw_gemm_split_weights(ops.dptr(w), M, K, 1, ops.GEMM_BF16X3, ops.dptr(at), st) == 0
+    assert lib.paradis_pw_gemm_split_weights_pair(ops.dptr(w), M, K, ops.dptr(b), ops.dptr(bt), st) == 0
+    assert torch.equal(a, b) and torch.equal(at, bt)
+    assert lib.paradis_pw_gemm_split_weights_pair(ops.dptr(w), M, K, ops.dptr(b), ops.dptr(b), st) == 1
+    # the cache: a recorded forward leaves both images behind, the data gradient launches nothing more
+    wp = torch.nn.Parameter(w.clone().reshape(M, K, 1, 1))
+    x = seeded(8, 2, K, 8, 16).cuda().requires_grad_(True)
+    with torch.no_grad():
+        ops.pointwise(x, wp, scheme=ops.GEMM_BF16X3)
+    assert (id(wp), False, ops.GEMM_BF16X3) in ops._IMAGES and (id(wp), True, ops.GEMM_BF16X3) not in ops._IMAGES
+    ops.weights_updated()
+    y = ops.pointwise(x, wp, scheme=ops.GEMM_BF16X3)
+    img, img_t = ops._IMAGES[(id(wp), False, ops.GEMM_BF16X3)][4], ops._IMAGES[(id(wp), True, ops.GEMM_BF16X3)][4]
+    assert torch.equal(img, a) and torch.equal(img_t, at)
+    y.sum().backward()
+    assert ops._IMAGES[(id(wp), True, ops.GEMM_BF16X3)][4] is img_t
+
+
 # ----------------------------------------------------------------------------------- depthwise
 @pytest.mark.parametrize("k", [1, 3, 5, 7, 9, 11])
 @pytest.mark.parametrize("B,C,H,W", [(2, 6, 12, 16), (2, 5, 33, 64), (1, 3, 70, 130), (2, 4, 9, 8),
@@ -124,6 +153,40 @@ def test_dwconv_geo(ops, k, B, C, H, W, bias):
     _cmp(wd.grad, wr.grad, BWD, "gw")
     if bias:
         _cmp(bd.grad, br.grad, BWD, "gb")
+
+
+@pytest.mark.parametrize("k,B,C,H,W", [(5, 2, 6, 32, 64), (5, 3, 5, 16, 64), (5, 2, 5, 33, 64), (3, 2, 6, 12, 16),
+                                       (7, 1, 3, 70, 130)])
+def test_dwconv_geo_skip_adds_the_other_gradient_in_the_dgrad_kernel(ops, k, B, C, H, W):
+    """``dwconv_geo_skip`` = ``(dwconv_geo(x), x)``: the gradient of the second output enters the data-gradient kernel
+    as an addend (paradis_dwconv_geo_dgrad_add; whole-plane and tiled kernels).  Oracle: the stencil's input consumed
+    twice, as the gated blend and the advection's down-projection do (reference model/paradis.py:236-240)."""
+    x, w, b = seeded(1, B, C, H, W), seeded(2, C, 1, k, k, scale=1.0 / k), seeded(3, C)
+    ct, ct2 = seeded(4, B, C, H, W), seeded(5, B, C, H, W)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    (O.depthwise_geo(xr, wr, br) * ct).sum().backward(retain_graph=False)
+    gx_conv = xr.grad.clone()
+    want_gx = gx_conv + 3.0 * ct2
+    xd, wd, bd = _dev(x), _dev(w), _dev(b)
+    yd, skip = ops.dwconv_geo_skip(xd, wd, bd)
+    assert skip.data_ptr() == xd.data_ptr()
+    ((yd * ct.cuda()).sum() + (skip * 3.0 * ct2.cuda()).sum()).backward()
+    _cmp(xd.grad, want_gx, BWD, "gx")
+    _cmp(wd.grad, wr.grad, BWD, "gw")
+    _cmp(bd.grad, br.grad, BWD, "gb")
+    # bit-identical to the two-pass form (plain data gradient, then the addition)
+    x2, w2 = _dev(x), _dev(w)
+    (ops.dwconv_geo(x2, w2, _dev(b)) * ct.cuda()).sum().backward()
+    assert torch.equal(xd.grad, x2.grad + 3.0 * ct2.cuda())
+    # only one of the two outputs used
+    x3 = _dev(x)
+    y3, s3 = ops.dwconv_geo_skip(x3, _dev(w), None)
+    (s3 * ct2.cuda()).sum().backward()
+    assert torch.equal(x3.grad.cpu(), ct2)
+    x4 = _dev(x)
+    y4, _ = ops.dwconv_geo_skip(x4, _dev(w), _dev(b))
+    (y4 * ct.cuda()).sum().backward()
+    assert torch.equal(x4.grad, x2.grad)
 
 
 def test_sepconv_golden(ops):

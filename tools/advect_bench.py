@@ -33,9 +33,20 @@ def main():
         _, lg, og = make_grids(H, W, poles)
         geom = ops.AdvectGeometry(lg, og)
         pts = B * K * H * W
-        for scale in scales:
+        for scale in scales + (["smooth"] if os.environ.get("ADVECT_BENCH_SMOOTH", "1") == "1" else []):
             f = torch.randn(B, K, H, W, device="cuda", requires_grad=True)
-            vel = (torch.randn(B, 2 * K, H, W, device="cuda") * scale).requires_grad_(True)
+            if scale == "smooth":
+                # what a trained model's velocity fields look like next to white noise: a zonal jet of ~12 cells per
+                # layer step (u dt = 12 cells) with smooth perturbations of a few cells, |v dt| ~ 2 cells
+                cells = 2 * 3.14159265 / W          # radians per cell
+                base = torch.randn(B, 2 * K, H // 8 + 1, W // 8 + 1, device="cuda")
+                sm = torch.nn.functional.interpolate(base, size=(H, W), mode="bicubic", align_corners=False)
+                vel = sm * (3 * cells / (0.196887 / 8))
+                vel[:, :K] += 12 * cells / (0.196887 / 8) * torch.cos(lg.cuda())[None, None] ** 2
+                vel[:, K:] *= 0.5
+                vel = vel.contiguous().requires_grad_(True)
+            else:
+                vel = (torch.randn(B, 2 * K, H, W, device="cuda") * scale).requires_grad_(True)
             go = torch.randn(B, K, H, W, device="cuda")
             for mode in ("bicubic", "bilinear"):
                 for name, flags in (("auto", None), ("generic", ops.advect_flags(generic=True))):
