@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 7: paradis_dwconv_geo_dgrad_add, paradis_pw_gemm_split_weights_pair; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -103,6 +103,11 @@ int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* gx,
  * instead of through an accumulation pass.  addend [B,C,H,W], must not alias gx.  (ABI 7) */
 int paradis_dwconv_geo_dgrad_add(const float* gy, const float* w, const float* addend, float* gx,
                                  int B, int C, int H, int W, int k, void* stream);
+/* Both gradients from one call (autograd of the same module): gx = dgrad(gy) (+ addend, nullable), gw [C,k,k],
+ * gbias [C] or NULL.  k = 5, W = 64, H <= 32 with 16-byte aligned planes: one kernel that reads gy once; otherwise the
+ * two kernels above.  Bit-identical to them.  workspace: paradis_dwconv_geo_wgrad_ws_bytes.  (ABI 7) */
+int paradis_dwconv_geo_bwd(const float* gy, const float* x, const float* w, const float* addend, float* gx,
+                           float* gw, float* gbias, int B, int C, int H, int W, int k, void* workspace, void* stream);
 size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k);
 int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* gw, float* gbias,
                              int B, int C, int H, int W, int k, void* workspace, void* stream);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
     "paradis_dwconv_geo_dgrad_add": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "paradis_dwconv_geo_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_dwconv_geo_wgrad_ws_bytes": (S, [I, I, I, I, I]),
     "paradis_dwconv_geo_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_avgpool_geo_fwd": (I, [P, P, L, I, I, I, P]),

@@ -140,6 +140,9 @@ constexpr int PLANE_CHUNK = DWCONV_PLANE_CHUNK;   // planes per workgroup on the
 #ifndef DWCONV_PLANES            // (A/B builds: 0 = one plane per workgroup)
 #define DWCONV_PLANES 1
 #endif
+#ifndef DWCONV_BWD_FUSED         // (A/B builds: 0 = paradis_dwconv_geo_bwd runs the two separate kernels)
+#define DWCONV_BWD_FUSED 1
+#endif
 
 // FLIP=false: y = w (*) geo-padded x  (+bias).   FLIP=true: self-alias part of the data gradient.
 template <int K, bool FLIP>
@@ -550,6 +553,156 @@ dwconv_geo_wgrad_planes_kernel(const float* __restrict__ gy, const float* __rest
   }
 }
 
+// Data gradient AND weight gradient of the whole-plane path in one pass (round 4): both read the cotangent plane; run
+// apart they move gy twice (812 MB per 32x64 B=32 layer at C = 1024), together once (603 MB).  The workgroup is the
+// weight-gradient kernel's - one channel, the samples of a chunk, the 26 sums in registers across planes - and stages
+// TWO tiles per plane: gy with its geocyclic extension (what the data gradient convolves) and x with its halo; the
+// cotangent values the weight gradient multiplies are the centre of the gy tile.  Same arithmetic in the same order as
+// dwconv_geo_dgrad_planes_kernel and dwconv_geo_wgrad_planes_kernel: bit-identical results.
+template <int K, bool ADD>
+__global__ void __launch_bounds__(256, 4)
+dwconv_geo_bwd_planes_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
+                             const float* __restrict__ addend, float* __restrict__ gx, float* __restrict__ partial,
+                             int B, int C, int H, int chunks) {
+  constexpr int P = (K - 1) / 2, LW = TW + K - 1, NW = K * K + 1, W = TW, TN = (TH + K - 1) * (TW + K - 1);
+  __shared__ float tg[TN], tx[TN];
+  __shared__ float red[4][NW];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x - c * chunks;
+  const int xl = threadIdx.x & 63, wave = threadIdx.x >> 6, r0 = wave * RPT;
+  const float* wc = w + (int64_t)c * K * K;
+  float accw[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) accw[i] = 0.f;
+  float gsum = 0.f;
+  PlaneStager<K> sg;
+  sg.init(H);
+  f32x4 qg[2], qx[2];
+  float hg[2], hx[2];
+  const unsigned o0 = (unsigned)(r0 * W + xl) * 4u;
+  auto fetch = [&](int item) __attribute__((always_inline)) {
+    const int64_t off = ((int64_t)item * C + c) * (int64_t)H * W;
+    sg.load(gy + off, qg, hg);
+    sg.load(x + off, qx, hx);
+  };
+  // (rows of the tiles beyond the padded plane are never staged: define them once - see the weight-gradient kernel)
+  for (int i = threadIdx.x; i < TN; i += 256) { tg[i] = 0.f; tx[i] = 0.f; }
+  __syncthreads();
+  if (chunk < B) fetch(chunk);
+  for (int item = chunk; item < B; item += chunks) {
+    const int64_t off = ((int64_t)item * C + c) * (int64_t)H * W;
+    sg.store(tg, qg, hg);
+    sg.store(tx, qx, hx);
+    __syncthreads();
+    if (item + chunks < B) fetch(item + chunks);
+    float av[RPT];
+    if (ADD) {
+      const ubase_t ab = uniform_base(addend + off);
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) av[o] = (r0 + o < H) ? load_at<float>(ab + o * W * 4, o0) : 0.f;
+    }
+    // ---- data gradient of this plane (dwconv_geo_dgrad_planes_kernel)
+    {
+      float wr[K * K];
+#pragma unroll
+      for (int j = 0; j < K * K; ++j) wr[j] = wc[j];
+      float acc[RPT];
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) acc[o] = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RPT + K - 1; ++rr) {
+        const int ii = r0 + rr - P;   // image row of this tile row (wave-uniform)
+        float val[K];
+#pragma unroll
+        for (int b = 0; b < K; ++b) val[b] = tg[(r0 + rr) * LW + xl + b];
+        if (ii >= 0 && ii < H) {
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            const int o = rr - a;
+            if (o >= 0 && o < RPT) {
+#pragma unroll
+              for (int b = 0; b < K; ++b) acc[o] += wr[(K - 1 - a) * K + (K - 1 - b)] * val[b];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            const int o = rr - a;
+            if (o >= 0 && o < RPT) {
+              const int yy = r0 + o;
+              const bool feeds = (ii < 0) ? (yy >= 1) : (yy <= H - 2);
+              if (feeds) {
+#pragma unroll
+                for (int b = 0; b < K; ++b) acc[o] += wr[a * K + (K - 1 - b)] * val[b];
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const ubase_t gp = uniform_base(gx + off);
+      constexpr int half = W >> 1;
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) {
+        const int yy = r0 + o;
+        if (yy < H) {
+          float extra = 0.f;
+          const bool south = yy >= 1 && yy <= P, north = yy >= H - 1 - P && yy <= H - 2;
+          if (south || north) {
+            const int a = south ? P - yy : P + (H - 1 - yy);
+            const int prow = south ? 0 : H - 1;
+#pragma unroll
+            for (int b = 0; b < K; ++b) {
+              int col = xl + P - b + half;
+              if (col >= W) col -= W;
+              if (col >= W) col -= W;
+              extra += wc[a * K + b] * tg[(prow + P) * LW + col + P];
+            }
+          }
+          store_at<float>(gp + o * W * 4, o0, ADD ? (acc[o] + extra) + av[o] : acc[o] + extra);
+        }
+      }
+    }
+    // ---- weight gradient: this plane's share of the channel's sums (dwconv_geo_wgrad_planes_kernel)
+    {
+      float g[RPT];
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) {
+        g[o] = (r0 + o < H) ? tg[(r0 + o + P) * LW + xl + P] : 0.f;
+        gsum += g[o];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPT + K - 1; ++rr) {
+        float val[K];
+#pragma unroll
+        for (int b = 0; b < K; ++b) val[b] = tx[(r0 + rr) * LW + xl + b];
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          const int o = rr - a;
+          if (o >= 0 && o < RPT) {
+#pragma unroll
+            for (int b = 0; b < K; ++b) accw[a * K + b] += g[o] * val[b];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) {
+    float s = wave_sum_dpp(accw[i]);
+    if (xl == 0) red[wave][i] = s;
+  }
+  {
+    float s = wave_sum_dpp(gsum);
+    if (xl == 0) red[wave][K * K] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NW) {
+    float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    partial[((int64_t)c * chunks + chunk) * NW + threadIdx.x] = s;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 dwconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ gw,
                     float* __restrict__ gbias, int C, int KK, int chunks) {
@@ -821,6 +974,39 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
   hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias,
                      C, k * k, chunks);
   PD_CHECK_LAUNCH("dwconv_geo_wgrad");
+  return 0;
+}
+
+// Both gradients of the stencil from one call: gx = dgrad(gy) (+ addend), gw / gbias.  On the whole-plane path
+// (k = 5, W = 64, H <= 32, aligned tensors: the reference grids at 5.625 degrees) ONE kernel reads gy once; elsewhere
+// the two kernels of paradis_dwconv_geo_dgrad / _wgrad run one after the other.  Results are bit-identical to theirs.
+// workspace: paradis_dwconv_geo_wgrad_ws_bytes.  addend, gbias: nullable.
+extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const float* w, const float* addend, float* gx,
+                                      float* gw, float* gbias, int B, int C, int H, int W, int k, void* workspace,
+                                      void* stream) {
+  if (int e = check_dw("dwconv_geo_bwd", B, C, H, W, k)) return e;
+  PD_REQUIRE(workspace != nullptr, "dwconv_geo_bwd: workspace required");
+  PD_REQUIRE(addend == nullptr || addend != gx, "dwconv_geo_bwd: addend must not alias gx");
+  const bool fused = DWCONV_BWD_FUSED && DWCONV_PLANES && B > 0 && whole_plane_vec4(gy, H, W, k) &&
+                     whole_plane_vec4(x, H, W, k) && (reinterpret_cast<uintptr_t>(gx) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(addend) & 3) == 0;
+  if (!fused) {
+    if (int e = dwconv_geo_dgrad_launch(gy, w, addend, gx, B, C, H, W, k, stream)) return e;
+    return paradis_dwconv_geo_wgrad(gy, x, gw, gbias, B, C, H, W, k, workspace, stream);
+  }
+  const int chunks = wgrad_chunks(B, C, 1);
+  float* partial = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (addend)
+    hipLaunchKernelGGL((dwconv_geo_bwd_planes_kernel<5, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend,
+                       gx, partial, B, C, H, chunks);
+  else
+    hipLaunchKernelGGL((dwconv_geo_bwd_planes_kernel<5, false>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend,
+                       gx, partial, B, C, H, chunks);
+  const int n = C * (k * k + 1);
+  hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias, C, k * k,
+                     chunks);
+  PD_CHECK_LAUNCH("dwconv_geo_bwd");
   return 0;
 }
 

@@ -437,6 +437,49 @@ def _(gy, x, k, has_bias):
     return x.new_empty(C, 1, k, k), x.new_empty(C if has_bias else 0)
 
 
+@_define("dwconv_geo_bwd(Tensor gy, Tensor x, Tensor weight, Tensor? addend, bool has_bias) -> (Tensor, Tensor, Tensor)")
+def _dwconv_geo_bwd(gy, x, weight, addend, has_bias):
+    """(gx (+ addend), gw, gb) of the stencil in one call: on the 5.625-degree grids one kernel that reads gy once
+    (paradis_dwconv_geo_bwd); bit-identical to ``dwconv_geo_dgrad`` (``_add``) + ``dwconv_geo_wgrad``."""
+    _f32(gy, x, weight, addend)
+    gy, x, w = gy.contiguous(), x.contiguous(), weight.contiguous()
+    if addend is not None:
+        addend = addend.contiguous()
+        assert addend.shape == gy.shape
+    B, C, H, W = x.shape
+    k = w.shape[-1]
+    gx = torch.empty_like(gy)
+    gw = torch.empty(C, 1, k, k, dtype=x.dtype, device=x.device)
+    gb = torch.empty(C if has_bias else 0, dtype=x.dtype, device=x.device)
+    ws = _ws(lib.paradis_dwconv_geo_wgrad_ws_bytes(B, C, H, W, k), x.device)
+    check(lib.paradis_dwconv_geo_bwd(dptr(gy), dptr(x), dptr(w), dptr(addend), dptr(gx), dptr(gw),
+                                     dptr(gb) if has_bias else None, B, C, H, W, k, dptr(ws), stream_ptr()),
+          "dwconv_geo_bwd")
+    return gx, gw, gb
+
+
+@_fake("dwconv_geo_bwd")
+def _(gy, x, weight, addend, has_bias):
+    C, k = x.shape[1], weight.shape[-1]
+    return gy.new_empty(gy.shape), x.new_empty(C, 1, k, k), x.new_empty(C if has_bias else 0)
+
+
+def _dw_grads(ctx, gy, x, w, addend):
+    """input / weight / bias gradients as the context needs them (one fused call when it needs both kinds)"""
+    need_x = ctx.needs_input_grad[0]
+    need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+    gx = gw = gb = None
+    if need_x and need_w:
+        gx, gw, gb = _dwconv_geo_bwd(gy, x, w, addend, ctx.has_bias)
+    elif need_x:
+        gx = _dwconv_geo_dgrad(gy, w) if addend is None else _dwconv_geo_dgrad_add(gy, w, addend)
+    elif need_w:
+        gw, gb = _dwconv_geo_wgrad(gy, x, w.shape[-1], ctx.has_bias)
+    if not ctx.has_bias:
+        gb = None
+    return gx, gw, gb
+
+
 def _dw_setup(ctx, inputs, output):
     x, w, bias = inputs
     ctx.save_for_backward(x, w)
@@ -445,14 +488,7 @@ def _dw_setup(ctx, inputs, output):
 
 def _dw_backward(ctx, gy):
     x, w = ctx.saved_tensors
-    gx = gw = gb = None
-    if ctx.needs_input_grad[0]:
-        gx = _dwconv_geo_dgrad(gy, w)
-    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-        gw, gb = _dwconv_geo_wgrad(gy, x, w.shape[-1], ctx.has_bias)
-        if not ctx.has_bias:
-            gb = None
-    return gx, gw, gb
+    return _dw_grads(ctx, gy, x, w, None)
 
 
 _autograd("dwconv_geo", _dw_setup, _dw_backward)
@@ -482,14 +518,7 @@ class _DwconvSkip(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if gy is None:          # only the skip path was used
             return gskip, None, None
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = _dwconv_geo_dgrad(gy, w) if gskip is None else _dwconv_geo_dgrad_add(gy, w, gskip)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _dwconv_geo_wgrad(gy, x, w.shape[-1], ctx.has_bias)
-            if not ctx.has_bias:
-                gb = None
-        return gx, gw, gb
+        return _dw_grads(ctx, gy, x, w, gskip)
 
 
 def dwconv_geo_skip(x, weight, bias=None):

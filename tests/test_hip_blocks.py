@@ -189,6 +189,22 @@ def test_dwconv_geo_skip_adds_the_other_gradient_in_the_dgrad_kernel(ops, k, B, 
     assert torch.equal(x4.grad, x2.grad)
 
 
+@pytest.mark.parametrize("B,C,H,W,k", [(2, 6, 32, 64, 5), (5, 3, 16, 64, 5), (3, 1030, 32, 64, 5), (2, 5, 33, 64, 5),
+                                       (2, 6, 12, 16, 3)])
+@pytest.mark.parametrize("add", [False, True])
+@pytest.mark.parametrize("bias", [False, True])
+def test_dwconv_geo_bwd_one_pass_is_bit_identical_to_the_two_kernels(ops, B, C, H, W, k, add, bias):
+    """paradis_dwconv_geo_bwd (whole-plane grids: ONE kernel reading the cotangent once; elsewhere the two kernels):
+    same bits as dgrad (+ addend) and wgrad run apart - which tests/test_dwconv_geo pins to the oracle."""
+    gy, x, w = seeded(1, B, C, H, W).cuda(), seeded(2, B, C, H, W).cuda(), seeded(3, C, 1, k, k, scale=1.0 / k).cuda()
+    ad = seeded(4, B, C, H, W).cuda() if add else None
+    gx, gw, gb = ops._dwconv_geo_bwd(gy, x, w, ad, bias)
+    gx2 = ops._dwconv_geo_dgrad_add(gy, w, ad) if add else ops._dwconv_geo_dgrad(gy, w)
+    gw2, gb2 = ops._dwconv_geo_wgrad(gy, x, k, bias)
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    assert gb.numel() == (C if bias else 0)
+
+
 def test_sepconv_golden(ops):
     g = load_golden("g3_blocks.pt")
     for k in (5, 7):
