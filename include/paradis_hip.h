@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -161,6 +161,14 @@ int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy
                         const float* res, float* Y, float* zpre,
                         int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
                         int act, void* stream);
+/* The same with the gated blend of reference model/paradis.py:239-243 in the epilogue:
+ * Y = res + sigmoid(gate[m]) (act(...) - res); gate [M] = alpha_adv, res = the field the advection started from.
+ * Bit-identical to paradis_pw_gemm_fwd (res = NULL) followed by paradis_gated_blend_fwd.  (ABI 7) */
+int paradis_pw_gemm_fwd_gated(const float* Wt, const float* WtT, const void* Wsplit, int scheme, const uint32_t* x_amax,
+                              const float* X, const float* bias, const float* map, const float* m8, const float* pwT,
+                              int cin, const float* res, const float* gate, float* Y, float* zpre,
+                              int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs,
+                              int act, void* stream);
 /* dX[b][K,N] = (W^T[K,M] * dY[b][M,N]) (* act'(zpre[b][K,N]) if zpre) (+ addend[b][K,N] if addend);
  * WTsplit: split image of W^T (paradis_pw_gemm_split_weights(..., transpose=1)), NULL for PARADIS_GEMM_EXACT */
 int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme,
@@ -223,6 +231,11 @@ size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P);
 int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv, const float* alpha,
                             float* gh, float* gadv, float* galpha, int B, int C, int P,
                             void* workspace, void* stream);
+/* the same gradients from the blended OUTPUT instead of adv (the gated GEMM epilogue never writes adv):
+ * galpha = (1 - sigmoid) sum gout (out - h)  (ABI 7) */
+int paradis_gated_blend_bwd_out(const float* gout, const float* h, const float* out, const float* alpha,
+                                float* gh, float* gadv, float* galpha, int B, int C, int P,
+                                void* workspace, void* stream);
 /* gmap[C,P] = sum_b dz[b,C,P] (NULL to skip), gbias[C] = sum_{b,p} dz (NULL to skip) */
 int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
                        int64_t dz_bs, void* stream);

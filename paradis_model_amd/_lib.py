@@ -51,6 +51,7 @@ SIGNATURES = {
     "paradis_pw_gemm_split_weights": (I, [P, I, I, I, I, P, P]),
     "paradis_pw_gemm_split_weights_pair": (I, [P, I, I, P, P, P]),
     "paradis_pw_gemm_fwd": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
+    "paradis_pw_gemm_fwd_gated": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, L, L, L, I, P]),
     "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I, I]),
     "paradis_forcings": (I, [P, P, P, I, I, I, I, I, I, P, I, ctypes.c_double, ctypes.c_double, P, P, P]),
     "paradis_normalize_features": (I, [P, P, P, P, L, I, ctypes.c_float, I, P]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "paradis_gated_blend_fwd": (I, [P, P, P, P, I, I, I, P]),
     "paradis_gated_blend_bwd_ws_bytes": (S, [I, I, I]),
     "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
+    "paradis_gated_blend_bwd_out": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
     "paradis_bias_grads": (I, [P, P, P, I, I, I, L, P]),
     "paradis_add": (I, [P, P, P, L, P]),
     "paradis_add_bcast": (I, [P, P, P, L, I, P]),
@@ -157,9 +159,10 @@ class LaunchProfiler:
 PROFILER = None
 
 
-def call(name: str, work: float, *args) -> None:
-    """Invoke ``paradis_<name>`` and raise on a non-zero return code; time it when profiling."""
-    fn = getattr(lib, "paradis_" + name)
+def call(name: str, work: float, *args, symbol: str = None) -> None:
+    """Invoke ``paradis_<name>`` (or ``paradis_<symbol>``, accounted under ``name``) and raise on a non-zero return
+    code; time it when profiling."""
+    fn = getattr(lib, "paradis_" + (symbol or name))
     prof = PROFILER
     if prof is None:
         check(fn(*args), name)

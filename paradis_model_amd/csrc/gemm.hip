@@ -44,8 +44,10 @@ struct GemmArgs {
   int nbatch;                 // grid batches (fwd/dgrad: samples; wgrad: k-range splits)
   int inner;                  // wgrad: number of samples reduced (0 for fwd/dgrad)
   int64_t a_is, b_is;         // wgrad: strides between samples
-  // epilogue:  v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v); v += res
+  // epilogue:  v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v);
+  //            v = gate ? res + sigmoid(gate[m]) (v - res) : v + res
   const float* bias; const float* map; const float* res; const float* zmul; float* zout;
+  const float* gate;          // [M] or NULL: the residual is blended in per output channel (gated blend of the advection)
   int64_t res_bs, zmul_bs, zout_bs;
   int act;
   int stagger;                // start-up skew between co-resident workgroups, in units of 512 cycles
@@ -143,8 +145,11 @@ __device__ __forceinline__ void gemm_add_projection(const GemmArgs& g, f32x16 (&
   }
 }
 
+__device__ __forceinline__ float gate_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
+
 // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-//   v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v); v += res; C = v
+//   v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v);
+//   v = gate ? res + sigmoid(gate[m]) (v - res) : v + res; C = v
 // Interior tiles take a path without per-element guards in which all loads of one 32-row group are
 // issued back to back (the guarded form serialises every load behind an s_waitcnt vmcnt(0)).
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int bz, int m0,
@@ -196,8 +201,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
           if (resb) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) t[q] = resb[base + ROWOFF(q)];
+            if (g.gate) {   // h + sigmoid(alpha) (adv - h): the arithmetic of gated_blend_fwd_kernel (misc.hip), bit for bit
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += t[q];
+              for (int q = 0; q < 8; ++q) {
+                const float gm = gate_sigmoid(g.gate[mrow + (q & 3) + 8 * (2 * h + (q >> 2))]);
+                v[q] = fmaf(gm, v[q] - t[q], t[q]);
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] += t[q];
+            }
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) Cb[base + ROWOFF(q)] = v[q];
@@ -227,7 +240,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         if (zoutb) zoutb[off] = v;
         if (zmulb) v *= act_grad(zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
-        if (resb) v += resb[off];
+        if (resb) {
+          const float r = resb[off];
+          v = g.gate ? fmaf(gate_sigmoid(g.gate[m]), v - r, r) : v + r;
+        }
         Cb[off] = v;
       }
     }
@@ -1628,13 +1644,14 @@ int run_split(GemmArgs d, const void* img, int AM, int AK, int scheme, const uin
 }
 }  // namespace
 
-extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void* Wsplit, int scheme,
-                                   const uint32_t* x_amax, const float* X,
-                                   const float* bias, const float* map, const float* m8,
-                                   const float* pwT, int cin, const float* res, float* Y, float* zpre,
-                                   int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
-                                   int64_t y_bs, int act, void* stream) {
+static int pw_gemm_fwd_impl(const float* Wt, const float* WtT, const void* Wsplit, int scheme,
+                            const uint32_t* x_amax, const float* X,
+                            const float* bias, const float* map, const float* m8,
+                            const float* pwT, int cin, const float* res, const float* gate, float* Y, float* zpre,
+                            int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
+                            int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
+  PD_REQUIRE(gate == nullptr || res != nullptr, "pw_gemm_fwd: a gate needs the tensor it blends with (res)");
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
   PD_REQUIRE(known_scheme(scheme) && (Wsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
              "pw_gemm_fwd: scheme %d needs %s weight image", scheme, scheme ? "a" : "no");
@@ -1647,7 +1664,7 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
   g.lda = K; g.ldb = N; g.ldc = N;
   g.a_bs = 0; g.b_bs = x_bs; g.c_bs = y_bs; g.nbatch = B; g.inner = 0;
   g.bias = bias; g.map = map; g.res = res; g.res_bs = res_bs; g.zmul = nullptr; g.zout = zpre;
-  g.zout_bs = (int64_t)M * N; g.act = act;
+  g.zout_bs = (int64_t)M * N; g.act = act; g.gate = gate;
   g.stagger = g_stagger;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
   if (Wsplit != nullptr) {   // split image of the weights: split kernel (any shape)
@@ -1668,6 +1685,30 @@ extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void
   if (int e = launch_gemm<true, false>(g, grid, (hipStream_t)stream)) return e;
   PD_CHECK_LAUNCH("pw_gemm_fwd");
   return 0;
+}
+
+extern "C" int paradis_pw_gemm_fwd(const float* Wt, const float* WtT, const void* Wsplit, int scheme,
+                                   const uint32_t* x_amax, const float* X,
+                                   const float* bias, const float* map, const float* m8,
+                                   const float* pwT, int cin, const float* res, float* Y, float* zpre,
+                                   int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
+                                   int64_t y_bs, int act, void* stream) {
+  return pw_gemm_fwd_impl(Wt, WtT, Wsplit, scheme, x_amax, X, bias, map, m8, pwT, cin, res, nullptr, Y, zpre, B, M, K, N,
+                          x_bs, res_bs, y_bs, act, stream);
+}
+
+// Y = res + sigmoid(gate[m]) (act(W X + ...) - res): the gated blend of the advected field with the field it was
+// advected from (reference model/paradis.py:239-243) inside the epilogue of the up-projection's last layer - the
+// advected tensor is never written.  Same bits as paradis_pw_gemm_fwd followed by paradis_gated_blend_fwd.
+extern "C" int paradis_pw_gemm_fwd_gated(const float* Wt, const float* WtT, const void* Wsplit, int scheme,
+                                         const uint32_t* x_amax, const float* X,
+                                         const float* bias, const float* map, const float* m8,
+                                         const float* pwT, int cin, const float* res, const float* gate, float* Y,
+                                         float* zpre, int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
+                                         int64_t y_bs, int act, void* stream) {
+  PD_REQUIRE(gate != nullptr && res != nullptr, "pw_gemm_fwd_gated: gate [M] and res required");
+  return pw_gemm_fwd_impl(Wt, WtT, Wsplit, scheme, x_amax, X, bias, map, m8, pwT, cin, res, gate, Y, zpre, B, M, K, N,
+                          x_bs, res_bs, y_bs, act, stream);
 }
 
 // Plain batched GEMM  C_b[M,N] = A_b[M,K] B_b[K,N]  (row-major, batch strides in elements) on the same

@@ -215,7 +215,7 @@ gated_blend_fwd_kernel(const float* __restrict__ h, const float* __restrict__ ad
   const int64_t base = (int64_t)blockIdx.x * P;
   for (int p = threadIdx.x; p < P; p += 256) {
     const float hv = h[base + p];
-    out[base + p] = hv + g * (adv[base + p] - hv);
+    out[base + p] = fmaf(g, adv[base + p] - hv, hv);     // (the GEMM epilogue's gated form computes the same bits)
   }
 }
 
@@ -241,15 +241,16 @@ gated_blend_bwd_kernel(const float* __restrict__ gout, const float* __restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// from_out: the partial sums were taken against the blended OUTPUT, sum gout (out - h) = sigmoid sum gout (adv - h)
 __global__ void __launch_bounds__(256)
 gated_blend_finish(const float* __restrict__ partial, const float* __restrict__ alpha,
-                   float* __restrict__ galpha, int B, int C) {
+                   float* __restrict__ galpha, int B, int C, int from_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
   for (int b = 0; b < B; ++b) s += partial[(int64_t)b * C + c];
   const float g = 1.0f / (1.0f + expf(-alpha[c]));
-  galpha[c] = s * g * (1.0f - g);
+  galpha[c] = from_out ? s * (1.0f - g) : s * g * (1.0f - g);
 }
 
 // ------------------------------------------------------------------ bias / bias-map gradients
@@ -418,19 +419,34 @@ extern "C" size_t paradis_gated_blend_bwd_ws_bytes(int B, int C, int P) {
   return (size_t)std::max(B, 1) * C * sizeof(float) + 256;
 }
 
-extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv,
-                                       const float* alpha, float* gh, float* gadv, float* galpha, int B,
-                                       int C, int P, void* workspace, void* stream) {
+static int gated_blend_bwd_impl(const float* gout, const float* h, const float* third, const float* alpha, float* gh,
+                                float* gadv, float* galpha, int B, int C, int P, void* workspace, void* stream,
+                                int from_out) {
   PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "gated_blend_bwd: bad shape");
   PD_REQUIRE(workspace != nullptr, "gated_blend_bwd: workspace required");
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   if (B > 0)
     hipLaunchKernelGGL(gated_blend_bwd_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0, st, gout, h,
-                       adv, alpha, gh, gadv, partial, C, P);
-  hipLaunchKernelGGL(gated_blend_finish, dim3((C + 255) / 256), dim3(256), 0, st, partial, alpha, galpha, B, C);
+                       third, alpha, gh, gadv, partial, C, P);
+  hipLaunchKernelGGL(gated_blend_finish, dim3((C + 255) / 256), dim3(256), 0, st, partial, alpha, galpha, B, C,
+                     from_out);
   PD_CHECK_LAUNCH("gated_blend_bwd");
   return 0;
+}
+
+extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const float* adv,
+                                       const float* alpha, float* gh, float* gadv, float* galpha, int B,
+                                       int C, int P, void* workspace, void* stream) {
+  return gated_blend_bwd_impl(gout, h, adv, alpha, gh, gadv, galpha, B, C, P, workspace, stream, 0);
+}
+
+// The same gradients when the advected tensor was never materialised (paradis_pw_gemm_fwd_gated): `out` is the
+// blended output, adv - h = (out - h) / sigmoid, so galpha = (1 - sigmoid) sum gout (out - h) - no division.
+extern "C" int paradis_gated_blend_bwd_out(const float* gout, const float* h, const float* out,
+                                           const float* alpha, float* gh, float* gadv, float* galpha, int B,
+                                           int C, int P, void* workspace, void* stream) {
+  return gated_blend_bwd_impl(gout, h, out, alpha, gh, gadv, galpha, B, C, P, workspace, stream, 1);
 }
 
 extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,

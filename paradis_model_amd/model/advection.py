@@ -76,6 +76,16 @@ class NeuralSemiLagrangian(torch.nn.Module):
         out = self.up_projection(interpolated)
         return (out, skip) if return_skip else out
 
+    def transport(self, hidden_features: torch.Tensor, velocities: torch.Tensor, dt: float,
+                  alpha: torch.Tensor) -> torch.Tensor:
+        """``h + sigmoid(alpha) * (A(h) - h)`` (reference model/paradis.py:236-243: the advection followed by the
+        caller's gated blend) in one chain: the blend runs in the epilogue of the up-projection's last GEMM, so the
+        advected tensor is never written, and the blend's gradient of ``h`` enters the down-projection's first
+        backward kernel.  Bit-identical to ``ops.gated_blend(h, self.forward_velocities(h, ...), alpha)``."""
+        projected, skip = self.down_projection(hidden_features, return_skip=True)
+        interpolated = ops.sl_advect_vel(projected, velocities, self._geom, dt, self.interpolation)
+        return self.up_projection(interpolated, residual=skip, gate=alpha)
+
 
 # north_star spelling
 SemiLagrangianAdvection = NeuralSemiLagrangian

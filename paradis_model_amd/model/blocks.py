@@ -77,9 +77,9 @@ class CLinear(nn.Module):
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
     def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, x_pre=None,
-                x_act=None, defer_act_grad=False, bias_proj=None):
+                x_act=None, defer_act_grad=False, bias_proj=None, gate=None):
         return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act, x_pre, x_act,
-                             defer_act_grad, bias_proj)
+                             defer_act_grad, bias_proj, gate=gate)
 
 
 class SepConv(nn.Module):
@@ -98,7 +98,7 @@ class SepConv(nn.Module):
         self.pointwise = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
     def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, bias_proj=None,
-                with_skip: bool = False):
+                with_skip: bool = False, gate=None):
         """``with_skip``: also hand back the input for a consumer around the block (``(out, x)``): its gradient is
         then added inside the stencil's data-gradient kernel (``ops.dwconv_geo_skip``)."""
         skip = None
@@ -107,7 +107,7 @@ class SepConv(nn.Module):
         else:
             x = ops.dwconv_geo(x, self.depthwise.weight, self.depthwise.bias)
         out = ops.pointwise(x, self.pointwise.weight, self.pointwise.bias, bias_map, residual, act,
-                            bias_proj=bias_proj)
+                            bias_proj=bias_proj, gate=gate)
         return (out, skip) if with_skip else out
 
 
@@ -244,10 +244,15 @@ class GMBlock(nn.Sequential):
         super().__init__(OrderedDict(children))
         init_module_convs(self, last_conv_scale=0.1)
 
-    def forward(self, x, residual=None, x_extra=None, return_skip: bool = False):
+    def forward(self, x, residual=None, x_extra=None, return_skip: bool = False, gate=None):
         """``return_skip``: also return the block input for other consumers (``(out, x)``); with a
         leading ChannelNorm the gradients of all those consumers are summed inside its backward
-        kernel.  The same happens automatically when ``residual`` is the block input itself."""
+        kernel.  The same happens automatically when ``residual`` is the block input itself.
+        ``gate`` (with ``residual``): the block output is BLENDED with the residual per channel,
+        ``residual + sigmoid(gate) * (block(x) - residual)`` (reference model/paradis.py:239-243), inside the last
+        layer's GEMM epilogue."""
+        if gate is not None and residual is None:
+            raise ValueError("GMBlock: a gate needs the residual it blends with")
         mods = list(self.children())
         n = len(mods)
         i = 0
@@ -287,13 +292,14 @@ class GMBlock(nn.Sequential):
                 # layer is a CLinear (only consumer of this output) and autograd is recording
                 hand_off = (act is not None and res is None and j < n and isinstance(mods[j], CLinear)
                             and isinstance(m, CLinear) and torch.is_grad_enabled())
+                g = gate if res is not None else None
                 if isinstance(m, CLinear):
                     out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
-                            defer_act_grad=hand_off, bias_proj=bias_proj)
+                            defer_act_grad=hand_off, bias_proj=bias_proj, gate=g)
                 elif i == 0 and stencil_skip:
                     out, skip = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj, with_skip=True)
                 else:
-                    out = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj)
+                    out = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj, gate=g)
                 if hand_off:
                     x, pre = out
                     pre_act = act
@@ -309,7 +315,7 @@ class GMBlock(nn.Sequential):
                 x = m(x)
                 i += 1
         if residual is not None:
-            x = ops.add(x, residual)
+            x = ops.add(x, residual) if gate is None else ops.gated_blend(residual, x, gate)
         if return_skip:
             return x, (skip if skip is not None else x_in)
         return x

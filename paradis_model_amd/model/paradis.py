@@ -157,10 +157,9 @@ class Paradis(nn.Module):
         velocities, hidden = self.velocity_nets[i](hidden, return_skip=True)
 
         # transport, gated per latent channel:  h + sigmoid(alpha_i) * (A(h) - h)
-        # (the advection hands its input back: the blend's gradient of `hidden` enters the down-projection's
-        #  first backward kernel instead of an accumulation pass)
-        advected, hidden = self.advection[i].forward_velocities(hidden, velocities, self.dt, return_skip=True)
-        hidden = ops.gated_blend(hidden, advected, self.alpha_adv[i])
+        # (one chain: the blend sits in the epilogue of the up-projection's last GEMM and its gradient of `hidden`
+        #  enters the down-projection's first backward kernel - NeuralSemiLagrangian.transport)
+        hidden = self.advection[i].transport(hidden, velocities, self.dt, self.alpha_adv[i])
 
         # mixing: h + D(h)      (residual add fused in the last GEMM epilogue)
         hidden = self.diffusion[i](hidden, residual=hidden)

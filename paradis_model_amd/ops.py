@@ -1019,12 +1019,14 @@ def _(x):
 
 
 @_define("pointwise(Tensor x, Tensor weight, Tensor? bias, Tensor? bmap, Tensor? residual, int act, "
-         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z, int scheme) "
-         "-> (Tensor, Tensor, Tensor)")
-def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme):
+         "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z, int scheme, "
+         "Tensor? gate) -> (Tensor, Tensor, Tensor)")
+def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme, gate):
     """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z);
     third = amax partials of x (f16x2 scheme; empty otherwise), kept for the weight gradient.
     ``scheme``: GEMM arithmetic (GEMM_EXACT / GEMM_BF16X3 / GEMM_F16X2); the backward uses the same.
+    ``gate`` [Co] (with ``residual``): y = residual + sigmoid(gate)[:,None] * (act(...) - residual) - the gated blend
+    of reference model/paradis.py:239-243 in the GEMM epilogue (``ops.gated_blend`` without the advected tensor).
 
     Activation-gradient hand-off between two chained ops (GMBlock drives it):
       * ``defer_act_grad`` (producer): the op's backward receives d(pre-activation) directly and
@@ -1033,12 +1035,15 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         dgrad multiplies by act'(x_pre) in the GEMM epilogue, so what it returns as the gradient of
         ``x`` already is the producer's d(pre-activation).
     """
-    _f32(x, weight, bias, bmap, residual, m8, pw)
+    _f32(x, weight, bias, bmap, residual, m8, pw, gate)
     x, x_bs = _plane_view(x)
     B, Ci, H, W = x.shape
     Co = weight.shape[0]
     P = H * W
     assert weight.numel() == Co * Ci, "weight/in-channel mismatch"
+    if gate is not None:
+        assert residual is not None and gate.numel() == Co, "a gate needs the residual it blends with, one value per channel"
+        gate = gate.reshape(Co).contiguous()
     res_bs = 0
     if residual is not None:
         residual, res_bs = _plane_view(residual)
@@ -1070,15 +1075,18 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
         w2 = weight.reshape(Co, Ci)
         if not w2.is_contiguous():
             w2 = w2.contiguous()
-    _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, dptr(w2), dptr(w2t), dptr(wsp), scheme,
-              dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
-              dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual), dptr(y),
-              dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
+    head = (dptr(w2), dptr(w2t), dptr(wsp), scheme, dptr(x_amax) if x_amax.numel() else None, dptr(x), dptr(bias),
+            dptr(bmap), dptr(m8) if cin else None, dptr(pwt) if cin else None, cin, dptr(residual))
+    tail = (dptr(y), dptr(z) if z.numel() else None, B, Co, Ci, P, x_bs, res_bs, Co * P, act, stream_ptr())
+    if gate is None:
+        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, *head, *tail)
+    else:
+        _lib.call("pw_gemm_fwd", 2.0 * B * Co * Ci * P, *head, dptr(gate), *tail, symbol="pw_gemm_fwd_gated")
     return y, z, x_amax
 
 
 @_fake("pointwise")
-def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme):
+def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme, gate):
     B, _, H, W = x.shape
     y = x.new_empty(B, weight.shape[0], H, W)
     return (y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0)),
@@ -1197,9 +1205,12 @@ def _(gmap, m8, pw):
 
 
 def _pw_setup(ctx, inputs, output):
-    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, scheme = inputs
+    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, scheme, gate = inputs
     y, z, x_amax = output
-    ctx.save_for_backward(x, weight, z, x_pre, m8, pw, x_amax)
+    gated = gate is not None
+    # (a gated epilogue blends with its residual: the backward needs both ends of the blend - the residual and the
+    #  output, which the next block keeps alive anyway - and the gate)
+    ctx.save_for_backward(x, weight, z, x_pre, m8, pw, x_amax, *((residual, y, gate) if gated else (None, None, None)))
     ctx.meta = (act, bias is not None, bmap is not None, residual is not None,
                 x_act if x_pre is not None else 0, bool(defer), scheme)
     # z carries no gradient; without this autograd would materialise a full-size zero tensor for it
@@ -1208,13 +1219,20 @@ def _pw_setup(ctx, inputs, output):
 
 
 def _pw_backward(ctx, gy, gz=None, gamax=None):
-    x, weight, z, x_pre, m8, pw, x_amax = ctx.saved_tensors
+    x, weight, z, x_pre, m8, pw, x_amax, res_saved, y_saved, gate = ctx.saved_tensors
     act, has_bias, has_map, has_res, x_act, deferred, scheme = ctx.meta
     need = ctx.needs_input_grad
     if gy is None:
-        return (None,) * 13
+        return (None,) * 14
     has_proj = pw is not None
-    gres = gy if has_res else None
+    ggate = None
+    if gate is not None:
+        # gradient of the blend: d residual, d (activated GEMM output) - what the rest of this backward continues
+        # with - and d gate, in one pass over (gy, residual, y)
+        gres, gy, ggate = _gated_blend_backward_out(gy, res_saved, y_saved, gate)
+        ggate = ggate.reshape(gate.shape)
+    else:
+        gres = gy if has_res else None
     if act != 0 and not deferred:
         dz = _act_backward(gy, z, act)
     else:
@@ -1242,31 +1260,35 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
         gpw, gm8 = _global_bias_proj_backward(gmap, m8, pw)
         gmap = None
-    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None, None
+    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None, None, ggate
 
 
 _autograd("pointwise", _pw_setup, _pw_backward)
 
 
 def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
-              defer_act_grad=False, bias_proj=None, scheme: Optional[int] = None):
+              defer_act_grad=False, bias_proj=None, scheme: Optional[int] = None, gate=None):
     """y = residual + act(weight . x + bias[:,None] + bias_map); weight [Co,Ci] or [Co,Ci,1,1].
 
     ``bias_proj=(m8[Cin,H,W], Pw[Co,Cin])`` adds the projected low-rank GlobalBias map inside the GEMM
     epilogue instead of a materialised ``bias_map``.
     ``scheme``: GEMM arithmetic, default ``ops.GEMM_SCHEME`` (read when the call is made / traced).
     ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
-    called with ``x_pre=z, x_act=act`` (see the op docstring); only valid when ``y`` has no other use."""
+    called with ``x_pre=z, x_act=act`` (see the op docstring); only valid when ``y`` has no other use.
+    ``gate`` [Co] (needs ``residual``): y = residual + sigmoid(gate) * (act(...) - residual), i.e.
+    ``gated_blend(residual, pointwise(...), gate)`` without the intermediate tensor (bit-identical)."""
     if defer_act_grad and (act is None or residual is not None):
         raise ValueError("defer_act_grad needs an activation and no residual")
+    if gate is not None and residual is None:
+        raise ValueError("a gate needs the residual it blends with")
     m8, pw = bias_proj if bias_proj is not None else (None, None)
-    require_hip(x, weight, bias, bias_map, residual, x_pre, m8, pw)
+    require_hip(x, weight, bias, bias_map, residual, x_pre, m8, pw, gate)
     code = ACT_CODES[act]
     save_z = bool(defer_act_grad)
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
     args = (x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw, save_z,
-            GEMM_SCHEME if scheme is None else int(scheme))
+            GEMM_SCHEME if scheme is None else int(scheme), gate)
     if torch.compiler.is_compiling():
         y, z, _ = _pointwise(*args)
     else:
@@ -1346,6 +1368,27 @@ def _gated_blend_backward(gout, h, adv, alpha):
 @_fake("gated_blend_backward")
 def _(gout, h, adv, alpha):
     return h.new_empty(h.shape), h.new_empty(h.shape), alpha.new_empty(alpha.shape)
+
+
+@_define("gated_blend_backward_out(Tensor gout, Tensor h, Tensor out, Tensor alpha) -> (Tensor, Tensor, Tensor)")
+def _gated_blend_backward_out(gout, h, out, alpha):
+    """(gh, gadv, galpha) of ``out = h + sigmoid(alpha) (adv - h)`` from the blended output (the gated GEMM epilogue
+    never materialises adv): galpha = (1 - sigmoid) sum gout (out - h)."""
+    _f32(gout, h, out, alpha)
+    gout, h, out = gout.contiguous(), h.contiguous(), out.contiguous()
+    B, C, H, W = h.shape
+    alpha = alpha.reshape(C).contiguous()
+    gh, gadv = torch.empty_like(h), torch.empty_like(h)
+    galpha = torch.empty(C, dtype=h.dtype, device=h.device)
+    ws = _ws(lib.paradis_gated_blend_bwd_ws_bytes(B, C, H * W), h.device)
+    check(lib.paradis_gated_blend_bwd_out(dptr(gout), dptr(h), dptr(out), dptr(alpha), dptr(gh), dptr(gadv),
+                                          dptr(galpha), B, C, H * W, dptr(ws), stream_ptr()), "gated_blend_bwd_out")
+    return gh, gadv, galpha
+
+
+@_fake("gated_blend_backward_out")
+def _(gout, h, out, alpha):
+    return h.new_empty(h.shape), h.new_empty(h.shape), alpha.new_empty(alpha.numel())
 
 
 def _blend_setup(ctx, inputs, output):

@@ -119,10 +119,18 @@ def test_fake_kernels_of_backward_ops_give_the_right_shapes():
         assert gw.shape == (5, C) and gb.shape == (5,)
         gb, gmap = O.bias_grads(e(B, 5, H, W), False, True)
         assert gb.numel() == 0 and gmap.shape == (5, H, W)
-        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, True, 3)
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, True, 3, None)
         assert y.shape == z.shape == (B, 5, H, W) and am.numel() == 0
-        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, False, 2)
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, None, 1, None, 0, False, None, None, False, 2, None)
         assert z.numel() == 0 and am.numel() == 1024     # the f16x2 scheme's amax words are an explicit op output
+        y, z, am = O.pointwise(e(B, C, H, W), e(5, C, 1, 1), e(5), None, e(B, 5, H, W), 1, None, 0, False, None, None, True,
+                               3, e(5))                          # gated epilogue (blend with the residual)
+        assert y.shape == (B, 5, H, W)
+        gh, gadv, ga = O.gated_blend_backward_out(e(B, C, H, W), e(B, C, H, W), e(B, C, H, W), e(C))
+        assert gh.shape == gadv.shape == (B, C, H, W) and ga.shape == (C,)
+        gx, gw, gb = O.dwconv_geo_bwd(e(B, C, H, W), e(B, C, H, W), e(C, 1, 5, 5), e(B, C, H, W), True)
+        assert gx.shape == (B, C, H, W) and gw.shape == (C, 1, 5, 5) and gb.shape == (C,)
+        assert O.dwconv_geo_dgrad_add(e(B, C, H, W), e(C, 1, 5, 5), e(B, C, H, W)).shape == (B, C, H, W)
         assert O.concat_channels([e(B, 3, H, W), e(B, 4, H, W)]).shape == (B, 7, H, W)
         assert O.slice_channels(e(B, 7, H, W), 3, 4).shape == (B, 4, H, W)
         loss, grad = O.paradis_loss(e(B, C, H, W), e(B, C, H, W), e(C), e(H), 1, 1.0, True)

@@ -385,6 +385,69 @@ def test_activation_and_blend(ops, act):
         _cmp(d.grad, t.grad, BWD, n)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 10, 7, 12, 16), (2, 130, 258, 32, 64), (1, 768, 1024, 32, 64)])
+@pytest.mark.parametrize("act", [None, "SiLU"])
+@pytest.mark.parametrize("scheme", ["exact", "bf16x3"])
+def test_gated_epilogue_equals_gemm_then_blend(ops, B, Ci, Co, H, W, act, scheme):
+    """``pointwise(..., residual=h, gate=alpha)`` = ``gated_blend(h, pointwise(...), alpha)`` (reference
+    model/paradis.py:236-243) without the advected tensor: the forward bit for bit (interior and edge tiles), the
+    gradients of x, W, bias and h bit for bit as well (same kernels on the same d adv), d alpha - taken against the
+    blended output instead of adv - within the gradient tolerance of the oracle formula."""
+    sc = {"exact": ops.GEMM_EXACT, "bf16x3": ops.GEMM_BF16X3}[scheme]
+    x, w, b = seeded(1, B, Ci, H, W), seeded(2, Co, Ci, 1, 1, scale=Ci ** -0.5), seeded(3, Co, scale=0.1)
+    h, al, ct = seeded(4, B, Co, H, W), seeded(5, Co), seeded(6, B, Co, H, W)
+    a = [_dev(t) for t in (x, w, b, h, al)]
+    y1 = ops.gated_blend(a[3], ops.pointwise(a[0], a[1], a[2], act=act, scheme=sc), a[4])
+    y1.backward(ct.cuda())
+    f = [_dev(t) for t in (x, w, b, h, al)]
+    y2 = ops.pointwise(f[0], f[1], f[2], residual=f[3], act=act, scheme=sc, gate=f[4])
+    y2.backward(ct.cuda())
+    assert torch.equal(y1, y2)
+    for n, p, q in zip(("gx", "gw", "gb", "gh"), a[:4], f[:4]):
+        assert torch.equal(p.grad, q.grad), n
+    _cmp(f[4].grad, a[4].grad.cpu(), 2e-5, "galpha")
+    # against the oracle formula in fp64
+    t = [v.double().requires_grad_(True) for v in (x, w, b, h, al)]
+    z = torch.nn.functional.conv2d(t[0], t[1], t[2])
+    z = torch.nn.functional.silu(z) if act == "SiLU" else z
+    yo = t[3] + torch.sigmoid(t[4]).view(1, -1, 1, 1) * (z - t[3])
+    yo.backward(ct.double())
+    _cmp(y2, yo.float(), 2e-5, "y")
+    _cmp(f[4].grad, t[4].grad.float(), BWD, "galpha vs fp64")
+    _cmp(f[3].grad, t[3].grad.float(), BWD, "gh vs fp64")
+
+
+def test_advection_transport_equals_advection_then_blend(ops):
+    """NeuralSemiLagrangian.transport (blend in the up-projection's epilogue, its gradient of h through the
+    down-projection's stencil) against forward_velocities + ops.gated_blend: same output bits, same gradients."""
+    from paradis_model_amd.config import reduced_config
+    from paradis_model_amd.harness import make_grids
+    from paradis_model_amd.model.advection import NeuralSemiLagrangian
+    cfg = reduced_config()
+    _, lg, og = make_grids(16, 32, False)
+    torch.manual_seed(3)
+    adv = NeuralSemiLagrangian(cfg, 24, (16, 32), num_vels=6, lat_grid=lg, lon_grid=og,
+                               interpolation=cfg.model.adv_interpolation).cuda()
+    hsrc, vel, al, ct = seeded(1, 2, 24, 16, 32), seeded(2, 2, 12, 16, 32, scale=0.5), seeded(3, 24), seeded(4, 2, 24, 16, 32)
+    outs = []
+    for fused in (False, True):
+        adv.zero_grad(set_to_none=True)
+        h, v, a = _dev(hsrc), _dev(vel), _dev(al)
+        h2 = h * 1.0            # a non-leaf input, as inside the model
+        if fused:
+            y = adv.transport(h2, v, 0.1, a)
+        else:
+            y = ops.gated_blend(h2, adv.forward_velocities(h2, v, 0.1), a)
+        y.backward(ct.cuda())
+        outs.append((y.detach(), h.grad, v.grad, a.grad, [p.grad.clone() for p in adv.parameters()]))
+    (y0, gh0, gv0, ga0, gp0), (y1, gh1, gv1, ga1, gp1) = outs
+    assert torch.equal(y0, y1)
+    assert max_rel(gh1.cpu(), gh0.cpu()) <= 1e-6 and max_rel(gv1.cpu(), gv0.cpu()) <= 1e-6
+    assert max_rel(ga1.cpu(), ga0.cpu()) <= 2e-5
+    for p, q in zip(gp0, gp1):
+        assert max_rel(q.cpu(), p.cpu()) <= 1e-6
+
+
 def test_gmblock_golden():
     from paradis_model_amd.model import GMBlock
     rec = load_golden("g3_blocks.pt")["gmblock"]

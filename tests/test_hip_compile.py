@@ -112,8 +112,13 @@ def test_opcheck_registrations():
     opcheck(torch.ops.paradis.channel_norm.default, (g(1, 4, H, W), g(1, 2, H, W), g(6), g(6), 1e-5),
             test_utils=tests)
     opcheck(torch.ops.paradis.pointwise.default,
-            (g(1, 4, H, W), g(5, 4, 1, 1), g(5), None, g(1, 5, H, W), 1, None, 0, False, None, None, True, ops.GEMM_BF16X3),
-            test_utils=tests)
+            (g(1, 4, H, W), g(5, 4, 1, 1), g(5), None, g(1, 5, H, W), 1, None, 0, False, None, None, True, ops.GEMM_BF16X3,
+             None), test_utils=tests)
+    opcheck(torch.ops.paradis.pointwise.default,      # gated epilogue: blend with the residual
+            (g(1, 4, H, W), g(5, 4, 1, 1), g(5), None, g(1, 5, H, W), 1, None, 0, False, None, None, True, ops.GEMM_BF16X3,
+             g(5)), test_utils=tests)
+    opcheck(torch.ops.paradis.dwconv_geo_bwd.default, (g(1, 3, H, W), g(1, 3, H, W), g(3, 1, 5, 5), g(1, 3, H, W), True),
+            test_utils=("test_schema", "test_faketensor"))
     opcheck(torch.ops.paradis.gated_blend.default, (g(1, 3, H, W), g(1, 3, H, W), g(3)), test_utils=tests)
     opcheck(torch.ops.paradis.concat_channels.default, ([g(1, 3, H, W), g(1, 2, H, W)],), test_utils=tests)
 

@@ -150,6 +150,13 @@ def _nccl_worker(rank, port, out_dir, graphed):
     torch.cuda.synchronize()
     rec.update(params=torch.cat([p.detach().flatten() for p in model.parameters()]).cpu(), losses=losses)
     torch.save(rec, os.path.join(out_dir, f"nccl_{int(graphed)}.pt"))
+    # ordered teardown: a captured graph holds RCCL nodes - it goes before the communicator does
+    if graphed:
+        del g
+    del step, ddp
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
