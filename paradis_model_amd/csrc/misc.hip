@@ -56,31 +56,85 @@ small_mix_kernel(const float* __restrict__ Wm, int ldo, int ldc, const float* __
   out[(int64_t)o * P + p] = acc;
 }
 
-// gm8[c,p] += sum_{o in chunk} Pw[o,c] * gmap[o,p]   (c < CIN <= 16 kept in registers; gm8 pre-zeroed)
-// grid (ceil(P/256), ceil(Co/OCH)): the long reduction over Co is split so the launch fills the chip
+// gm8[c,p] = sum_o Pw[o,c] * gmap[o,p]   (c < CIN <= 16 kept in registers)
+// One workgroup = 64 pixels x 16 slices of the long sum over Co (one wave per slice: the row of Pw is wave-uniform);
+// the slices meet in LDS and are added in slice order - no atomics, no zero fill, the same bits on every run.
+// (Rounds 1-3 split Co over the grid and combined the chunks with float atomicAdd: run-to-run differences in the
+// last bit of the GlobalBias gradients, which AdamW's normalisation can turn into visible parameter differences.)
+constexpr int GM8_SLICES = 16;
 template <int CIN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * GM8_SLICES)
 gbias_gm8_kernel(const float* __restrict__ Pw, const float* __restrict__ gmap, float* __restrict__ gm8,
-                 int Cin, int Co, int64_t P, int och) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  const int o0 = blockIdx.y * och, o1 = min(o0 + och, Co);
+                 int Cin, int Co, int64_t P) {
+  __shared__ float part[GM8_SLICES][CIN][64];
+  const int px = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t p = (int64_t)blockIdx.x * 64 + px;
+  const int64_t pc = min(p, P - 1);
+  const int per = (Co + GM8_SLICES - 1) / GM8_SLICES, o0 = slice * per, o1 = min(o0 + per, Co);
   float acc[CIN];
 #pragma unroll
   for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
-  for (int o = o0; o < o1; ++o) {
-    const float g = gmap[(int64_t)o * P + p];
+  int o = o0;
+  for (; o + 8 <= o1; o += 8) {      // eight independent row loads in flight
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = gmap[(int64_t)(o + j) * P + pc];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+        if (c < Cin) acc[c] += Pw[(int64_t)(o + j) * Cin + c] * g[j];
+  }
+  for (; o < o1; ++o) {
+    const float g = gmap[(int64_t)o * P + pc];
 #pragma unroll
     for (int c = 0; c < CIN; ++c)
       if (c < Cin) acc[c] += Pw[(int64_t)o * Cin + c] * g;
   }
 #pragma unroll
-  for (int c = 0; c < CIN; ++c)
-    if (c < Cin) atomicAdd(&gm8[(int64_t)c * P + p], acc[c]);
+  for (int c = 0; c < CIN; ++c) part[slice][c][px] = acc[c];
+  __syncthreads();
+  if (slice < Cin && p < P) {          // wave `slice` finishes channel c = slice
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < GM8_SLICES; ++k) s += part[k][slice][px];
+    gm8[(int64_t)slice * P + p] = s;
+  }
 }
 
 // ------------------------------------------------------------------ global bias map, backward
-// gPw[o,c] = sum_p gmap[o,p] * m8[c,p]; one workgroup per (o,c)
+// gPw[o,c] = sum_p gmap[o,p] * m8[c,p]; one workgroup per output channel o takes all Cin <= CIN bias channels: the
+// row of gmap is read once instead of Cin times (at 128x256, Co = 1024: 809 -> ~140 MB per launch).  Per (o,c) the
+// same sums in the same order as the one-workgroup-per-(o,c) kernel below.
+template <int CIN>
+__global__ void __launch_bounds__(256)
+gbias_gpw_rows_kernel(const float* __restrict__ gmap, const float* __restrict__ m8,
+                      float* __restrict__ gPw, int Cin, int64_t P) {
+  __shared__ float red[4][CIN];
+  const int o = blockIdx.x;
+  float acc[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+  for (int64_t p = threadIdx.x; p < P; p += 256) {
+    const float g = gmap[(int64_t)o * P + p];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+      if (c < Cin) acc[c] += g * m8[(int64_t)c * P + p];
+  }
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    const float s = wave_sum(acc[c]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < Cin) {
+    const int c = threadIdx.x;
+    gPw[(int64_t)o * Cin + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+// (any Cin) one workgroup per (o,c)
 __global__ void __launch_bounds__(256)
 gbias_gpw_kernel(const float* __restrict__ gmap, const float* __restrict__ m8,
                  float* __restrict__ gPw, int Cin, int64_t P) {
@@ -314,6 +368,16 @@ bias_grads_vec4_kernel(const float* __restrict__ dz, float* __restrict__ gmap, f
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// gPw: long rows (P >= 8192: 128x256 and up) read gmap once per output channel; on the small grids the per-(o,c)
+// workgroups win (measured at 32x64: 15 us against 32 us - the 16 wave reductions outweigh 64 KB of re-reads).
+// Same bits either way.
+void launch_gpw(const float* gmap, const float* m8, float* gPw, int Cin, int Co, int64_t P, hipStream_t st) {
+  if (Cin <= 16 && P >= 8192)
+    hipLaunchKernelGGL(gbias_gpw_rows_kernel<16>, dim3(Co), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
+  else
+    hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
+}
+
 }  // namespace
 
 extern "C" int paradis_global_bias_map_fwd(const float* A, const float* U, const float* V,
@@ -355,13 +419,11 @@ extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, co
   const float* gm8_src = gmap;
   if (Pw) {
     PD_REQUIRE(m8 != nullptr && gPw != nullptr, "global_bias_map_bwd: m8/gPw required with projection");
-    hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
+    launch_gpw(gmap, m8, gPw, Cin, Co, P, st);
     // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
     if (Cin <= 16) {
-      if (pd_zero_async(gm8, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
-      const int och = paradis_deterministic() ? Co : 32;   // one chunk: a single add per element, fixed order
-      hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och),
-                         dim3(256), 0, st, Pw, gmap, gm8, Cin, Co, P, och);
+      hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 63) / 64)), dim3(64 * GM8_SLICES), 0, st, Pw, gmap,
+                         gm8, Cin, Co, P);
     } else {
       hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Cin), dim3(256), 0, st, Pw, 1,
                          Cin, gmap, gm8, Cin, Co, P);
@@ -466,14 +528,16 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
   if (!gmap && !gbias) return 0;
   if (P % 4 == 0 && dz_bs % 4 == 0 && aligned16(dz) && (!gmap || aligned16(gmap))) {
     const int P4 = P / 4;
-    int pch = std::max(1, std::min((P4 + 255) / 256, std::max(1, 2048 / C)));
+    // at most TWO chunks per channel: their atomic adds into the zeroed gbias commute exactly (a + b = b + a), so the
+    // result does not depend on which workgroup arrives first
+    int pch = std::max(1, std::min(2, std::min((P4 + 255) / 256, std::max(1, 2048 / C))));
     if (paradis_deterministic()) pch = 1;
     hipLaunchKernelGGL(bias_grads_vec4_kernel, dim3((unsigned)((int64_t)C * pch)), dim3(256), 0, st, dz, gmap,
                        gbias, B, C, P4, dz_bs, pch);
     PD_CHECK_LAUNCH("bias_grads");
     return 0;
   }
-  int pchunks = std::max(1, std::min((P + 255) / 256, std::max(1, 2048 / C)));
+  int pchunks = std::max(1, std::min(2, std::min((P + 255) / 256, std::max(1, 2048 / C))));   // (two adds commute)
   if (paradis_deterministic()) pchunks = 1;   // one workgroup per channel: no atomics between chunks
   hipLaunchKernelGGL(bias_grads_kernel, dim3((unsigned)((int64_t)C * pchunks)), dim3(256), 0, st, dz, gmap,
                      gbias, B, C, P, dz_bs, pchunks);
@@ -520,11 +584,9 @@ extern "C" int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, 
                                             void* stream) {
   PD_REQUIRE(Cin >= 1 && Cin <= 16 && Co >= 1 && P >= 1, "global_bias_proj_bwd: bad shape (Cin <= 16)");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
-  if (pd_zero_async(gm8, (size_t)Cin * P * sizeof(float), st) != hipSuccess) return 2;
-  const int och = paradis_deterministic() ? Co : 32;
-  hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 255) / 256), (Co + och - 1) / och), dim3(256),
-                     0, st, Pw, gmap, gm8, Cin, Co, P, och);
+  launch_gpw(gmap, m8, gPw, Cin, Co, P, st);
+  hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 63) / 64)), dim3(64 * GM8_SLICES), 0, st, Pw, gmap, gm8,
+                     Cin, Co, P);
   PD_CHECK_LAUNCH("global_bias_proj_bwd");
   return 0;
 }

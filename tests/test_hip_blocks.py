@@ -52,7 +52,8 @@ def test_pointwise_gemm(ops, B, Ci, Co, H, W, act):
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,cin,R", [(2, 10, 8, 12, 16, 4, 6), (2, 128, 160, 32, 64, 8, 16),
-                                               (1, 130, 260, 17, 32, 3, 5)])
+                                               (1, 130, 260, 17, 32, 3, 5),
+                                               (1, 32, 64, 64, 128, 8, 6)])    # last: P >= 8192, the row-wise gPw kernel
 @pytest.mark.parametrize("act", [None, "SiLU"])
 def test_pointwise_fused_global_bias_projection(ops, B, Ci, Co, H, W, cin, R, act):
     """GlobalBias with projection applied inside the GEMM epilogue (no [Co,H,W] map in the forward)
