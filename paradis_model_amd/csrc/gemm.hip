@@ -714,16 +714,6 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, 
   l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
 }
 
-// -x splits exactly into -h, -m, -l: with a compile-time sign the negation rides on the source modifiers of the
-// conversion and the first subtraction (no instruction of its own)
-template <bool NEG>
-__device__ __forceinline__ void split8_signed(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  float y[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) y[j] = NEG ? -x[j] : x[j];
-  split8(y, h, m, l);
-}
-
 __device__ __forceinline__ void split8_f16(const float (&x)[8], float s, u32x4& h, u32x4& l) {
   uint32_t hh[4], ll[4];
 #pragma unroll

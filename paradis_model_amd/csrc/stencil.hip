@@ -776,11 +776,10 @@ __device__ __forceinline__ Lerp lerp_index(int o, int in_size, int out_size) {
   return L;
 }
 
-template <bool BWD>
 __global__ void __launch_bounds__(256)
 upsample_lonp_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t planes, int Hc,
                      int Wc, int H, int W) {
-  // forward: src = coarse x, dst = fine y.   backward: src = gy (fine), dst = gx (coarse, zeroed)
+  // src = coarse x, dst = fine y   (the adjoint is the gather kernel below)
   const int64_t per = (int64_t)H * W, total = planes * per;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * 256) {
@@ -791,19 +790,10 @@ upsample_lonp_kernel(const float* __restrict__ src, float* __restrict__ dst, int
     const Lerp lw = lerp_index(w, Wc + 1, W + 1);  // periodic column appended on both sides
     const int c0 = lw.i0 >= Wc ? lw.i0 - Wc : lw.i0, c1 = lw.i1 >= Wc ? lw.i1 - Wc : lw.i1;
     const int64_t base = plane * (int64_t)Hc * Wc;
-    if (!BWD) {
-      const float* xp = src + base;
-      const float top = lw.l0 * xp[(int64_t)lh.i0 * Wc + c0] + lw.l1 * xp[(int64_t)lh.i0 * Wc + c1];
-      const float bot = lw.l0 * xp[(int64_t)lh.i1 * Wc + c0] + lw.l1 * xp[(int64_t)lh.i1 * Wc + c1];
-      dst[idx] = lh.l0 * top + lh.l1 * bot;
-    } else {
-      const float g = src[idx];
-      float* gp = dst + base;
-      atomicAdd(&gp[(int64_t)lh.i0 * Wc + c0], g * lh.l0 * lw.l0);
-      atomicAdd(&gp[(int64_t)lh.i0 * Wc + c1], g * lh.l0 * lw.l1);
-      atomicAdd(&gp[(int64_t)lh.i1 * Wc + c0], g * lh.l1 * lw.l0);
-      atomicAdd(&gp[(int64_t)lh.i1 * Wc + c1], g * lh.l1 * lw.l1);
-    }
+    const float* xp = src + base;
+    const float top = lw.l0 * xp[(int64_t)lh.i0 * Wc + c0] + lw.l1 * xp[(int64_t)lh.i0 * Wc + c1];
+    const float bot = lw.l0 * xp[(int64_t)lh.i1 * Wc + c0] + lw.l1 * xp[(int64_t)lh.i1 * Wc + c1];
+    dst[idx] = lh.l0 * top + lh.l1 * bot;
   }
 }
 
@@ -1048,7 +1038,7 @@ extern "C" int paradis_upsample_lonp_fwd(const float* x, float* y, int64_t plane
   if (planes == 0) return 0;
   const int64_t total = planes * H * W;
   const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
-  hipLaunchKernelGGL(upsample_lonp_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y,
+  hipLaunchKernelGGL(upsample_lonp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y,
                      planes, Hc, Wc, H, W);
   PD_CHECK_LAUNCH("upsample_lonp_fwd");
   return 0;
