@@ -16,30 +16,74 @@ inline int stream_blocks(int64_t n_items) {
 // walked all R ranks in one dependent chain (23 us for 2 M multiply-adds).
 __global__ void __launch_bounds__(256)
 gbias_m8_kernel(const float* __restrict__ A, const float* __restrict__ U, const float* __restrict__ V,
-                float* __restrict__ m8, int Cin, int R, int H, int W, int rows) {
+                float* __restrict__ m8, int Cin, int R, int H, int W) {
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int w = min(blockIdx.x * 64 + tx, W - 1), c = blockIdx.z;
+  const int w = min(blockIdx.x * 64 + tx, W - 1), h = blockIdx.y, c = blockIdx.z;
   const int rq = (R + 3) / 4, r1 = min(R, (q + 1) * rq);
-  // `rows` latitude rows per workgroup (large grids: at 721x1440 one row per workgroup was 132 k workgroups of a few
-  // hundred multiply-adds each - 394 us for 33 MB of output); same arithmetic per output as with rows = 1
-  for (int h = blockIdx.y * rows; h < min(H, (int)(blockIdx.y + 1) * rows); ++h) {
-    // rank loop in batches of independent loads (one dependent load per iteration made this 50 us)
-    float acc = 0.f;
-    int r = q * rq;
-    for (; r + 8 <= r1; r += 8) {
-      float a[8], u[8], v[8];
+  // rank loop in batches of independent loads (one dependent load per iteration made this 50 us)
+  float acc = 0.f;
+  int r = q * rq;
+  for (; r + 8 <= r1; r += 8) {
+    float a[8], u[8], v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { a[j] = A[c * R + r + j]; u[j] = U[(r + j) * H + h]; v[j] = V[(r + j) * W + w]; }
+    for (int j = 0; j < 8; ++j) { a[j] = A[c * R + r + j]; u[j] = U[(r + j) * H + h]; v[j] = V[(r + j) * W + w]; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc += a[j] * u[j] * v[j];
-    }
-    for (; r < r1; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
-    part[q][tx] = acc;
-    __syncthreads();
-    if (q == 0 && blockIdx.x * 64 + tx < W)
-      m8[((int64_t)c * H + h) * W + w] = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
-    __syncthreads();
+    for (int j = 0; j < 8; ++j) acc += a[j] * u[j] * v[j];
+  }
+  for (; r < r1; ++r) acc += A[c * R + r] * U[r * H + h] * V[r * W + w];
+  part[q][tx] = acc;
+  __syncthreads();
+  if (q == 0 && blockIdx.x * 64 + tx < W)
+    m8[((int64_t)c * H + h) * W + w] = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
+}
+
+// Large grids: ROWS latitude rows per workgroup.  The rank-dependent factors a[c,r] u[r,h] of the workgroup's rows are
+// formed once into LDS (wave-uniform broadcast reads afterwards), so the rank loop is one coalesced V load per rank
+// feeding ROWS independent accumulators, eight ranks in flight.  (One row per workgroup, every factor a scalar load
+// in front of its use: 398 us for the 33 MB map of 721x1440.)  Per output the same products (a u) v in the same
+// order as the kernel above.  R <= GM8_MAXR.
+constexpr int GM8_MAXR = 256;
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+gbias_m8_rows_kernel(const float* __restrict__ A, const float* __restrict__ U, const float* __restrict__ V,
+                     float* __restrict__ m8, int Cin, int R, int H, int W) {
+  __shared__ float part[4][ROWS][64];
+  __shared__ float coef[GM8_MAXR][ROWS];
+  const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int w = min(blockIdx.x * 64 + tx, W - 1), h0 = blockIdx.y * ROWS, c = blockIdx.z;
+  for (int i = threadIdx.x; i < R * ROWS; i += 256) {
+    const int r = i / ROWS, j = i - r * ROWS;
+    coef[r][j] = A[c * R + r] * U[r * H + min(h0 + j, H - 1)];
+  }
+  __syncthreads();
+  const int rq = (R + 3) / 4, r1 = min(R, (q + 1) * rq);
+  float acc[ROWS];
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) acc[j] = 0.f;
+  int r = q * rq;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = V[(r + k) * W + w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) acc[j] += coef[r + k][j] * v[k];
+  }
+  for (; r < r1; ++r) {
+    const float v = V[r * W + w];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) acc[j] += coef[r][j] * v;
+  }
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) part[q][j][tx] = acc[j];
+  __syncthreads();
+  if (q == 0 && blockIdx.x * 64 + tx < W) {
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j)
+      if (h0 + j < H)
+        m8[((int64_t)c * H + h0 + j) * W + w] = ((part[0][j][tx] + part[1][j][tx]) + part[2][j][tx]) + part[3][j][tx];
   }
 }
 
@@ -104,37 +148,9 @@ gbias_gm8_kernel(const float* __restrict__ Pw, const float* __restrict__ gmap, f
 }
 
 // ------------------------------------------------------------------ global bias map, backward
-// gPw[o,c] = sum_p gmap[o,p] * m8[c,p]; one workgroup per output channel o takes all Cin <= CIN bias channels: the
-// row of gmap is read once instead of Cin times (at 128x256, Co = 1024: 809 -> ~140 MB per launch).  Per (o,c) the
-// same sums in the same order as the one-workgroup-per-(o,c) kernel below.
-template <int CIN>
-__global__ void __launch_bounds__(256)
-gbias_gpw_rows_kernel(const float* __restrict__ gmap, const float* __restrict__ m8,
-                      float* __restrict__ gPw, int Cin, int64_t P) {
-  __shared__ float red[4][CIN];
-  const int o = blockIdx.x;
-  float acc[CIN];
-#pragma unroll
-  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
-  for (int64_t p = threadIdx.x; p < P; p += 256) {
-    const float g = gmap[(int64_t)o * P + p];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c)
-      if (c < Cin) acc[c] += g * m8[(int64_t)c * P + p];
-  }
-#pragma unroll
-  for (int c = 0; c < CIN; ++c) {
-    const float s = wave_sum(acc[c]);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < Cin) {
-    const int c = threadIdx.x;
-    gPw[(int64_t)o * Cin + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-  }
-}
-
-// (any Cin) one workgroup per (o,c)
+// gPw[o,c] = sum_p gmap[o,p] * m8[c,p]; one workgroup per (o,c).  (A one-workgroup-per-o form that reads the row of
+// gmap once - 109 instead of 809 MB at 128x256 - was measured in round 4: 383 us against 180 us, 32 against 15 us at
+// 32x64: 1024 workgroups walking 128 dependent iterations lose more than the re-reads through L2 cost.)
 __global__ void __launch_bounds__(256)
 gbias_gpw_kernel(const float* __restrict__ gmap, const float* __restrict__ m8,
                  float* __restrict__ gPw, int Cin, int64_t P) {
@@ -368,14 +384,8 @@ bias_grads_vec4_kernel(const float* __restrict__ dz, float* __restrict__ gmap, f
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// gPw: long rows (P >= 8192: 128x256 and up) read gmap once per output channel; on the small grids the per-(o,c)
-// workgroups win (measured at 32x64: 15 us against 32 us - the 16 wave reductions outweigh 64 KB of re-reads).
-// Same bits either way.
 void launch_gpw(const float* gmap, const float* m8, float* gPw, int Cin, int Co, int64_t P, hipStream_t st) {
-  if (Cin <= 16 && P >= 8192)
-    hipLaunchKernelGGL(gbias_gpw_rows_kernel<16>, dim3(Co), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
-  else
-    hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
+  hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
 }
 
 }  // namespace
@@ -389,9 +399,11 @@ extern "C" int paradis_global_bias_map_fwd(const float* A, const float* U, const
   const int64_t P = (int64_t)H * W;
   float* m8_dst = Pw ? m8 : map;
   PD_REQUIRE(H <= 65535 && Cin <= 65535 && Co <= 65535, "global_bias_map_fwd: grid too large");
-  const int m8_rows = (int64_t)H * W >= (1 << 17) ? 8 : 1;
-  hipLaunchKernelGGL(gbias_m8_kernel, dim3((W + 63) / 64, (H + m8_rows - 1) / m8_rows, Cin), dim3(256), 0, st, A, U, V,
-                     m8_dst, Cin, R, H, W, m8_rows);
+  if ((int64_t)H * W >= (1 << 17) && R <= GM8_MAXR)
+    hipLaunchKernelGGL(gbias_m8_rows_kernel<8>, dim3((W + 63) / 64, (H + 7) / 8, Cin), dim3(256), 0, st, A, U, V, m8_dst,
+                       Cin, R, H, W);
+  else
+    hipLaunchKernelGGL(gbias_m8_kernel, dim3((W + 63) / 64, H, Cin), dim3(256), 0, st, A, U, V, m8_dst, Cin, R, H, W);
   if (Pw)
     hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Co), dim3(256), 0, st, Pw, Cin, 1,
                        m8, map, Co, Cin, P);
