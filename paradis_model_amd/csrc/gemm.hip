@@ -1641,7 +1641,7 @@ static int pw_gemm_fwd_impl(const float* Wt, const float* WtT, const void* Wspli
                             int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
                             int64_t y_bs, int act, void* stream) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
-  PD_REQUIRE(gate == nullptr || res != nullptr, "pw_gemm_fwd: a gate needs the tensor it blends with (res)");
+  PD_REQUIRE(gate == nullptr || res != nullptr || B == 0, "pw_gemm_fwd: a gate needs the tensor it blends with (res)");
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
   PD_REQUIRE(known_scheme(scheme) && (Wsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
              "pw_gemm_fwd: scheme %d needs %s weight image", scheme, scheme ? "a" : "no");
@@ -1696,7 +1696,7 @@ extern "C" int paradis_pw_gemm_fwd_gated(const float* Wt, const float* WtT, cons
                                          const float* pwT, int cin, const float* res, const float* gate, float* Y,
                                          float* zpre, int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
                                          int64_t y_bs, int act, void* stream) {
-  PD_REQUIRE(gate != nullptr && res != nullptr, "pw_gemm_fwd_gated: gate [M] and res required");
+  PD_REQUIRE(gate != nullptr && (res != nullptr || B == 0), "pw_gemm_fwd_gated: gate [M] and res required");
   return pw_gemm_fwd_impl(Wt, WtT, Wsplit, scheme, x_amax, X, bias, map, m8, pwT, cin, res, gate, Y, zpre, B, M, K, N,
                           x_bs, res_bs, y_bs, act, stream);
 }

@@ -638,8 +638,8 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
                                         const float* b, float* y, float* mean, float* rstd, int B,
                                         int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
   if (int e = check_norm("channel_norm_fwd", B, C1, C2, P)) return e;
+  if (B == 0) return 0;       // (an empty batch has no x2 pointer either)
   PD_REQUIRE(C2 == 0 || x2 != nullptr, "channel_norm_fwd: x2 missing");
-  if (B == 0) return 0;
   CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
   const int C = C1 + C2;
   hipStream_t st = (hipStream_t)stream;

@@ -936,7 +936,7 @@ extern "C" int paradis_dwconv_geo_dgrad(const float* gy, const float* w, float* 
 // gx = dgrad(gy) + addend (addend [B,C,H,W], not aliasing gx)
 extern "C" int paradis_dwconv_geo_dgrad_add(const float* gy, const float* w, const float* addend, float* gx, int B,
                                             int C, int H, int W, int k, void* stream) {
-  PD_REQUIRE(addend != nullptr && addend != gx, "dwconv_geo_dgrad_add: addend must be a tensor other than gx");
+  PD_REQUIRE(B == 0 || (addend != nullptr && addend != gx), "dwconv_geo_dgrad_add: addend must be a tensor other than gx");
   return dwconv_geo_dgrad_launch(gy, w, addend, gx, B, C, H, W, k, stream);
 }
 

@@ -465,3 +465,40 @@ def test_gmblock_golden():
     _cmp(x.grad, rec["gx"], BWD, "gx")
     for n, p in blk.named_parameters():
         _cmp(p.grad, rec["grads"][n], 2e-4, n)
+
+
+@pytest.mark.parametrize("scheme", ["exact", "bf16x3", "f16x2"])
+def test_empty_batch_block_ops(ops, scheme):
+    """B = 0 through the block-level ops on every GEMM arithmetic: empty outputs, ZERO (not uninitialised) parameter
+    gradients."""
+    sc = {"exact": ops.GEMM_EXACT, "bf16x3": ops.GEMM_BF16X3, "f16x2": ops.GEMM_F16X2}[scheme]
+    H, W, Ci, Co = 16, 32, 12, 20
+    x = torch.zeros(0, Ci, H, W, device="cuda", requires_grad=True)
+    w, b = _dev(seeded(1, Co, Ci, 1, 1)), _dev(seeded(2, Co))
+    res = torch.zeros(0, Co, H, W, device="cuda", requires_grad=True)
+    gate = _dev(seeded(3, Co))
+    y = ops.pointwise(x, w, b, residual=res, act="SiLU", scheme=sc, gate=gate)
+    assert tuple(y.shape) == (0, Co, H, W)
+    y.sum().backward()
+    for t in (w, b, gate):
+        assert t.grad is not None and float(t.grad.abs().max()) == 0.0
+    assert tuple(x.grad.shape) == (0, Ci, H, W) and tuple(res.grad.shape) == (0, Co, H, W)
+    # depthwise stencil (+ skip), ChannelNorm over a virtual concat, blend, resampling
+    dw = _dev(seeded(4, Ci, 1, 5, 5))
+    x2 = torch.zeros(0, Ci, H, W, device="cuda", requires_grad=True)
+    yd, skip = ops.dwconv_geo_skip(x2, dw, None)
+    (yd.sum() + skip.sum()).backward()
+    assert float(dw.grad.abs().max()) == 0.0 and tuple(x2.grad.shape) == (0, Ci, H, W)
+    nw, nb = _dev(seeded(5, Ci + 4)), _dev(seeded(6, Ci + 4))
+    x3 = torch.zeros(0, Ci, H, W, device="cuda", requires_grad=True)
+    xe = torch.zeros(0, 4, H, W, device="cuda", requires_grad=True)
+    yn = ops.channel_norm(x3, nw, nb, x_extra=xe)
+    yn.sum().backward()
+    assert float(nw.grad.abs().max()) == 0.0 and float(nb.grad.abs().max()) == 0.0
+    al = _dev(seeded(7, Ci))
+    h0 = torch.zeros(0, Ci, H, W, device="cuda", requires_grad=True)
+    yb = ops.gated_blend(h0, torch.zeros(0, Ci, H, W, device="cuda", requires_grad=True), al)
+    yb.sum().backward()
+    assert float(al.grad.abs().max()) == 0.0
+    assert tuple(ops.avgpool_geo(h0, 2).shape)[:2] == (0, Ci)
+    assert tuple(ops.upsample_lonp(h0, 2 * H - 1, 2 * W).shape) == (0, Ci, 2 * H - 1, 2 * W)

@@ -277,3 +277,29 @@ def test_forward_under_inference_mode(gemm, monkeypatch):
         y = ops.pointwise(x, w)
     assert torch.equal(got, want) and torch.equal(got2, want)
     assert y.shape == (2, w.shape[0], 16, 32) and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("H,W", [(16, 32), (32, 64)])
+def test_empty_batch_forward_and_backward(H, W):
+    """B = 0 (the last, empty shard of an uneven distributed sampler; a filtered-out batch): every op returns an empty
+    tensor of the right shape without launching on zero-sized grids, the backward gives every parameter a zero
+    gradient, and a training step on it leaves the library usable (the next real step matches a fresh run)."""
+    cfg = reduced_config()
+    _, lg, og = make_grid(H, W, False)
+    model = _build(cfg, lg, og)
+    x0 = torch.zeros(0, 186, H, W, device="cuda", requires_grad=True)
+    y0 = model(x0)
+    assert tuple(y0.shape) == (0, 97, H, W)
+    y0.sum().backward()
+    assert tuple(x0.grad.shape) == (0, 186, H, W)
+    for n, p in model.named_parameters():
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+    # the library still works afterwards, and the empty step has changed nothing
+    x = seeded(3, 2, 186, H, W).cuda()
+    model.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        got = model(x)
+    twin = _build(cfg, lg, og)
+    with torch.no_grad():
+        want = twin(x)
+    assert torch.equal(got, want)

@@ -174,3 +174,34 @@ def test_advect_nan_cotangent_propagates(ops, tiled):
         assert not bool(torch.isfinite(gf[0, 1]).any()) or bool(torch.isnan(gf[0, 1]).any())
         assert bool(torch.isnan(gf[0, 1]).any()), "NaN cotangent lost"
         assert bool(torch.isfinite(gf[0, 0]).all()), "other planes must stay finite"
+
+
+@pytest.mark.parametrize("H,W", [(12, 16), (32, 64), (128, 256), (181, 360)])
+@pytest.mark.parametrize("mode", ["bicubic", "bilinear"])
+def test_empty_batch_through_every_advection_schedule(ops, H, W, mode):
+    """B = 0 on every schedule (generic, W = 64 rows, ring strips + full circle, strips with float flush): empty outputs
+    of the right shape, empty gradients, no launch on an empty grid; pad and its adjoint likewise."""
+    _, lg, og = make_grid(H, W, False)
+    geo = ops.AdvectGeometry(lg, og)
+    K = 3
+    f = torch.zeros(0, K, H, W, device="cuda", requires_grad=True)
+    u = torch.zeros(0, K, H, W, device="cuda", requires_grad=True)
+    v = torch.zeros(0, K, H, W, device="cuda", requires_grad=True)
+    y = ops.sl_advect(f, u, v, geo, 0.196887, mode)
+    assert tuple(y.shape) == (0, K, H, W)
+    y.sum().backward()
+    assert tuple(f.grad.shape) == tuple(u.grad.shape) == tuple(v.grad.shape) == (0, K, H, W)
+    vel = torch.zeros(0, 2 * K, H, W, device="cuda", requires_grad=True)
+    f2 = torch.zeros(0, K, H, W, device="cuda", requires_grad=True)
+    y2 = ops.sl_advect_vel(f2, vel, geo, 0.196887, mode)
+    y2.sum().backward()
+    assert tuple(vel.grad.shape) == (0, 2 * K, H, W)
+    x = torch.zeros(0, 2, H, W, device="cuda", requires_grad=True)
+    yp = ops.geocyclic_pad(x, 2)
+    assert tuple(yp.shape) == (0, 2, H + 4, W + 4)
+    yp.sum().backward()
+    assert tuple(x.grad.shape) == (0, 2, H, W)
+    # and the library is in a sane state afterwards
+    g = seeded(1, 1, K, H, W).cuda()
+    z = ops.sl_advect(g, torch.zeros_like(g), torch.zeros_like(g), geo, 0.196887, mode)
+    assert bool(torch.isfinite(z).all())
