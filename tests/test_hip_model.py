@@ -213,9 +213,10 @@ def test_default_config_backward_vs_oracle():
     print("default-config worst grad error vs fp64 (gpu, cpu32)", worst)
 
 
-@pytest.mark.parametrize("nlat,nlon,poles", [(128, 256, False), (65, 130, True)])
+@pytest.mark.parametrize("nlat,nlon,poles", [(128, 256, False), (65, 130, True), (9, 30, True), (20, 50, False)])
 def test_reduced_model_on_large_grids_vs_oracle(nlat, nlon, poles):
-    """The large-plane code paths inside the model - tiled advection windows (forward and backward),
+    """(The last two: ragged small grids - W not a multiple of 4, so every 16-byte staging path falls back; an odd
+    latitude count with pole rows.)  The large-plane code paths inside the model - tiled advection windows (forward and backward),
     GlobalBias projection inside the GEMM epilogue (planes >= 8192 points), multi-tile stencils -
     against the CPU oracle, forward and every parameter gradient.  Gradients: the velocity path
     amplifies fp32 coordinate rounding with the grid size (SURVEY 8c iii), hence 2e-3 there."""
