@@ -176,6 +176,118 @@ def cpu_baseline(cfg, nlat, nlon, poles, batch, steps_timed=2):
                                       f"{nlat}x{nlon} S=1 workload (1 warm-up), {dt:.2f} s/step"}
 
 
+def _rooflines(s, elapsed_s, gemm):
+    """roofline records of one timed region from the LaunchProfiler summary `s` (GEMMs: algorithmic FLOP against the
+    dense bf16 peak / 6 resp. the f32 MFMA peak; advection: 16 / 28 algorithmic bytes per gather point against HBM)"""
+    out = {}
+    gem = [s[k] for k in ("pw_gemm_fwd", "pw_gemm_dgrad", "pw_gemm_wgrad") if k in s]
+    if gem:
+        flops = sum(g["work"] for g in gem)
+        ms = sum(g["ms"] for g in gem)
+        n = sum(g["launches"] for g in gem)
+        ach = flops / (ms * 1e-3) / 1e12
+        products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS}.get(gemm)
+        if gemm == "bf16x3":
+            kname = ("pw_gemm_split_wide_kernel<2, 3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
+                     "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
+            peak = MFMA_BF16_PEAK_TFLOPS / products
+        elif gemm == "f16x2":
+            kname = ("pw_gemm_split_wide_kernel<2>/pw_gemm_wgrad_split_kernel<2> (fwd+dgrad+wgrad; fp32 operands as "
+                     "2 f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)")
+            peak = MFMA_BF16_PEAK_TFLOPS / products
+        else:
+            kname = "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)"
+            peak = MFMA_F32_PEAK_TFLOPS
+        gemm_traffic, gemm_src = pmc_traffic("pw_gemm")
+        out["roofline"] = {"kernel": kname,
+                           "bound": "mfma", "achieved": ach, "peak": peak,
+                           "unit": "TFLOP/s", "frac": ach / peak,
+                           "flops": "algorithmic 2*M*N*K per GEMM (fp32-equivalent)"
+                                    + (f"; executed 16-bit MFMA rate = {products}x achieved, peak = 2500/{products}"
+                                       if products else ""),
+                           "traffic": gemm_traffic, "traffic_source": gemm_src,
+                           "launches": n, "avg_launch_ms": ms / n,
+                           "flops_per_launch": flops / n,
+                           "share_of_step": ms / (1e3 * elapsed_s),
+                           "mfma_busy_pmc": pmc_mfma_busy()}
+    for key, name in (("sl_advect_fwd", "roofline_advect_fwd"), ("sl_advect_bwd", "roofline_advect_bwd")):
+        if key in s:
+            r = s[key]
+            ach = r["work"] / (r["ms"] * 1e-3) / 1e9
+            tr, tr_src = pmc_traffic(key)
+            out[name] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
+                         "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
+                         "bytes_per_launch": r["work"] / r["launches"]}
+    return out
+
+
+def other_config_leg(name, n_steps, dev, gemm):
+    """One bounded leg of another BASELINE config in the same process (verdict r4 item 2): fresh default model on that
+    grid, one warm-up step, `n_steps` timed steps (training step, or the inference forward for the 0.25-degree config)
+    with the launch events on, its own peak memory and advection / GEMM rooflines; PMC traffic is read back from the
+    committed profile of THAT workload (profiles/*_cfg{2,3,4}_traffic.json)."""
+    global WORKLOAD
+    import gc
+    from paradis_model_amd import _lib
+    from paradis_model_amd.config import default_config, feature_layout, stub_datamodule
+    from paradis_model_amd.harness import TrainStep, assemble_model_input, make_grids, synthetic_batch
+    from paradis_model_amd.loss import build_loss
+    from paradis_model_amd.model import Paradis
+
+    nlat, nlon, poles, B, S = WORKLOADS[name]
+    fwd_only = "_fwd_" in name
+    keep = WORKLOAD
+    WORKLOAD = name
+    try:
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        cfg = default_config()
+        lay = feature_layout(cfg)
+        lat_deg, lg, og = make_grids(nlat, nlon, poles)
+        torch.manual_seed(cfg.init.seed)
+        model = Paradis(stub_datamodule(cfg), cfg, lg, og).to(dev)
+        batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234, device=dev)
+        if fwd_only:
+            mi = assemble_model_input(batch[0], batch[2].permute(0, 1, 4, 2, 3)[:, 0].unsqueeze(1),
+                                      batch[3][:, :1].permute(0, 1, 4, 2, 3))
+
+            def step(_b):
+                with torch.no_grad():
+                    return model(mi).mean()
+        else:
+            step = TrainStep(model, build_loss(cfg, lat_deg).to(dev), cfg, num_common=lay.num_common_features,
+                             n_inputs=cfg.dataset.n_time_inputs)
+        step(batch)                       # warm-up (allocator pools, weight images)
+        torch.cuda.synchronize()
+        prof = _lib.LaunchProfiler()
+        _lib.PROFILER = prof
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            loss = step(batch)
+        torch.cuda.synchronize()
+        e = time.perf_counter() - t0
+        _lib.PROFILER = None
+        rec = {"value": B * n_steps / e, "unit": "samples/s", "ms_per_step": 1e3 * e / n_steps, "steps": n_steps,
+               "warmup": 1, "grid": f"{nlat}x{nlon}", "rollout_steps": S, "per_gpu_batch": B,
+               "mode": "forward-only" if fwd_only else "train", "gemm_arithmetic": gemm,
+               "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9, "final_loss": float(loss)}
+        rec.update(_rooflines(prof.summary(), e, gemm))
+        return rec
+    except Exception as exc:              # never lose the headline line over an extra leg
+        _lib.PROFILER = None
+        return {"error": repr(exc)[:300]}
+    finally:
+        WORKLOAD = keep
+        model = batch = step = prof = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+OTHER_CONFIGS = (("era5_5.625deg_32x64_S6_B32", 2), ("era5_1.4deg_128x256_S1_B8", 3), ("era5_0.25deg_721x1440_fwd_B1", 3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +312,9 @@ def main():
                          "not reference-width arithmetic, labelled as such in the output")
     ap.add_argument("--no-extra-legs", "--no-exact-leg", dest="no_extra_legs", action="store_true",
                     help="skip the extra timed loops (exact_f32_gemm, f16x2_emulated)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the bounded legs of the other BASELINE configs (other_configs: S = 6 rollout, 128x256 B = 8, "
+                         "721x1440 forward)")
     ap.add_argument("--bucket-mb", type=int, default=32, help="DDP gradient bucket size (N>1)")
     ap.add_argument("--static-graph", action="store_true", help="DDP static_graph=True (N>1)")
     ap.add_argument("--graph", action="store_true",
@@ -296,6 +411,8 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.PROFILER = None
     elapsed = max_over_ranks(elapsed, dev)
+    peak_headline_gb = torch.cuda.max_memory_allocated(dev) / 1e9      # (before the extra legs allocate theirs)
+    final_loss = float(loss)
 
     # The same K steps in the other two arithmetics, timed the same way (>= 5 warm-up steps each) and reported
     # beside the headline under their own names.
@@ -439,51 +556,21 @@ def main():
                    "mode": "forward-only" if args.forward_only else "train",
                    "hip_graph": bool(args.graph),
                    "activation_checkpointing": bool(args.checkpoint),
-                   "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
-                   "final_loss": float(loss)},
+                   "peak_hbm_gb": peak_headline_gb,
+                   "final_loss": final_loss},
     }
     if prof is not None and rank == 0:
-        s = prof.summary()
-        gem = [s[k] for k in ("pw_gemm_fwd", "pw_gemm_dgrad", "pw_gemm_wgrad") if k in s]
-        if gem:
-            flops = sum(g["work"] for g in gem)
-            ms = sum(g["ms"] for g in gem)
-            n = sum(g["launches"] for g in gem)
-            ach = flops / (ms * 1e-3) / 1e12
-            products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS}.get(args.gemm)
-            if args.gemm == "bf16x3":
-                kname = ("pw_gemm_split_wide_kernel<2, 3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
-                         "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
-                peak = MFMA_BF16_PEAK_TFLOPS / products
-            elif args.gemm == "f16x2":
-                kname = ("pw_gemm_split_wide_kernel<2>/pw_gemm_wgrad_split_kernel<2> (fwd+dgrad+wgrad; fp32 operands as "
-                         "2 f16 terms, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate)")
-                peak = MFMA_BF16_PEAK_TFLOPS / products
-            else:
-                kname = "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)"
-                peak = MFMA_F32_PEAK_TFLOPS
-            gemm_traffic, gemm_src = pmc_traffic("pw_gemm")
-            out["roofline"] = {"kernel": kname,
-                               "bound": "mfma", "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak,
-                               "flops": "algorithmic 2*M*N*K per GEMM (fp32-equivalent)"
-                                        + (f"; executed 16-bit MFMA rate = {products}x achieved, peak = 2500/{products}"
-                                           if products else ""),
-                               "traffic": gemm_traffic, "traffic_source": gemm_src,
-                               "launches": n, "avg_launch_ms": ms / n,
-                               "flops_per_launch": flops / n,
-                               "share_of_step": ms / (1e3 * elapsed),
-                               "mfma_busy_pmc": pmc_mfma_busy()}
-        for key, name in (("sl_advect_fwd", "roofline_advect_fwd"), ("sl_advect_bwd", "roofline_advect_bwd")):
-            if key in s:
-                r = s[key]
-                ach = r["work"] / (r["ms"] * 1e-3) / 1e9
-                tr, tr_src = pmc_traffic(key)
-                out[name] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
-                             "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
-                             "bytes_per_launch": r["work"] / r["launches"]}
+        out.update(_rooflines(prof.summary(), elapsed, args.gemm))
     out.update(legs)
+    # The other BASELINE configs that fit one GPU, as bounded legs of the same process (each frees memory first):
+    # configs[2] (S = 6 rollout), configs[3]'s per-GPU shape (128x256, B = 8) and configs[4] (0.25-degree forward).
+    if (rank == 0 and world == 1 and not args.no_extra_legs and not args.no_other_configs and not args.graph
+            and args.workload == "era5_5.625deg_32x64_S1_B32" and not args.forward_only and args.optimizer == "adamw"):
+        import gc
+        del step, ddp, model, batch, loss_fn
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["other_configs"] = {name: other_config_leg(name, n, dev, args.gemm) for name, n in OTHER_CONFIGS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=8)
     if world > 1:

@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 8: paradis_pw_gemm_wgrad_slabs (query only; nothing changed); 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -180,6 +180,9 @@ int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme,
  * into the GEMM as row sums of its A operand); workspace >= paradis_pw_gemm_wgrad_ws_bytes;
  * a split scheme is used when N % 16 == 0 and the rows are 16-B aligned (the exact kernels run otherwise) */
 size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N);
+/* number of K-range slabs of the split weight-gradient kernel for this shape: 1 or an even number (alternate slabs
+ * accumulate with opposite sign; the bf16 MFMA's accumulator-alignment offset cancels in the slab sum).  (ABI 8) */
+int paradis_pw_gemm_wgrad_slabs(int B, int M, int K, int N);
 int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias,
                           int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
                           const uint32_t* dy_amax, const uint32_t* x_amax /* PARADIS_GEMM_F16X2 only */,

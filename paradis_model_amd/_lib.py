@@ -61,6 +61,7 @@ SIGNATURES = {
     "paradis_transpose": (I, [P, P, I, I, P]),
     "paradis_pw_gemm_dgrad": (I, [P, P, I, P, P, P, P, P, I, I, I, I, L, L, L, L, I, P]),
     "paradis_pw_gemm_wgrad_ws_bytes": (S, [I, I, I, I]),
+    "paradis_pw_gemm_wgrad_slabs": (I, [I, I, I, I]),
     "paradis_pw_gemm_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, I, P, P, P, P]),
     "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
     "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),

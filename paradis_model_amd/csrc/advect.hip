@@ -2210,7 +2210,8 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
         const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
         float gix = 0.f, giy = 0.f;
-        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane);
+        // (the sample coordinates ride along, as in the forward: the fix-up evaluates the gradient where the forward sampled)
+        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane, (size_t)H * STRIP_W, ix, iy);
         if (tl.active && fast) {
           {
             float wx[NT], wy[NT], dwx[NT], dwy[NT];
@@ -2431,7 +2432,8 @@ sl_advect_bwd_circle(const float* __restrict__ gout, const float* __restrict__ f
         const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
         float gix = 0.f, giy = 0.f;
-        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane);
+        // (the sample coordinates ride along, as in the forward: the fix-up evaluates the gradient where the forward sampled)
+        strip_defer(!fast && tl.active, (unsigned)(y * W + tl.cbase) + tl.lx, q, &qcount, lane, (size_t)strips * H * STRIP_W, ix, iy);   // (one list per plane: three lists of strips x H x 128 entries)
         if (tl.active && fast) {
           float wx[NT], wy[NT], dwx[NT], dwy[NT];
           Interp<MODE>::weights(tx, wx); Interp<MODE>::weights(ty, wy);
@@ -2531,7 +2533,9 @@ sl_advect_bwd_strip_fixup(const float* __restrict__ gout, const float* __restric
                           const float* __restrict__ lon, const float* __restrict__ fmeans, const float* __restrict__ gmeans,
                           int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs, int64_t gf_bs, int64_t guv_bs,
                           int strips, unsigned long long* __restrict__ gacc, const unsigned* __restrict__ pmax,
-                          const unsigned* __restrict__ queue, const unsigned* __restrict__ counts) {
+                          const unsigned* __restrict__ queue, const unsigned* __restrict__ counts, int lists_per_plane) {
+  // lists_per_plane: `strips` (one list per strip, capacity H x 128) or 1 (the full-circle kernel: one list per plane
+  // at the plane's first strip, capacity strips x H x 128)
   const int H = g.H, W = g.W, p = g.p, P = H * W;
   const unsigned n = counts[blockIdx.x];
   if (n == 0) return;
@@ -2545,7 +2549,10 @@ sl_advect_bwd_strip_fixup(const float* __restrict__ gout, const float* __restric
   float* GU = gu + (int64_t)b * guv_bs + (int64_t)k * P;
   float* GV = gv + (int64_t)b * guv_bs + (int64_t)k * P;
   unsigned long long* GA = DET ? gacc + (int64_t)plane * P : nullptr;
-  const unsigned* q = queue + (size_t)blockIdx.x * 3 * (size_t)(H * STRIP_W);
+  const size_t qcap1 = (size_t)H * STRIP_W, qcap = lists_per_plane == 1 ? qcap1 * strips : qcap1;
+  const unsigned* q = queue + (size_t)blockIdx.x * 3 * qcap1;
+  const float* qx = reinterpret_cast<const float*>(q) + qcap;
+  const float* qy = qx + qcap;
   const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
   const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
   float scale = 0.f;
@@ -2557,9 +2564,14 @@ sl_advect_bwd_strip_fixup(const float* __restrict__ gout, const float* __restric
   for (unsigned i = threadIdx.x; i < n; i += 256) {
     const unsigned idx = q[i];
     const float sa = sin_lat[idx], ca = cos_lat[idx];
-    float ix, iy, gix, giy;
+    float ix_l, iy_l, gix, giy;
     DepState st;
-    departure_lane(U[idx], V[idx], sa, ca, lon_cells(lon[idx], g), g, ix, iy, &st);      // (no wave-uniform branches)
+    // the chain-rule state of the departure map, per lane (no wave-uniform branches: a list's order, and with it a
+    // point's wave mates, varies from run to run).  The tap block and the weights are those of the coordinates the
+    // strip kernel computed, decided on and stored - the ones the forward sampled at (departure_lane's own
+    // coordinates differ from them in the last bits, which a polar point amplified to 2e-4 of its velocity gradient)
+    departure_lane(U[idx], V[idx], sa, ca, lon_cells(lon[idx], g), g, ix_l, iy_l, &st);
+    const float ix = qx[i], iy = qy[i];
     const float gval = idx < (unsigned)W ? gm0 : (idx >= last ? gm1 : GO[idx]);
     scatter_global<MODE, DET>(F, GF, GA, ix, iy, H, W, p, m0, m1, gval, scale, gix, giy);
     float guv, gvv;
@@ -2911,7 +2923,12 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
         (reinterpret_cast<uintptr_t>(pmax + planes) + 15) & ~(uintptr_t)15);
     hipLaunchKernelGGL(plane_absmax_kernel, dim3(planes), dim3(256), 0, st, gout, pmax, K, P, go_bs);
   }
-  const bool circle = separable(flags, lat_cells) && strip_ok(W, flags) && W <= 256 && !gacc && !(flags & PARADIS_ADVECT_STRIPS);
+  // full-circle ring only where both of its variants fit LDS (H > 160 takes the 64-row ring: W beyond ~200 columns then
+  // does not fit and the 128-column strips run instead, with their zero fill)
+  const size_t circle_lds = ((size_t)strip_ring_rows(H) * (W + NT) * 3 + 8) * sizeof(float);
+  const size_t circle_lds_wide = ((size_t)64 * (W + NT) * 2 + 8) * sizeof(float);
+  const bool circle = separable(flags, lat_cells) && strip_ok(W, flags) && W <= 256 && !gacc && !(flags & PARADIS_ADVECT_STRIPS) &&
+                      circle_lds <= (size_t)STRIP_LDS_MAX && circle_lds_wide <= (size_t)STRIP_LDS_MAX;
   if (!circle && pd_zero_async(gacc ? (void*)gacc : (void*)gfield, (size_t)planes * P * (gacc ? 8 : 4), st) != hipSuccess) {
     paradis_set_error("sl_advect_bwd: memset failed");
     return 2;
@@ -2949,9 +2966,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
     // Two variants, chosen per plane on the device (adv_dy_class_kernel): field + sums in a ring of strip_ring_rows(H)
     // rows, or - displacements of many rows - the sums alone in a ring of 64 rows with the field taps from L2.
     const int ring = strip_ring_rows(H), strips = (W + STRIP_W - 1) / STRIP_W;
-    const size_t slds = ((size_t)ring * (W + NT) * 3 + 8) * sizeof(float);
-    const size_t slds_wide = ((size_t)64 * (W + NT) * 2 + 8) * sizeof(float);
-    PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX && slds_wide <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
+    const size_t slds = circle_lds, slds_wide = circle_lds_wide;
     static PerDeviceOnce once_circle;
     if (once_circle.first()) {
 #define RESERVE_CIRCLE(M, R_, WPR_, F_) reserve_lds(&sl_advect_bwd_circle<M, R_, WPR_, F_>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX)
@@ -2989,7 +3004,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
                          gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans,               \
                          (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips,                        \
                          (unsigned long long*)nullptr, (const unsigned*)nullptr, (const unsigned*)queue,               \
-                         (const unsigned*)counts);                                                                     \
+                         (const unsigned*)counts, 1);                                                                  \
     } while (0)
     if (cubic) LAUNCH_CIRCLE_M(PARADIS_INTERP_BICUBIC); else LAUNCH_CIRCLE_M(PARADIS_INTERP_BILINEAR);
 #undef LAUNCH_CIRCLE_M
@@ -3022,7 +3037,7 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
       hipLaunchKernelGGL((sl_advect_bwd_strip_fixup<M, D>), dim3((unsigned)(planes * strips)), dim3(256), 0, st, gout, \
                          field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, \
                          K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips, gacc, (const unsigned*)pmax,                 \
-                         (const unsigned*)queue, (const unsigned*)counts);                                            \
+                         (const unsigned*)queue, (const unsigned*)counts, strips);                                    \
     } while (0)
     unsigned* counts = nullptr;
     unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);

@@ -1428,8 +1428,11 @@ bool wgrad_dma_ok(int N, int64_t dy_bs, int64_t x_bs, const void* a, const void*
 int wgrad_splits(int B, int M, int K, int N, int bk, int wg_per_cu) {
   const int tiles = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
   const int64_t total_kt = (int64_t)B * ((N + bk - 1) / bk);
-  int s = 256 * wg_per_cu / tiles;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(s, total_kt));
+  int s = (int)std::max<int64_t>(1, std::min<int64_t>(256 * wg_per_cu / tiles, total_kt));
+  // the split kernels accumulate alternate slabs with opposite sign so that the bf16 MFMA's alignment offset cancels
+  // in the slab sum ("sign checkerboard"): that takes an even number of slabs (1536 x 384: 21 -> 20; round 5)
+  if (s > 1) s &= ~1;
+  return s;
 }
 int wgrad_dma_wgs() { return g_wgrad_dma_stages == 2 ? 4 : 3; }
 
@@ -1785,6 +1788,12 @@ extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
   const int S = std::max({wgrad_splits(b, M, K, N, DBK, wgrad_dma_wgs()), wgrad_splits(b, M, K, N, g_bk, g_wg_per_cu),
                           wgrad_splits(b, M, K, N, SBK, 3)});
   return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256;   // slabs + row-sum partials
+}
+
+// K-range slabs the split weight-gradient kernel runs for this shape (1, or an even number: see wgrad_splits)
+extern "C" int paradis_pw_gemm_wgrad_slabs(int B, int M, int K, int N) {
+  if (M < 1 || K < 1 || N < 1) return 0;
+  return wgrad_splits(std::max(B, 1), M, K, N, SBK, 3);
 }
 
 extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,

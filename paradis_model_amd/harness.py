@@ -169,7 +169,7 @@ class GraphedTrainStep:
     notes for DDP): the wrapper constructed on a side stream, at least 11 eager DDP iterations before the capture (the
     Reducer rebuilds its buckets after the first one and settles its bookkeeping over the next ones), and no
     asynchronous NCCL error handling thread touching the captured work (TORCH_NCCL_ASYNC_ERROR_HANDLING=0, set by
-    ``init_distributed``)."""
+    ``init_distributed(capturable=True)``)."""
 
     DDP_WARMUP = 11
 
@@ -199,6 +199,7 @@ class GraphedTrainStep:
         # the capture ran the Python side of one step (host step counts advanced) without executing it on the
         # device: bring the device-side count of the captured tick back in line on first replay
         self._first = True
+        self._replayed = torch.cuda.Event()
 
     def __call__(self, batch):
         for dst, src in zip(self.static_batch, batch):
@@ -209,6 +210,7 @@ class GraphedTrainStep:
         else:
             self.step.opt.note_replayed()
         self.graph.replay()
+        self._replayed.record()      # eager_step() waits for it before it touches the optimiser's pointer tables
         # the replay rewrites the parameters through raw pointers: no autograd version bump, no optimiser post-hook.
         # Without this an eager forward between replays (validation) would keep using the split weight images it
         # cached at the previous epoch.
@@ -220,15 +222,27 @@ class GraphedTrainStep:
         """A real (un-captured) optimiser step on ``batch`` - e.g. an odd-shaped last batch of an epoch.  The
         captured graph reads the gradient / moment addresses of ITS step from the optimiser's pinned pointer table;
         an eager step rewrites that table (its gradients are fresh allocations), so the table is restored afterwards
-        and the gradients of the capture stay alive (``TrainStep`` keeps them: see ``_captured_grads``)."""
+        and the gradients of the capture stay alive (``TrainStep`` keeps them: see ``_captured_grads``).
+
+        ``graph.replay()`` is asynchronous and the captured optimiser node re-reads the pinned table WHEN THE GPU REACHES
+        IT: an eager step issued right behind a replay would overwrite the table under a replay that has not got
+        there yet (any GPU-bound configuration: ~150 ms of device time against ~30 ms of host enqueue), and that
+        replay would apply AdamW with the eager step's gradient addresses.  So the host first waits for the last
+        replay to finish (ADVICE r4; ``tests/test_hip_graph.py::test_eager_step_right_behind_a_gpu_bound_replay``)."""
+        self._replayed.synchronize()
         loss = self.step(batch)
         self.step.opt.restore_pointer_tables(self._tables)
         return loss
 
 
 # ---------------------------------------------------------------------------------- data parallel
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, local_rank, world) from the torchrun environment; no-op for a single process."""
+def init_distributed(backend: Optional[str] = None, capturable: bool = False) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; no-op for a single process.
+
+    ``capturable``: the DDP step will be captured into a HIP graph (``GraphedTrainStep``): a replay runs its RCCL
+    kernels without the watchdog's bookkeeping, so the asynchronous error-handling thread is switched off
+    (TORCH_NCCL_ASYNC_ERROR_HANDLING=0).  Eager multi-GPU training keeps PyTorch's default: a failed or hung
+    collective on one rank aborts the job instead of hanging it."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -239,8 +253,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
                 ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-            # a captured step replays its RCCL kernels without the watchdog's bookkeeping (see GraphedTrainStep)
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            if capturable:
+                os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 

@@ -935,7 +935,6 @@ def gemm_scheme_name() -> str:
 # post-hook covers both).  Raw writes outside an optimiser step (a user kernel, ``p.data.copy_``) must be
 # followed by ``ops.weights_updated()``.
 WEIGHT_EPOCH = 0
-_WANT_WT_IMAGE = False   # set by ``pointwise`` around the op call: autograd is recording and x needs a gradient
 _IMAGES = {}     # (id(weight), transpose, scheme) -> (weakref, data_ptr, version, epoch, image)
 
 
@@ -967,7 +966,10 @@ def _version_of(t: Tensor) -> int:
     return 0 if t.is_inference() else t._version
 
 
-def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int) -> Tensor:
+def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int, want_wt: bool = False) -> Tensor:
+    """``want_wt`` (forward image only): the caller's backward will ask for the image of W^T - emit both from one
+    launch.  An argument of the ``pointwise`` op (the public wrapper computes it where grad mode is still visible), not
+    process state: autograd runs backward nodes - and checkpoint recomputes their forwards - on its own threads."""
     key = (id(weight), transpose, scheme)
     ent = _IMAGES.get(key)
     ver = _version_of(weight)
@@ -980,9 +982,9 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int)
     out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     cacheable = isinstance(weight, torch.nn.Parameter) or weight.is_leaf
     out_t = None
-    if not transpose and scheme == GEMM_BF16X3 and cacheable and _WANT_WT_IMAGE:
+    if not transpose and scheme == GEMM_BF16X3 and cacheable and want_wt:
         # a recorded forward whose input needs a gradient: the dgrad GEMM will ask for the image of W^T - both in
-        # one launch (the public wrapper sets the hint: grad mode is off inside the op's own forward)
+        # one launch
         out_t = torch.empty(lib.paradis_pw_gemm_split_bytes(Ci, Co, scheme), dtype=torch.uint8, device=weight.device)
         check(lib.paradis_pw_gemm_split_weights_pair(dptr(w2), Co, Ci, dptr(out), dptr(out_t), stream_ptr()),
               "pw_gemm_split_weights_pair")
@@ -1020,13 +1022,16 @@ def _(x):
 
 @_define("pointwise(Tensor x, Tensor weight, Tensor? bias, Tensor? bmap, Tensor? residual, int act, "
          "Tensor? x_pre, int x_act, bool defer_act_grad, Tensor? m8, Tensor? pw, bool save_z, int scheme, "
-         "Tensor? gate) -> (Tensor, Tensor, Tensor)")
-def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme, gate):
+         "Tensor? gate, bool want_wt_image=False) -> (Tensor, Tensor, Tensor)")
+def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme, gate,
+               want_wt_image=False):
     """y = residual + act(W x + bias + bias_map); second output = pre-activation z (empty unless save_z);
     third = amax partials of x (f16x2 scheme; empty otherwise), kept for the weight gradient.
     ``scheme``: GEMM arithmetic (GEMM_EXACT / GEMM_BF16X3 / GEMM_F16X2); the backward uses the same.
     ``gate`` [Co] (with ``residual``): y = residual + sigmoid(gate)[:,None] * (act(...) - residual) - the gated blend
     of reference model/paradis.py:239-243 in the GEMM epilogue (``ops.gated_blend`` without the advected tensor).
+    ``want_wt_image``: a hint, no effect on the result - the backward of this call will need the split image of W^T
+    (x requires a gradient): both images are then written by one launch and cached.
 
     Activation-gradient hand-off between two chained ops (GMBlock drives it):
       * ``defer_act_grad`` (producer): the op's backward receives d(pre-activation) directly and
@@ -1061,7 +1066,7 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
     w2 = w2t = wsp = None
     x_amax = x.new_empty(0, dtype=torch.int32)
     if scheme != GEMM_EXACT:
-        wsp = _split_image(weight, Co, Ci, False, scheme)   # split planes in tile order
+        wsp = _split_image(weight, Co, Ci, False, scheme, bool(want_wt_image))   # split planes in tile order
         if scheme == GEMM_F16X2:
             x_amax = torch.empty(AMAX_PARTIALS, dtype=torch.int32, device=x.device)
             check(lib.paradis_amax_partials(dptr(x), B, Ci * P, x_bs, dptr(x_amax), stream_ptr()), "amax_partials")
@@ -1086,7 +1091,8 @@ def _pointwise(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_gra
 
 
 @_fake("pointwise")
-def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme, gate):
+def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw, save_z, scheme, gate,
+      want_wt_image=False):
     B, _, H, W = x.shape
     y = x.new_empty(B, weight.shape[0], H, W)
     return (y, (x.new_empty(y.shape) if (save_z and act != 0) else x.new_empty(0)),
@@ -1205,7 +1211,7 @@ def _(gmap, m8, pw):
 
 
 def _pw_setup(ctx, inputs, output):
-    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, scheme, gate = inputs
+    x, weight, bias, bmap, residual, act, x_pre, x_act, defer, m8, pw, save_z, scheme, gate, _want_wt = inputs
     y, z, x_amax = output
     gated = gate is not None
     # (a gated epilogue blends with its residual: the backward needs both ends of the blend - the residual and the
@@ -1223,7 +1229,7 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     act, has_bias, has_map, has_res, x_act, deferred, scheme = ctx.meta
     need = ctx.needs_input_grad
     if gy is None:
-        return (None,) * 14
+        return (None,) * 15
     has_proj = pw is not None
     ggate = None
     if gate is not None:
@@ -1260,7 +1266,7 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
         gpw, gm8 = _global_bias_proj_backward(gmap, m8, pw)
         gmap = None
-    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None, None, ggate
+    return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None, None, ggate, None
 
 
 _autograd("pointwise", _pw_setup, _pw_backward)
@@ -1287,17 +1293,11 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     save_z = bool(defer_act_grad)
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
-    args = (x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw, save_z,
-            GEMM_SCHEME if scheme is None else int(scheme), gate)
-    if torch.compiler.is_compiling():
-        y, z, _ = _pointwise(*args)
-    else:
-        global _WANT_WT_IMAGE
-        _WANT_WT_IMAGE = torch.is_grad_enabled() and (x.requires_grad or (x_pre is not None and x_pre.requires_grad))
-        try:
-            y, z, _ = _pointwise(*args)
-        finally:
-            _WANT_WT_IMAGE = False
+    # (grad mode is off inside the op's own forward: the hint is computed here and travels as an argument)
+    want_wt = (not torch.compiler.is_compiling()) and torch.is_grad_enabled() and \
+        (x.requires_grad or (x_pre is not None and x_pre.requires_grad))
+    y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw,
+                         save_z, GEMM_SCHEME if scheme is None else int(scheme), gate, bool(want_wt))
     return (y, z) if defer_act_grad else y
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/paradis_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.lib.paradis_abi_version() == 7
+    assert _lib.lib.paradis_abi_version() == 8
 
 
 def test_argument_validation_without_gpu():
@@ -201,3 +201,18 @@ def test_weight_image_cache_invalidation():
     v = ops._version_of(q)
     q.add_(1)
     assert ops._version_of(q) == v + 1
+
+
+def test_weight_gradient_slab_count_is_even_or_one():
+    """The weight gradient cancels the offset between K-range slabs of alternating sign, which needs an even number of
+    them.  The host picks the slab count from the tile count (768 resident workgroups / tiles): 1536 x 384 would get 21.
+    It is rounded down to an even number (csrc/gemm.hip wgrad_splits); one slab (weight matrices beyond 384 tiles, none in
+    this model) has no partner and keeps the offset - documented, not cancelled."""
+    from paradis_model_amd._lib import lib
+    shapes = [(1024, 186), (384, 1024), (1536, 384), (768, 1024), (1024, 768), (1024, 1024), (896, 1152), (896, 896),
+              (1024, 896), (768, 768), (97, 768), (2048, 1536), (128, 128), (640, 640)]
+    for (Co, Ci) in shapes:
+        for (B, N) in ((4, 2048), (1, 32768), (32, 2048), (1, 16)):
+            S = lib.paradis_pw_gemm_wgrad_slabs(B, Co, Ci, N)
+            assert S >= 1 and (S == 1 or S % 2 == 0), ((Co, Ci, B, N), S)
+    assert lib.paradis_pw_gemm_wgrad_slabs(4, 1536, 384, 2048) == 20      # 768 / 36 tiles = 21 -> 20

@@ -183,6 +183,46 @@ def _oracle_grads_ckpt(model, spec, x, ct, lg, og, dtype):
     return y.detach(), {k: v.grad for k, v in ps.items() if torch.is_tensor(v) and v.requires_grad}
 
 
+def test_cfg3_one_layer_128x256_gradients_single_seed():
+    """The deterministic companion of the distributional test below: ONE ADR layer of the full-width model at
+    128x256, one fixed seed, forward and every parameter gradient by the fp64 protocol at the single-seed bounds
+    (8 x max-abs, 5 x norm-wise of the CPU-fp32 oracle's own distance to fp64) for BOTH arithmetics - the default bf16x3
+    and the f32-MFMA kernels - against one pair of host oracle runs.  With one layer the chain amplifies rounding far less
+    than with two (no advection differentiating through another layer's output), so a hard per-parameter assertion holds
+    here where the two-layer case needs a distribution; a regression confined to one arithmetic or one seed of the
+    distributional test still fails this one."""
+    from paradis_model_amd import ops
+    from tests.test_hip_model import _check_grads_by_fp64_protocol
+    cfg = default_config()
+    cfg.model.num_layers = 1
+    H, W = 128, 256
+    _, lg, og = make_grid(H, W, False)
+    spec = _spec(cfg, H, W)
+    model = _build(cfg, lg, og, bias_scale=0.05)
+    x = _smooth(seeded(123, 1, 186, H, W)) * 4.0
+    x[:, -2], x[:, -1] = lg, og
+    ct = _smooth(seeded(124, 1, 97, H, W)) * 4.0
+    y32, g32 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float32)
+    y64, g64 = _oracle_grads_ckpt(model, spec, x, ct, lg, og, torch.float64)
+    keep = ops.GEMM_SCHEME
+    try:
+        for name in ("bf16x3", "exact"):
+            ops.GEMM_SCHEME = ops._SCHEMES[name]
+            model.zero_grad(set_to_none=True)
+            got = model(x.cuda())
+            (got * ct.cuda()).sum().backward()
+            e = max_rel(got.detach().cpu(), y32)
+            assert e <= 1e-5, (name, e)
+            _check_grads_by_fp64_protocol(model, g32, g64, factor=8.0, rms_factor=5.0)
+            r = rms_rel(model.get_parameter("reaction.0.0-ChannelNorm.bias").grad.cpu().double(),
+                        g64["reaction.0.0-ChannelNorm.bias"]) / max(rms_rel(g32["reaction.0.0-ChannelNorm.bias"].double(),
+                                                                            g64["reaction.0.0-ChannelNorm.bias"]), 1e-12)
+            print("cfg3 128x256 L=1 %s: forward %.2e, ChannelNorm.bias ratio %.2f" % (name, e, r))
+            assert r <= 5.0, (name, r)          # the pixel-sum gradient that exposed the bf16 MFMA offset
+    finally:
+        ops.GEMM_SCHEME = keep
+
+
 def test_cfg3_default_width_model_128x256_gradients_fp64_protocol():
     """configs[3]'s per-sample work inside the full-width model (latent 1024, 768 velocity planes, every block of the
     default configuration): forward AND every parameter gradient at 128x256, B=1 - the ring-window advection scatter,

@@ -133,3 +133,33 @@ def test_eager_step_after_capture_keeps_the_graph_valid():
     pe = torch.cat([p.detach().flatten() for p in model_e.parameters()])
     pg = torch.cat([p.detach().flatten() for p in model_g.parameters()])
     assert max_rel(pg, pe) <= 1e-6, max_rel(pg, pe)
+
+
+def test_eager_step_right_behind_a_gpu_bound_replay():
+    """``graph.replay()`` is asynchronous and the captured optimiser node reads the pinned pointer table when the
+    GPU reaches it.  With the queue ~200 ms deep (large fp32 matmuls in front of the replay stand in for a GPU-bound
+    configuration: the 16x32 reduced model alone is host-bound) an ``eager_step`` issued right behind the replay used to
+    overwrite the table under it - the replay then applied AdamW with the eager step's gradient addresses.
+    ``eager_step`` now waits for the last replay (an event recorded after every replay).  Twin: the same steps eagerly."""
+    from paradis_model_amd.harness import GraphedTrainStep
+    model_e, step_e, batches = _setup(False)
+    model_g, step_g, _ = _setup(True)
+    warm = 2
+    g = GraphedTrainStep(step_g, batches[0], warmup=warm)
+    for _ in range(warm):
+        step_e(batches[0])
+    small = tuple(t[:1].contiguous() for t in batches[1])
+    a = torch.randn(8192, 8192, device="cuda")
+    for rnd in range(3):
+        step_e(batches[rnd % 2]); step_e(small)
+        torch.cuda.synchronize()
+        for _ in range(20):            # ~10 ms each: the replay below sits behind them in the queue
+            a @ a
+        g(batches[rnd % 2])
+        assert not g._replayed.query()             # the replay has not run yet: the race window is open
+        g.eager_step(small)
+    g(batches[0]); step_e(batches[0])
+    torch.cuda.synchronize()
+    pe = torch.cat([p.detach().flatten() for p in model_e.parameters()])
+    pg = torch.cat([p.detach().flatten() for p in model_g.parameters()])
+    assert max_rel(pg, pe) <= 1e-6, max_rel(pg, pe)

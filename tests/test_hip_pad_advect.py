@@ -112,7 +112,10 @@ def test_advect_core_vs_golden_and_fp64(ops, force_gmem, halo, generic, strips, 
 @pytest.mark.parametrize("H,W,poles,mode,strips", [(32, 64, False, "bicubic", False), (33, 64, True, "bilinear", False),
                                                    (128, 256, False, "bicubic", False), (65, 130, True, "bicubic", False),
                                                    (128, 256, False, "bicubic", True), (65, 130, True, "bilinear", True),
-                                                   (181, 360, True, "bicubic", False)])
+                                                   (181, 360, True, "bicubic", False),
+                                                   # H > 160 takes the 64-row ring: at W = 256 the full circle does not fit
+                                                   # LDS and the 128-column strips must run (used to be an error)
+                                                   (181, 256, True, "bicubic", False), (181, 256, True, "bilinear", False)])
 def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode, strips):
     """Gradients against fp64 autograd through the oracle (the formula check)."""
     B, K = 2, 4
