@@ -343,7 +343,7 @@ def main():
     if args.gemm == "split":
         args.gemm = "bf16x3"
     ops.GEMM_SCHEME = ops._SCHEMES[args.gemm]
-    rank, local, world = init_distributed()
+    rank, local, world = init_distributed(capturable=args.graph)   # (the async NCCL error handler stays on for eager DDP)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
     if os.environ.get("PARADIS_SHARE_GPU0") == "1":   # test hook: all ranks on cuda:0 (with gloo)
@@ -440,6 +440,48 @@ def main():
             legs["f16x2_emulated"] = extra_leg(
                 "f16x2", "NOT reference-width: block-exponent emulation, two f16 terms of the per-tensor scaled "
                          "operands (22 significand bits relative to each tensor's maximum), 3 products on f16 MFMA")
+
+    # The reference's SHIPPED training mode (use_amp: true -> precision="bf16-mixed", config/paradis_settings.yaml:75,
+    # train.py:56): forward + loss under torch.autocast(bfloat16), where the pointwise GEMMs run ONE bf16 product
+    # (PARADIS_GEMM_BF16).  Never the headline: NOT reference-width arithmetic for the fp32 parity path.  Eager, and
+    # replayed from a captured graph (at this step length the eager host path is what bounds slow hosts).
+    if not args.no_extra_legs and not args.graph and world == 1 and not args.forward_only and args.optimizer == "adamw":
+        try:
+            from paradis_model_amd.harness import GraphedTrainStep
+            astep = TrainStep(model, loss_fn, cfg, num_common=lay.num_common_features, n_inputs=cfg.dataset.n_time_inputs,
+                              amp=True)
+            for _ in range(max(args.warmup, 5)):
+                astep(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                astep(batch)
+            torch.cuda.synchronize()
+            e = time.perf_counter() - t1
+            rec = {"value": B * args.steps / e, "unit": "samples/s", "ms_per_step": 1e3 * e / args.steps,
+                   "warmup": max(args.warmup, 5),
+                   "gemm_arithmetic": "NOT reference-width, reference AMP mode: torch.autocast(bfloat16) - pointwise GEMMs "
+                                      "with operands rounded to bf16, one product, fp32 accumulate, bf16-rounded results; "
+                                      "advection / stencils / norms fp32; fp32 storage"}
+            del astep
+            try:
+                gstep = GraphedTrainStep(TrainStep(model, loss_fn, cfg, num_common=lay.num_common_features,
+                                                   n_inputs=cfg.dataset.n_time_inputs, capturable=True, amp=True),
+                                         batch, warmup=2)
+                for _ in range(3):
+                    gstep(batch)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    gstep(batch)
+                torch.cuda.synchronize()
+                rec["ms_per_step_graph_replay"] = 1e3 * (time.perf_counter() - t1) / args.steps
+                del gstep
+            except Exception as exc:
+                rec["graph_error"] = repr(exc)[:300]
+            legs["bf16_mixed_amp"] = rec
+        except Exception as exc:
+            legs["bf16_mixed_amp"] = {"error": repr(exc)[:300]}
 
     # The same step (headline arithmetic) replayed from ONE captured HIP graph: what the host costs disappears
     # (N = 1, AdamW; DDP's bucket hooks are not capturable).  Reported beside the headline, never as the headline.

@@ -57,6 +57,12 @@ struct GemmArgs {
   // f16x2 scheme: where the operands' max |value| comes from.  a_amax: one word (bits of max |A|, weight
   // image tail) for fwd/dgrad, PARADIS_AMAX_PARTIALS words for wgrad; b_amax: PARADIS_AMAX_PARTIALS words.
   const uint32_t* a_amax; const uint32_t* b_amax;
+  // PARADIS_GEMM_BF16 (the reference's bf16-mixed mode): the result is rounded to bf16 where the reference's autocast
+  // conv2d rounds it - the pre-activation and the activated value (fwd), the activation-gradient product (dgrad) -
+  // before the fp32 residual / blend.  Stored as fp32.
+  int round16;
+  // wgrad: one word per K-range slab for the soft rendezvous of the slab's tiles (NULL = none), see WGRAD_SYNC_T
+  unsigned* sync;
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -146,6 +152,8 @@ __device__ __forceinline__ void gemm_add_projection(const GemmArgs& g, f32x16 (&
 }
 
 __device__ __forceinline__ float gate_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
+// value of x rounded to bf16 (round to nearest even; a NaN stays a NaN: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
 
 // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 //   v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v);
@@ -185,6 +193,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += t[q];
           }
+          if (g.round16) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
+          }
           if (zoutb) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) zoutb[base + ROWOFF(q)] = v[q];
@@ -197,6 +209,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
           } else if (g.act) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = act_apply(v[q], g.act);
+          }
+          if (g.round16 && (zmulb || g.act)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
           }
           if (resb) {
 #pragma unroll
@@ -237,9 +253,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const int64_t off = (int64_t)m * g.ldc + n;
         float v = acc[tm][tn][r] + bv;
         if (g.map) v += g.map[off];
+        if (g.round16) v = round_bf16(v);
         if (zoutb) zoutb[off] = v;
         if (zmulb) v *= act_grad(zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
+        if (g.round16 && (zmulb || g.act)) v = round_bf16(v);
         if (resb) {
           const float r = resb[off];
           v = g.gate ? fmaf(gate_sigmoid(g.gate[m]), v - r, r) : v + r;
@@ -597,7 +615,8 @@ constexpr int SBK = 16;                  // k depth of a tile = one bf16 / f16 M
 constexpr int SCH = 128;                 // chunks per k-half row of an unpadded image
 constexpr int SCHP = 128 + 8;            // padded variant (wgrad: lane pairs write both k-halves of a row)
 // NP = number of planes of an operand image = terms of the split: 3 = bf16 h/m/l (exact, six products),
-// 2 = f16 h/l of the scaled value (22 significand bits, three products)
+// 2 = f16 h/l of the scaled value (22 significand bits, three products), 1 = the value rounded to bf16 (ONE product:
+// PARADIS_GEMM_BF16, the arithmetic of the reference's bf16-mixed training mode - train.py:56 - never the fp32 path's)
 constexpr int simg(int np) { return np * 2 * SCH; }      // chunks per operand per stage (12 / 8 KiB)
 constexpr int simgp(int np) { return np * 2 * SCHP; }
 constexpr int SIMG = simg(3);
@@ -714,6 +733,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, 
   l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
 }
 
+// eight values rounded to bf16 (the one plane of PARADIS_GEMM_BF16)
+__device__ __forceinline__ u32x4 round8(const float (&x)[8]) {
+  return (u32x4){pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
+}
+
 __device__ __forceinline__ void split8_f16(const float (&x)[8], float s, u32x4& h, u32x4& l) {
   uint32_t hh[4], ll[4];
 #pragma unroll
@@ -751,6 +775,7 @@ amax_partials_kernel(const float* __restrict__ x, int B, int64_t inner, int64_t 
 
 // Image of A[m,k] = W[m*rs + k*cs] (rs/cs select W or W^T), zero padded to [MT*128, KT*16]:
 // out[((mt*KT + kt)*3 + s)*256 + half*128 + row] ; one thread per (mt, kt, half, row).
+template <int NP = 3>
 __device__ __forceinline__ void split_weights_body(const float* __restrict__ Wb, int64_t rs, int64_t cs, int M, int K,
                                                    int KT, int64_t units, u32x4* __restrict__ ob) {
   for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
@@ -765,17 +790,22 @@ __device__ __forceinline__ void split_weights_body(const float* __restrict__ Wb,
       x[j] = (m < M && k < K) ? Wb[(int64_t)m * rs + (int64_t)k * cs] : 0.f;
       if (SPLIT_SIGNED && (row & 32)) x[j] = -x[j];      // sign checkerboard: odd 32-row blocks hold -W
     }
-    u32x4 h, mm, l;
-    split8(x, h, mm, l);
-    u32x4* o = ob + tile * SIMG + half * SCH + row;
-    o[0] = h; o[2 * SCH] = mm; o[4 * SCH] = l;
+    if constexpr (NP == 3) {
+      u32x4 h, mm, l;
+      split8(x, h, mm, l);
+      u32x4* o = ob + tile * SIMG + half * SCH + row;
+      o[0] = h; o[2 * SCH] = mm; o[4 * SCH] = l;
+    } else {
+      ob[tile * simg(1) + half * SCH + row] = round8(x);
+    }
   }
 }
 
+template <int NP>
 __global__ void __launch_bounds__(256)
 split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
                      int64_t w_bs, int64_t out_bs, u32x4* __restrict__ out) {
-  split_weights_body(W + (int64_t)blockIdx.y * w_bs, rs, cs, M, K, KT, units, out + (int64_t)blockIdx.y * out_bs);
+  split_weights_body<NP>(W + (int64_t)blockIdx.y * w_bs, rs, cs, M, K, KT, units, out + (int64_t)blockIdx.y * out_bs);
 }
 
 // both images of one row-major W[M,K] in ONE launch (a training step needs W for the forward GEMM and W^T for the
@@ -783,8 +813,8 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 __global__ void __launch_bounds__(256)
 split_weights_pair_kernel(const float* __restrict__ W, int M, int K, int KT, int KTt, int64_t units, int64_t units_t,
                           u32x4* __restrict__ out, u32x4* __restrict__ out_t) {
-  if (blockIdx.y == 0) split_weights_body(W, K, 1, M, K, KT, units, out);
-  else split_weights_body(W, 1, K, K, M, KTt, units_t, out_t);
+  if (blockIdx.y == 0) split_weights_body<3>(W, K, 1, M, K, KT, units, out);
+  else split_weights_body<3>(W, 1, K, K, M, KTt, units_t, out_t);
 }
 
 // f16x2 image: out[((mt*KT + kt)*2 + s)*256 + half*128 + row]; `tail` = the words behind the image:
@@ -837,11 +867,14 @@ __device__ __forceinline__ void split_tile_read(const u32x4* As, const u32x4* Bs
     f.a[0][0] = As[0];           f.b[2][0] = Bs[2 * PB];
     f.b[1][1] = Bs[PB + 32];     f.b[0][1] = Bs[32];          f.b[2][1] = Bs[2 * PB + 32];
     f.a[1][1] = As[PA + 32];     f.a[2][1] = As[2 * PA + 32]; f.a[0][1] = As[32];
-  } else {
+  } else if constexpr (NP == 2) {
     f.a[1][0] = As[PA];          f.b[0][0] = Bs[0];
     f.a[0][0] = As[0];           f.b[1][0] = Bs[PB];
     f.b[0][1] = Bs[32];          f.b[1][1] = Bs[PB + 32];
     f.a[1][1] = As[PA + 32];     f.a[0][1] = As[32];
+  } else {
+    f.a[0][0] = As[0];  f.b[0][0] = Bs[0];
+    f.b[0][1] = Bs[32]; f.a[0][1] = As[32];
   }
 }
 // ... then the 24 (12) MFMAs, smallest products first
@@ -853,10 +886,12 @@ __device__ __forceinline__ void split_tile_mfma(const SplitFrags<NP>& f, f32x16 
     for (int tn = 0; tn < 2; ++tn) {
       if constexpr (NP == 3) {
         SPLIT_BLOCK(f.a[0][tm], f.a[1][tm], f.a[2][tm], f.b[0][tn], f.b[1][tn], f.b[2][tn], acc[tm][tn]);
-      } else {
+      } else if constexpr (NP == 2) {
         SPLIT_MFMA16(f.a[1][tm], f.b[0][tn], acc[tm][tn]);
         SPLIT_MFMA16(f.a[0][tm], f.b[1][tn], acc[tm][tn]);
         SPLIT_MFMA16(f.a[0][tm], f.b[0][tn], acc[tm][tn]);
+      } else {
+        SPLIT_MFMA(f.a[0][tm], f.b[0][tn], acc[tm][tn]);
       }
     }
 }
@@ -945,6 +980,10 @@ pw_gemm_split_kernel(GemmArgs g) {
       flip8(xs, x, flip);          // sign checkerboard: odd 64-column blocks are staged negated
       split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+    } else if constexpr (NP == 1) {
+      float xs[8];
+      flip8(xs, x, flip);
+      o[0] = round8(xs);
     } else {
       u32x4 h, l;
       split8_f16(x, sc_b, h, l);   // (the column's sign rides on the scale)
@@ -1000,7 +1039,7 @@ pw_gemm_split_kernel(GemmArgs g) {
     if (dmaA) issueA(t + DA);
     if (ldB) fetchB(t + 2, xload);
     // xsplit (tile t+1) was loaded a step ago; younger operations: this step's NP DMA and 8 loads
-    if (dmaA && ldB) { if constexpr (NP == 3) USE_X(xsplit, 11); else USE_X(xsplit, 10); }
+    if (dmaA && ldB) { if constexpr (NP == 3) USE_X(xsplit, 11); else if constexpr (NP == 2) USE_X(xsplit, 10); else USE_X(xsplit, 9); }
     else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
     // The fragment reads sit in the block of the MFMAs (behind the branches above the compiler's lgkmcnt
@@ -1013,11 +1052,13 @@ pw_gemm_split_kernel(GemmArgs g) {
     split_tile_mfma<NP>(f, acc);
     split_store(xsplit, Bst + (cur ^ 1) * SIMG);
     // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
+    if constexpr (NP > 1) {
     __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
 #pragma unroll
     for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 3 : 2, 0);
+    }
     }
     // weight tile t+1 landed (its DMA is DA steps old: 8 loads of that step + 8 + NP operations per step since
     // are younger), own ds_writes done, the loads of t+2 and the younger DMAs still in flight
@@ -1065,7 +1106,8 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
 
   // the weight tile (SIMG = 256 NP chunks of 16 bytes) goes by LDS-DMA, one chunk per thread and piece: f16x2 one
   // piece of 512 chunks (the first 512 threads), bf16x3 a piece of 512 and a piece of 256 (waves 0-3)
-  const bool doA = NSUB == 2 || wave < 8;            // wave-uniform
+  // (one plane: a piece of 256 chunks, waves 0-3)
+  const bool doA = NP == 1 ? wave < 4 : (NSUB == 2 || wave < 8);     // wave-uniform
   const bool doA2 = NP == 3 && wave < 4;             // wave-uniform: second piece
   const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + (tid & 511);
   const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
@@ -1112,6 +1154,10 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
       flip8(xs, x, flip);
       split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
+    } else if constexpr (NP == 1) {
+      float xs[8];
+      flip8(xs, x, flip);
+      o[0] = round8(xs);
     } else {
       u32x4 h, l;
       split8_f16(x, sc_b, h, l);   // (the column's sign rides on the scale)
@@ -1200,11 +1246,13 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
       split_tile_read<NP, 2 * SCH, 2 * SCH>(As, Bs, f);
       split_tile_mfma<NP>(f, acc);
       split_store(xsplit, Bst + (cur ^ 1) * SIMG);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
+      if constexpr (NP == 2) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
       }
     }
     // weight tile t+1 landed (8 loads of this step are younger), own ds_writes done, the loads of t+2 in flight
@@ -1231,6 +1279,16 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
 // per tile.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Soft rendezvous of the tiles of a K-range slab (round 5).  The MT x NT workgroups of a slab stream the same rows of
+// dY (the NT tiles of an m-tile) and of X (the MT tiles of an n-tile) through one XCD's L2; nothing keeps them in step,
+// and over the ~1400 k-tiles of a 128 x 256 B = 8 launch they drift apart by more than the L2 holds: every workgroup then
+// fetches its rows itself (rocprofv3 FETCH_SIZE 6.68 GB per launch for 1.8 GB of operands, round 4).  Every WGRAD_SYNC_T
+// k-tiles wave 0 of each workgroup adds one to the slab's counter and waits - BOUNDED: a fixed number of polls, then it
+// goes on regardless - until the slab's other tiles have done the same.  Correctness never depends on it; it needs all
+// workgroups co-resident to have any effect (the host enables it only for grids of one round).  0 = off.
+#ifndef WGRAD_SYNC_T
+#define WGRAD_SYNC_T 0
+#endif
 template <int NP>
 __global__ void __launch_bounds__(256, 3)
 pw_gemm_wgrad_split_kernel(GemmArgs g) {
@@ -1303,6 +1361,11 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
       o[0] = ha; o[2 * SCHP] = ma; o[4 * SCHP] = la;
       o += SIMGP;
       o[0] = hb; o[2 * SCHP] = mb; o[4 * SCHP] = lb;
+    } else if constexpr (NP == 1) {
+      float xs[8];
+      flip8(xs, xa, slab_flip);
+      o[0] = round8(xs);
+      o[SIMGP] = round8(xb);
     } else {
       u32x4 ha, la, hb, lb;
       split8_f16(xa, sc_a, ha, la);
@@ -1339,14 +1402,34 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     // one basic block for every tile; the last tile's split is surplus (stage nobody reads, keep = 0)
     split_tile_mfma<NP>(f, acc);
     split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+    if constexpr (NP > 1) {
 #pragma unroll
     for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the two splits
     }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
+#if WGRAD_SYNC_T
+  const int t_sync_end = (int)(total / g.nbatch);        // every tile of the slab runs at least this many k-tiles
+  const unsigned slab_tiles = (unsigned)(MT * NT);
+#endif
   for (int t = 0; t < T; t += 2) {
+#if WGRAD_SYNC_T
+    if (g.sync != nullptr && t > 0 && (t & (WGRAD_SYNC_T - 1)) == 0 && t < t_sync_end &&
+        __builtin_amdgcn_readfirstlane(wave) == 0) {
+      if (lane == 0) {
+        unsigned* cnt = g.sync + bz;
+        const unsigned target = (unsigned)(t / WGRAD_SYNC_T) * slab_tiles;
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; spin < 128; ++spin) {          // bounded: ~0.3 us per poll
+          if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    }
+#endif
     step(t, 0, r0, r1);
     if (t + 1 < T) step(t + 1, 1, r1, r0);
   }
@@ -1487,7 +1570,8 @@ int64_t split_image_chunks(int M, int K, int np = 3) {
 }
 
 bool known_scheme(int scheme) {
-  return scheme == PARADIS_GEMM_EXACT || scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2;
+  return scheme == PARADIS_GEMM_EXACT || scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2 ||
+         scheme == PARADIS_GEMM_BF16;
 }
 
 int launch_amax(const float* x, int B, int64_t inner, int64_t bs, uint32_t* out, hipStream_t st) {
@@ -1539,6 +1623,10 @@ int launch_split_wide(const GemmArgs& d, int NT, hipStream_t st) {
 }
 int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
   const int NT = (d.N + BN - 1) / BN;
+  if (scheme == PARADIS_GEMM_BF16) {
+    if (NT < 2) return launch_split_np<1>(d, st);
+    return launch_split_wide<1>(d, NT, st);
+  }
   if (scheme != PARADIS_GEMM_F16X2) {
 #if SPLIT_WIDE_BF16X3
     if (NT >= 2) return launch_split_wide<3>(d, NT, st);
@@ -1573,6 +1661,7 @@ extern "C" void paradis_debug_set_wgrad_dma(int stages) { g_wgrad_dma_stages = s
 extern "C" size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme) {
   if (M < 1 || K < 1) return 0;
   if (scheme == PARADIS_GEMM_F16X2) return (size_t)split_image_chunks(M, K, 2) * 16 + F16_TAIL_BYTES;
+  if (scheme == PARADIS_GEMM_BF16) return (size_t)split_image_chunks(M, K, 1) * 16;
   return scheme == PARADIS_GEMM_BF16X3 ? (size_t)split_image_chunks(M, K, 3) * 16 : 0;
 }
 
@@ -1591,7 +1680,8 @@ extern "C" int paradis_amax_partials(const float* x, int B, int64_t inner, int64
 extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, int scheme, void* out,
                                              void* stream) {
   PD_REQUIRE(W != nullptr && out != nullptr && M >= 1 && K >= 1, "pw_gemm_split_weights: bad arguments");
-  PD_REQUIRE(scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2, "pw_gemm_split_weights: unknown scheme %d", scheme);
+  PD_REQUIRE(scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2 || scheme == PARADIS_GEMM_BF16,
+             "pw_gemm_split_weights: unknown scheme %d", scheme);
   const int AM = transpose ? K : M, AK = transpose ? M : K;
   const int KT = (AK + SBK - 1) / SBK;
   const int64_t units = (int64_t)((AM + BM - 1) / BM) * KT * 256;
@@ -1601,8 +1691,12 @@ extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int t
     launch_amax(W, 1, (int64_t)M * K, 0, tail + 4, (hipStream_t)stream);
     hipLaunchKernelGGL(split_weights_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W,
                        (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units, (u32x4*)out, tail);
+  } else if (scheme == PARADIS_GEMM_BF16) {
+    hipLaunchKernelGGL(split_weights_kernel<1>, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
+                       (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units,
+                       (int64_t)0, (int64_t)0, (u32x4*)out);
   } else {
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
+    hipLaunchKernelGGL(split_weights_kernel<3>, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, W,
                        (int64_t)(transpose ? 1 : K), (int64_t)(transpose ? K : 1), AM, AK, KT, units,
                        (int64_t)0, (int64_t)0, (u32x4*)out);
   }
@@ -1628,6 +1722,7 @@ namespace {
 int run_split(GemmArgs d, const void* img, int AM, int AK, int scheme, const uint32_t* b_amax, const char* what,
               hipStream_t st) {
   d.A = (const float*)img; d.a_bs = 0;
+  d.round16 = scheme == PARADIS_GEMM_BF16;
   if (scheme == PARADIS_GEMM_F16X2) {
     if (b_amax == nullptr) { paradis_set_error(what); return 1; }
     d.a_amax = reinterpret_cast<const uint32_t*>((const char*)img + (size_t)split_image_chunks(AM, AK, 2) * 16);
@@ -1727,7 +1822,7 @@ extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, f
     const int KT = (K + SBK - 1) / SBK;
     const int64_t chunks = split_image_chunks(M, K), units = (int64_t)((M + BM - 1) / BM) * KT * 256;
     const int blocks = (int)std::min<int64_t>((units + 255) / 256, 1024);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, nbatch), dim3(256), 0, (hipStream_t)stream, A,
+    hipLaunchKernelGGL(split_weights_kernel<3>, dim3(blocks, nbatch), dim3(256), 0, (hipStream_t)stream, A,
                        (int64_t)K, (int64_t)1, M, K, KT, units, a_bs, chunks, (u32x4*)split_ws);
     GemmArgs d = g;
     d.A = (const float*)split_ws; d.a_bs = chunks;
@@ -1787,7 +1882,7 @@ extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
   const int b = std::max(B, 1);
   const int S = std::max({wgrad_splits(b, M, K, N, DBK, wgrad_dma_wgs()), wgrad_splits(b, M, K, N, g_bk, g_wg_per_cu),
                           wgrad_splits(b, M, K, N, SBK, 3)});
-  return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256;   // slabs + row-sum partials
+  return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256 + 4096;   // slabs + row-sum partials + rendezvous words
 }
 
 // K-range slabs the split weight-gradient kernel runs for this shape (1, or an even number: see wgrad_splits)
@@ -1834,9 +1929,19 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.stagger = g_stagger;
   g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
+#if WGRAD_SYNC_T
+  if (use_split && S >= 2 && S <= 1024 && grid <= 768 && (int64_t)B * (N / SBK) / S >= 4 * WGRAD_SYNC_T) {
+    // rendezvous words behind the slabs and the row sums (zeroed in-stream: a kernel, see pd_zero_async)
+    unsigned* sw = reinterpret_cast<unsigned*>(((uintptr_t)(rowsum_ws + (size_t)S * M) + 63) & ~(uintptr_t)63);
+    if (pd_zero_async(sw, (size_t)S * sizeof(unsigned), st) != hipSuccess) return 2;
+    g.sync = sw;
+  }
+#endif
   if (use_split && scheme == PARADIS_GEMM_F16X2) {
     g.a_amax = dy_amax; g.b_amax = x_amax;
     hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<2>, dim3(grid), dim3(256), split_lds_wgrad(2), st, g);
+  } else if (use_split && scheme == PARADIS_GEMM_BF16) {
+    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<1>, dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
   } else if (use_split) {
     hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<3>, dim3(grid), dim3(256), split_lds_wgrad(3), st, g);
   } else if (dma) {

@@ -114,8 +114,12 @@ class TrainStep:
     (SURVEY.md section 8d).  AdamW hyper-parameters follow reference trainer.py:327-335."""
 
     def __init__(self, model, loss_fn, cfg, *, num_common: int = 83, n_inputs: int = 2, fused=None,
-                 capturable: bool = False):
+                 capturable: bool = False, amp: bool = False):
         self.model, self.loss_fn = model, loss_fn
+        # amp: forward and loss under torch.autocast(bfloat16) - the reference's shipped ``use_amp: true`` /
+        # ``precision="bf16-mixed"`` (config/paradis_settings.yaml:75, train.py:56); parameters, gradients and the
+        # optimiser stay fp32, as with Lightning's mixed-precision plugin
+        self.amp = bool(amp)
         self.num_common, self.n_inputs = num_common, n_inputs
         o = cfg.training.optimizer
         params = [p for p in model.parameters() if p.requires_grad]
@@ -144,8 +148,10 @@ class TrainStep:
 
     def __call__(self, batch):
         self.opt.zero_grad(set_to_none=True)
-        loss, _ = rollout_loss(self.model, self.loss_fn, batch, num_common=self.num_common,
-                               n_inputs=self.n_inputs, detach_every=self.detach_every)
+        dev = "cuda" if batch[0].is_cuda else "cpu"
+        with torch.autocast(dev, dtype=torch.bfloat16, enabled=self.amp):
+            loss, _ = rollout_loss(self.model, self.loss_fn, batch, num_common=self.num_common,
+                                   n_inputs=self.n_inputs, detach_every=self.detach_every)
         self.opt.step()
         return loss
 

@@ -909,7 +909,11 @@ def global_bias_m8(A, U, V):
 #            format: 22 significand bits relative to the tensor's largest magnitude), three products on the f16 pipe.
 # PARADIS_GEMM selects ("split" = bf16x3, the name of earlier rounds).  The scheme is an explicit integer argument of
 # the ops below (as it is at the C ABI), so a traced graph pins the arithmetic it was traced with.
-GEMM_EXACT, GEMM_F16X2, GEMM_BF16X3 = 0, 2, 3
+#   "bf16"   NOT fp32 arithmetic: the reference's bf16-mixed (AMP) training mode (train.py:56, use_amp: true) - operands
+#            rounded to bf16, ONE product, fp32 accumulate, results rounded to bf16 where autocast's conv2d rounds them.
+#            Selected by ``pointwise`` only inside ``torch.autocast(device_type="cuda", dtype=torch.bfloat16)`` (or by an
+#            explicit ``scheme=``); PARADIS_GEMM cannot name it.
+GEMM_EXACT, GEMM_BF16, GEMM_F16X2, GEMM_BF16X3 = 0, 1, 2, 3
 _SCHEMES = {"exact": GEMM_EXACT, "f16x2": GEMM_F16X2, "bf16x3": GEMM_BF16X3, "split": GEMM_BF16X3}
 AMAX_PARTIALS = 1024
 
@@ -925,7 +929,19 @@ GEMM_SCHEME = _scheme_from_env()     # what the Python wrappers pass to the ops 
 
 
 def gemm_scheme_name() -> str:
-    return {GEMM_EXACT: "exact", GEMM_F16X2: "f16x2", GEMM_BF16X3: "bf16x3"}[GEMM_SCHEME]
+    return {GEMM_EXACT: "exact", GEMM_BF16: "bf16", GEMM_F16X2: "f16x2", GEMM_BF16X3: "bf16x3"}[GEMM_SCHEME]
+
+
+def autocast_scheme(default: int) -> int:
+    """GEMM arithmetic of a ``pointwise`` call that names none: inside ``torch.autocast("cuda", dtype=torch.bfloat16)`` -
+    the reference's ``precision="bf16-mixed"`` (train.py:56; its shipped default, ``use_amp: true``) - the one-product
+    bf16 scheme, i.e. what autocast makes of the reference's ``nn.Conv2d`` calls (model/blocks.py:86,110); the fp32
+    scheme otherwise.  Everything else on the path (advection, stencils, norms) stays fp32 under autocast, as autocast
+    keeps ``grid_sampler``; the scheme travels as an explicit argument of the op, so the backward and a traced graph
+    use the arithmetic the forward was called with."""
+    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return GEMM_BF16
+    return default
 
 
 # split tile images of the weights (split GEMMs) are rebuilt only when the weights change:
@@ -955,7 +971,7 @@ _register_step_post_hook(_optimizer_step_hook)
 
 
 def _drop_images(wid: int) -> None:
-    for scheme in (GEMM_F16X2, GEMM_BF16X3):
+    for scheme in (GEMM_BF16, GEMM_F16X2, GEMM_BF16X3):
         _IMAGES.pop((wid, False, scheme), None)
         _IMAGES.pop((wid, True, scheme), None)
 
@@ -1278,7 +1294,8 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
 
     ``bias_proj=(m8[Cin,H,W], Pw[Co,Cin])`` adds the projected low-rank GlobalBias map inside the GEMM
     epilogue instead of a materialised ``bias_map``.
-    ``scheme``: GEMM arithmetic, default ``ops.GEMM_SCHEME`` (read when the call is made / traced).
+    ``scheme``: GEMM arithmetic, default ``ops.GEMM_SCHEME`` (read when the call is made / traced); inside
+    ``torch.autocast("cuda", dtype=torch.bfloat16)`` the default is ``GEMM_BF16`` (``autocast_scheme``).
     ``defer_act_grad=True`` returns ``(y, z)`` and expects the consumer to be another ``pointwise``
     called with ``x_pre=z, x_act=act`` (see the op docstring); only valid when ``y`` has no other use.
     ``gate`` [Co] (needs ``residual``): y = residual + sigmoid(gate) * (act(...) - residual), i.e.
@@ -1297,7 +1314,7 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     want_wt = (not torch.compiler.is_compiling()) and torch.is_grad_enabled() and \
         (x.requires_grad or (x_pre is not None and x_pre.requires_grad))
     y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw,
-                         save_z, GEMM_SCHEME if scheme is None else int(scheme), gate, bool(want_wt))
+                         save_z, autocast_scheme(GEMM_SCHEME) if scheme is None else int(scheme), gate, bool(want_wt))
     return (y, z) if defer_act_grad else y
 
 

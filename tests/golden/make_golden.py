@@ -11,6 +11,7 @@ What each file pins:
   g2_advect.pt     advection core (projections = identity): fp32 + fp64 outputs and grads
   g3_blocks.pt     CLinear / SepConv / ChannelNorm / GlobalBias / PhysicalDownsample / upsample
   g4_model_*.pt    reduced-config Paradis: state_dict (= seed-42 init), input, output, loss, grads
+  g7_amp_*.pt      the same models under torch.autocast(bfloat16) - the reference's shipped bf16-mixed mode
   g5 manifest      default-config state_dict key/shape list (335 entries)
   g6_loss.pt       ParadisLoss weights and values
   c2_rollout.pt    2-step autoregressive rollout (restated trainer loop driving the reference model)
@@ -286,6 +287,34 @@ def g4_models():
         torch.save(rec, os.path.join(HERE, f"g4_model_{variant}.pt"))
 
 
+def g7_amp():
+    """The reference in its SHIPPED training mode: ``use_amp: true`` (config/paradis_settings.yaml:75) ->
+    ``precision="bf16-mixed"`` (train.py:56), i.e. forward and loss under ``torch.autocast(dtype=torch.bfloat16)``
+    (here on the CPU: the same autocast op lists route every conv2d / linear / matmul through bf16 and keep
+    grid_sampler in fp32).  Same reduced models, states and inputs as g4 (the states are read back from the g4 files);
+    stored: output, loss, input-gradient subsample and every parameter gradient - the pins of the PARADIS_GEMM_BF16
+    path (tests/test_hip_amp.py) at a bf16-level tolerance."""
+    for variant in ("a", "b"):
+        cfg, model, lat_deg, lg, og = build_model(variant)
+        g4 = torch.load(os.path.join(HERE, f"g4_model_{variant}.pt"), weights_only=False)
+        model.load_state_dict(g4["state"])
+        loss_fn, _, _ = loss_pieces(cfg, lat_deg)
+        B = 2
+        x = seeded(1234, B, 186, lg.shape[0], lg.shape[1])
+        x[:, -2] = lg
+        x[:, -1] = og
+        tgt = seeded(1235, B, 97, lg.shape[0], lg.shape[1])
+        x.requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y = model(x)
+            loss = loss_fn(y, tgt)
+        loss.backward()
+        rec = {"variant": VARIANTS[variant], "chk": chk(x.detach()) + chk(tgt), "y_dtype": str(y.dtype),
+               "y": y.detach().float(), "loss": loss.detach().float(), "gx_sub": x.grad[:, ::9].clone(),
+               "grads": {k: p.grad.clone() for k, p in model.named_parameters()}}
+        torch.save(rec, os.path.join(HERE, f"g7_amp_{variant}.pt"))
+
+
 def g5_manifest():
     cfg = load_cfg()
     _, lg, og = grid(32, 64, False)
@@ -355,9 +384,9 @@ def c2_rollout():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "c2"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "c2", "g7"]
     fns = {"g1": g1_pad, "g2": g2_advect, "g3": g3_blocks, "g4": g4_models, "g5": g5_manifest,
-           "g6": g6_loss, "c2": c2_rollout}
+           "g6": g6_loss, "c2": c2_rollout, "g7": g7_amp}
     for w in which:
         fns[w]()
         print("wrote", w)

@@ -1,0 +1,162 @@
+"""The reference's SHIPPED training mode on the GPU: bf16-mixed precision.
+
+``config/paradis_settings.yaml:75`` sets ``use_amp: true``, which ``train.py:56`` turns into Lightning's
+``precision="bf16-mixed"``: forward and loss run under ``torch.autocast(dtype=torch.bfloat16)``.  Autocast sends every
+``nn.Conv2d`` of the model (model/blocks.py:86,107-110: the pointwise GEMMs and the depthwise stencils) through bf16
+operands and a bf16 result and keeps ``grid_sampler`` in fp32.  Here, inside ``torch.autocast("cuda", torch.bfloat16)``
+the pointwise GEMMs - 80 % of the fp32 step - run ``PARADIS_GEMM_BF16``: operands rounded to bf16, ONE product on
+v_mfma_f32_32x32x16_bf16, fp32 accumulate, results rounded to bf16 where the reference's conv2d / activation round them;
+advection, stencils and norms stay fp32 (never narrower than the reference's).  It is never the arithmetic of the fp32
+headline (bench.py reports it as its own leg, labelled).
+
+Pins: goldens of the reference model under CPU autocast (tests/golden/make_golden.py g7), at a bf16-level tolerance that
+is MEASURED against the mode's own noise floor: the distance between the reference's bf16-mixed result and its fp32 result
+(forward 0.7-0.9e-2 rms, gradients 1e-2 in the median).  Two bf16-mixed implementations that round at different places
+are two realisations of that noise (the CPU oracle run under the same CPU autocast sits 0.7-0.8e-2 from the reference's
+autocast output - as far as that is from fp32), so the protocol, the fp64 protocol of SURVEY 8c(iii) one level down, is:
+  (i)  the HIP bf16-mixed result is not further from the reference's FP32 result than the reference's own bf16-mixed
+       result is (it rounds in fewer places: stencils, norms and advection stay fp32), and
+  (ii) it is within 1.5 x that noise floor of the reference's bf16-mixed result (sqrt(2) for two independent realisations).
+"""
+import pytest
+import torch
+
+from paradis_model_amd.config import reduced_config
+from tests._util import assert_chk, load_golden, rms_rel, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def test_bf16_scheme_is_the_rounded_product():
+    """``pointwise(scheme=GEMM_BF16)``: y = bf16(act(bf16(W_bf16 x_bf16 + b))) with the product accumulated in fp32,
+    dX = bf16(W_bf16^T dz_bf16 . act'(z)), dW = sum dz_bf16 x_bf16^T in fp32 (not rounded: parameter gradients are fp32).
+    Against an fp64 evaluation of the same rounded operands: equal up to the fp32 accumulation (<= 2e-6 before the final
+    rounding, so after it all but a few boundary cases agree exactly and none is further than one bf16 ulp)."""
+    from paradis_model_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (B, Ci, Co, H, W) in ((2, 186, 64, 16, 32), (1, 1024, 896, 32, 64), (3, 130, 258, 9, 20)):
+        x = torch.randn(B, Ci, H, W, generator=g).cuda()
+        w = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda()
+        b = (torch.randn(Co, generator=g) * 0.1).cuda()
+        ct = torch.randn(B, Co, H, W, generator=g).cuda()
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = ops.pointwise(xr, wr, b, act="SiLU", scheme=ops.GEMM_BF16)
+        y.backward(ct)
+        xb, wb = _bf16(x).double(), _bf16(w).double()
+        z = _bf16((torch.einsum("oc,bchw->bohw", wb, xb) + b.double()[None, :, None, None]).float())
+        want = _bf16(torch.nn.functional.silu(z.double()).float())
+        bad = (y - want).abs() > 1e-5 * want.abs().clamp_min(1e-3)
+        # (a boundary flip of z's rounding moves silu(z) by up to z silu'(z) / silu(z) ~ 2 ulps of bf16, plus the output's own)
+        assert float(bad.float().mean()) < 2e-3 and float(((y - want).abs() / want.abs().clamp_min(1e-2)).max()) <= 2.0 ** -5
+        # backward: dz = bf16(ct) ... the activation gradient is applied in fp32 on the bf16 cotangent, then rounded
+        zd = z.double().requires_grad_(True)
+        torch.nn.functional.silu(zd).backward(ct.double())
+        dz = zd.grad
+        dzb = _bf16(dz.float()).double()
+        gx = torch.einsum("oc,bohw->bchw", wb, dzb)
+        gw = torch.einsum("bohw,bchw->oc", dzb, xb)
+        assert rms_rel(xr.grad, gx) <= 3e-3, rms_rel(xr.grad, gx)        # one more bf16 rounding of the result: 2^-9 / sqrt(3)
+        assert rms_rel(wr.grad, gw) <= 3e-3, rms_rel(wr.grad, gw)        # (dz is rounded once more inside the kernel)
+
+
+def test_autocast_selects_the_bf16_scheme_and_only_there():
+    from paradis_model_amd import ops
+    assert ops.autocast_scheme(ops.GEMM_BF16X3) == ops.GEMM_BF16X3
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert ops.autocast_scheme(ops.GEMM_BF16X3) == ops.GEMM_BF16
+        with torch.autocast("cuda", enabled=False):
+            assert ops.autocast_scheme(ops.GEMM_BF16X3) == ops.GEMM_BF16X3
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert ops.autocast_scheme(ops.GEMM_EXACT) == ops.GEMM_EXACT          # fp16 autocast: fp32 arithmetic
+    assert "bf16" not in ops._SCHEMES                                          # PARADIS_GEMM cannot name it
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 64, 8, 16, generator=g).cuda()
+    w = (torch.randn(48, 64, generator=g) * 0.1).cuda()
+    y32 = ops.pointwise(x, w)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = ops.pointwise(x, w)
+    assert y16.dtype == torch.float32 and torch.equal(y16, _bf16(y16))         # bf16 VALUES, stored as fp32
+    assert 1e-4 < rms_rel(y16, y32) < 2e-2
+
+
+@pytest.mark.parametrize("variant", ["a", "b"])
+def test_reduced_model_bf16_mixed_vs_reference_autocast_golden(variant):
+    from paradis_model_amd.loss import build_loss
+    from tests.test_hip_model import _build
+    rec, amp = load_golden(f"g4_model_{variant}.pt"), load_golden(f"g7_amp_{variant}.pt")
+    v = rec["variant"]
+    cfg = reduced_config(activation=v["activation"], adv_interpolation=v["adv_interpolation"],
+                         coarsening_factor=v["coarsening_factor"])
+    lg, og = rec["lat_grid"], rec["lon_grid"]
+    model = _build(cfg, lg, og, rec["state"])
+    x = seeded(rec["x_seed"], rec["B"], 186, v["nlat"], v["nlon"])
+    x[:, -2] = lg
+    x[:, -1] = og
+    tgt = seeded(rec["target_seed"], rec["B"], 97, v["nlat"], v["nlon"])
+    assert_chk([x, tgt], amp["chk"])
+    loss_fn = build_loss(cfg, rec["lat_deg"]).cuda()
+    xd = x.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = model(xd)
+        loss = loss_fn(y, tgt.cuda())
+    loss.backward()
+    yc = y.detach().float().cpu()
+    floor = rms_rel(amp["y"], rec["y"])                    # the mode's own noise: reference bf16-mixed vs reference fp32
+    e = rms_rel(yc, amp["y"])
+    d32 = rms_rel(yc, rec["y"])
+    print("MEASURED bf16-mixed %s: forward rms vs reference-autocast %.2e (noise floor %.2e; vs reference fp32 %.2e)"
+          % (variant, e, floor, d32))
+    assert e <= 1.5 * floor, (e, floor)
+    assert d32 <= 1.0 * floor and d32 >= 0.05 * floor, (d32, floor)       # ... and it IS the bf16 path
+    assert abs(float(loss) - float(amp["loss"])) <= 3.0 * abs(float(amp["loss"]) - float(rec["loss"])) + 2e-4
+    egx, fgx = rms_rel(xd.grad.cpu()[:, ::9], amp["gx_sub"]), rms_rel(amp["gx_sub"], rec["gx_sub"])
+    assert egx <= 1.5 * fgx, (egx, fgx)
+    assert rms_rel(xd.grad.cpu()[:, ::9], rec["gx_sub"]) <= 1.0 * fgx
+    ratios, errs, floors, d32s = [], [], [], []
+    for n, p in model.named_parameters():
+        gref = amp["grads"][n]
+        if float(gref.abs().max()) == 0:
+            continue
+        ee, ff = rms_rel(p.grad.cpu(), gref), rms_rel(gref, rec["grads"][n])
+        errs.append(ee); floors.append(ff); ratios.append((ee / max(ff, 1e-12), n))
+        d32s.append(rms_rel(p.grad.cpu(), rec["grads"][n]))
+    errs.sort(); floors.sort(); ratios.sort(); d32s.sort()
+    med_e, med_f = errs[len(errs) // 2], floors[len(floors) // 2]
+    print("MEASURED bf16-mixed %s: parameter gradients, norm-wise vs reference-autocast: median %.2e, max %.2e (floor: median "
+          "%.2e, max %.2e); largest ratio %.2f (%s)" % (variant, med_e, errs[-1], med_f, floors[-1], *ratios[-1]))
+    assert med_e <= 1.5 * med_f, (med_e, med_f)
+    assert d32s[len(d32s) // 2] <= 1.0 * med_f, (d32s[len(d32s) // 2], med_f)
+    assert errs[-1] <= 2.0 * floors[-1], (errs[-1], floors[-1])
+
+
+def test_bf16_mixed_training_step_runs_and_is_captured():
+    """forward + loss under autocast, backward, AdamW: eager and replayed from a HIP graph give the same parameters
+    (the scheme is an argument of the captured ops, the autocast state only matters while the step is built)."""
+    from paradis_model_amd.config import stub_datamodule
+    from paradis_model_amd.harness import GraphedTrainStep, TrainStep, synthetic_batch
+    from paradis_model_amd.loss import build_loss
+    from paradis_model_amd.model import Paradis
+    from tests._util import make_grid, max_rel
+    cfg = reduced_config()
+    lat_deg, lg, og = make_grid(16, 32, False)
+
+    def setup(capturable):
+        torch.manual_seed(42)
+        model = Paradis(stub_datamodule(cfg), cfg, lg, og).cuda()
+        return model, TrainStep(model, build_loss(cfg, lat_deg).cuda(), cfg, capturable=capturable, amp=True)
+    batch = synthetic_batch(16, 32, False, 2, 1, seed=5, device="cuda")
+    me, se = setup(False)
+    mg, sg = setup(True)
+    g = GraphedTrainStep(sg, batch, warmup=2)
+    le = [float(se(batch)) for _ in range(5)]
+    lg_ = [float(g(batch)) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(le[2:], lg_)), (le, lg_)
+    pe = torch.cat([p.detach().flatten() for p in me.parameters()])
+    pg = torch.cat([p.detach().flatten() for p in mg.parameters()])
+    assert max_rel(pg, pe) <= 1e-6
+    assert le[-1] < le[0]            # and it trains

@@ -121,11 +121,15 @@ def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode, strips):
     B, K = 2, 4
     _, lg, og = make_grid(H, W, poles)
     f, u, v, ct = (seeded(50 + i, B, K, H, W) for i in range(4))
+    _check_vs_fp64_oracle(ops, f, u, v, ct, lg, og, mode, strips)
+
+
+def _check_vs_fp64_oracle(ops, f, u, v, ct, lg, og, mode, strips, force_gmem=False):
     geo = O.GridGeometry(lg.double(), og.double())
     fd, ud, vd = (t.double().requires_grad_(True) for t in (f, u, v))
     yr = O.sl_advect_core(fd, ud, vd, 0.196887, geo, mode)
     yr.backward(ct.double())
-    y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, 0.196887, mode, False, strips=strips)
+    y, gf, gu, gv = _run_advect(ops, f, u, v, ct, lg, og, 0.196887, mode, force_gmem, halo=None, strips=strips)
     # fp32 coordinate rounding is amplified by the grid size: judge against the CPU fp32 oracle's
     # own distance to fp64 (SURVEY.md 8c iii)
     f32, u32, v32 = (t.clone().requires_grad_(True) for t in (f, u, v))
@@ -145,6 +149,64 @@ def test_advect_backward_vs_fp64_oracle(ops, H, W, poles, mode, strips):
         # (the 0.999 quantile already sits among the ill-conditioned points: factor 2 there)
         assert bool((e_gpu <= torch.tensor([1.5, 1.5, 2.0]) * e_cpu + 1e-8).all()), (name, e_gpu.tolist(), e_cpu.tolist())
         assert rms_rel(got, g64) <= 8 * rms_rel(g32, g64) + 1e-5, name
+
+
+def _jet_velocities(B, K, H, W, lg, seed, jet_cells=14.0, pert_cells=2.0, dt=0.196887):
+    """coherent flow, what a trained model's velocity fields look like next to white noise: a zonal jet of `jet_cells`
+    columns per step at the equator (cos^2 profile in the rotated-frame angle) + smooth perturbations of a few cells"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    cells = 2 * 3.14159265358979 / W
+    base = torch.randn(B, 2 * K, H // 8 + 2, W // 8 + 2, generator=g)
+    sm = F.interpolate(base, size=(H, W), mode="bicubic", align_corners=False) * (pert_cells * cells / dt)
+    u = sm[:, :K] - jet_cells * cells / dt * torch.cos(lg)[None, None] ** 2      # (departure = arrival - u dt: eastward shift)
+    v = 0.5 * sm[:, K:]
+    return u.contiguous(), v.contiguous()
+
+
+@pytest.mark.parametrize("H,W,poles,mode,strips", [(128, 256, False, "bicubic", False), (128, 256, False, "bicubic", True),
+                                                   (128, 256, False, "bilinear", True), (181, 360, True, "bicubic", False),
+                                                   (64, 130, False, "bicubic", True)])
+def test_advect_departure_centred_windows(ops, H, W, poles, mode, strips, monkeypatch):
+    """Round 5 (verdict r4 item 3): with a coherent flow - a 22-column jet, beyond 1.5 x the 10-column forward halo of these grids -
+    the row groups of a strip shift their windows onto the mean departure column (adv_strip_shift_kernel) and the
+    shifted variants of the ring-strip kernels run: same parity bounds as every other schedule (fp64 protocol), the class
+    words say the shifted variants ran, and the shifts follow the jet.  strips: the backward's 128-column strips where
+    the full circle would run.  (64, 130): a ragged second strip, forced onto the windowed schedule."""
+    from paradis_model_amd._lib import lib
+    B, K = 2, 3
+    _, lg, og = make_grid(H, W, poles)
+    f, ct = seeded(61, B, K, H, W), seeded(62, B, K, H, W)
+    u, v = _jet_velocities(B, K, H, W, lg, 63, jet_cells=22.0)           # (beyond 1.5 forward halos of 10 columns)
+    seen = []
+    keep = ops._ws
+
+    def spy(nbytes, device):
+        t = keep(nbytes, device)
+        seen.append(t)
+        return t
+    monkeypatch.setattr(ops, "_ws", spy)
+    force = H * W < 20000           # small planes fit LDS whole: force the windowed schedule
+    _check_vs_fp64_oracle(ops, f, u, v, ct, lg, og, mode, strips, force_gmem=force)
+    flags = ops.advect_flags(tiled=force, strips=strips) | ops.ADVECT_SEPARABLE
+    off = lib.paradis_sl_advect_ws_shift_offset(B, K, H, W, flags)
+    assert off > 0
+    nstrips, NG = B * K * ((W + 127) // 128), (H + 7) // 8
+    ws = seen[0].view(torch.int32)          # the forward's workspace
+    tab = ws[off // 4: off // 4 + nstrips * NG].view(nstrips, NG).cpu()
+    cls = ws[off // 4 + nstrips * NG: off // 4 + nstrips * NG + nstrips].cpu()
+    full = torch.tensor([min(128, W - 128 * (i % ((W + 127) // 128))) >= 16 for i in range(nstrips)])
+    assert bool((cls[full] == 1).all()) and int(cls[~full].sum()) == 0, cls.tolist()    # (a 2-column strip decides nothing)
+    # mid-latitude groups follow the jet: 22 cos(lat) columns eastward departure -> window shift of that sign and size
+    mid = tab[full][:, NG // 2].float()
+    assert float(mid.abs().min()) >= 15 and float(mid.abs().max()) <= 29, mid.tolist()
+    # white noise must NOT shift (the 4-sigma coherence test): same shapes, N(0,1) velocities
+    seen.clear()
+    un, vn = seeded(64, B, K, H, W), seeded(65, B, K, H, W)
+    _run_advect(ops, f, un, vn, ct, lg, og, 0.196887, mode, force, halo=None, strips=strips)
+    ws = seen[0].view(torch.int32)
+    cls = ws[off // 4 + nstrips * NG: off // 4 + nstrips * NG + nstrips].cpu()
+    assert int(cls.sum()) <= max(1, nstrips // 8), cls.tolist()        # (a statistical test: ~1 % false positives per strip)
 
 
 def test_advect_channel_slice_inputs(ops):
