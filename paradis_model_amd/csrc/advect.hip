@@ -1902,25 +1902,36 @@ __device__ __forceinline__ bool tap_block_ring_u(float ix, float iy, float Hpf, 
 constexpr float SHIFT_MIN_MEAN = 3.0f, SHIFT_CLAMP = 96.f;
 constexpr int SHIFT_BATCH = 6;          // passes of sixteen (strip, row group) pairs whose samples a workgroup has in flight
 constexpr int SHIFT_MAX_STRIPS = 256;   // strips per plane the class words of one workgroup cover (W <= 32768)
+constexpr int SHIFT_MAX_PAIRS = 8192;   // (strip, row group) pairs of a plane whose shifts pass through LDS (32 KB)
 // One workgroup per PLANE (a launch of planes x strips workgroups with a handful of loads each cost 0.12 ms at
 // 721 x 1440: pure latency): its sixteen 16-lane groups walk the plane's (strip, row group) pairs.
-// min_mean: the smallest mean displacement worth a shift, relative to the longitude halo of the kernel that will use the
-// table (the shifted forward variants cost ~20 % more per point: a 12-column jet inside a 32-column halo needs none).
+// Samples of a pair: two clusters of eight consecutive columns (one 32-byte sector of u and of v each) at a quarter and
+// at three quarters of the strip, the group's middle row - 0.125 B of extra traffic per gather point.
+// What counts as COHERENT (a model at random init produces velocity NOISE with a correlation length of a few cells - the
+// 5 x 5 stencils of the velocity network - and 9-40 column displacements: sixteen adjacent samples of that look coherent
+// one time in ten):
+//   * the two clusters, 64 columns apart, agree: |mA - mB| <= |mean| / 2, and neither scatters more than the mean;
+//   * |mean| >= min_mean, relative to the longitude halo of the kernel that will use the table (the shifted forward
+//     variants cost ~20 % more per point: a 12-column jet inside a 32-column halo needs no shift);
+//   * the row group is further than 6 degrees from a pole (displacements there scatter over the whole circle);
+//   * a NEIGHBOURING row group of the strip carries a similar shift (within max(4, |shift| / 2) columns): a flow is
+//     smooth in latitude, a fluke is not.
 __global__ void __launch_bounds__(256)
 adv_strip_shift_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ sin_lat,
                        const float* __restrict__ cos_lat, int* __restrict__ shifts, unsigned* __restrict__ cls, int K,
                        AdvGeom g, int64_t uv_bs, int strips, int NG, float min_mean) {
   __shared__ unsigned anys[SHIFT_MAX_STRIPS];
+  __shared__ int tab[SHIFT_MAX_PAIRS];
+  __shared__ unsigned char keep[SHIFT_MAX_PAIRS];
   const int H = g.H, W = g.W, P = H * W;
   const int plane = blockIdx.x;
   const int b = plane / K, k = plane - b * K;
   const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
   const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
   const int lane = threadIdx.x & 63;
-  // sixteen samples per pair: 16 consecutive columns (one 64-byte segment of u and of v) at the strip's centre, the
-  // group's middle row - 0.125 B of extra traffic per gather point
-  const int sl = lane & 15, quad = threadIdx.x >> 4;           // 16 quads of sixteen lanes
+  const int sl = lane & 15, quad = threadIdx.x >> 4;           // 16 quads of sixteen lanes; lanes 0-7 / 8-15: clusters A / B
   const int npairs = strips * NG;
+  const bool filter = npairs <= SHIFT_MAX_PAIRS;               // (larger planes: no neighbour test)
   int* out = shifts + (size_t)plane * npairs;
   for (int i = threadIdx.x; i < strips; i += 256) anys[i] = 0u;
   __syncthreads();
@@ -1932,7 +1943,7 @@ adv_strip_shift_kernel(const float* __restrict__ u, const float* __restrict__ v,
       const int strip = pi / NG, gi = pi - strip * NG;
       const int x0 = strip * STRIP_W, tw = min(STRIP_W, W - x0);
       const int y = min(8 * gi + 4, H - 1);
-      const int xs = x0 + min(max(tw / 2 - 8, 0) + sl, tw - 1);
+      const int xs = x0 + min(max((sl < 8 ? tw / 4 : (3 * tw) / 4) - 4 + (sl & 7), 0), tw - 1);
       lu[j] = U[y * W + xs]; lv[j] = V[y * W + xs];
     }
 #pragma unroll
@@ -1940,7 +1951,7 @@ adv_strip_shift_kernel(const float* __restrict__ u, const float* __restrict__ v,
       const int pi = p0 + 16 * j;
       const int pc = min(pi, npairs - 1);
       const int strip = pc / NG, gi = pc - strip * NG;
-      const int tw = min(STRIP_W, W - strip * STRIP_W), nsmp = min(tw, 16);
+      const int tw = min(STRIP_W, W - strip * STRIP_W);
       const int y = min(8 * gi + 4, H - 1);
       const float lam = lu[j] * g.ndt, phi = lv[j] * g.ndt;
       // longitude displacement in columns, small-angle form of atan2(cos phi' sin lam', cos phi' cos lam' cos lat -
@@ -1949,25 +1960,50 @@ adv_strip_shift_kernel(const float* __restrict__ u, const float* __restrict__ v,
       const float den = ca - phi * sin_lat[y * W];
       float dx = lam * g.cx / (fabsf(den) > 0.02f ? den : 0.02f);
       dx = fminf(fmaxf(dx, -SHIFT_CLAMP), SHIFT_CLAMP);                // (a NaN becomes -SHIFT_CLAMP: finite)
-      const bool smp = sl < nsmp;
-      float s1 = smp ? dx : 0.f, s2 = smp ? dx * dx : 0.f;
+      float s1 = dx, s2 = dx * dx;                                     // sums over this lane's cluster of eight
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      const float inv_n = 1.f / (float)nsmp;
-      const float mean = s1 * inv_n, var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+      for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      const float m = s1 * 0.125f, var = fmaxf(s2 * 0.125f - m * m, 0.f);
+      const float mo = __shfl_xor(m, 8, 64), varo = __shfl_xor(var, 8, 64);      // the other cluster's
+      const float mean = 0.5f * (m + mo);
       int sh = (int)rintf(mean);
-      // coherent flow only: |mean| >= 1.22 standard deviations of the sixteen samples (white noise: a 4.9 sigma event of
-      // their mean) and large enough to matter; never within 6 degrees of a pole (displacements there scatter over the
-      // whole circle); a ragged strip with fewer than sixteen columns decides nothing
-      if (!(nsmp >= 16 && fabsf(mean) >= min_mean && mean * mean >= 1.5f * var && fabsf(ca) > 0.1f)) sh = 0;
+      if (!(tw >= 64 && fabsf(mean) >= min_mean && fabsf(m - mo) <= 0.5f * fabsf(mean) && fmaxf(var, varo) <= mean * mean &&
+            fabsf(ca) > 0.1f))
+        sh = 0;
       sh = min(max(sh, -(W / 2 - 1)), W / 2 - 1);
       if (pi < npairs && sl == 0) {
-        out[pi] = sh;
-        if (sh != 0) atomicOr(&anys[strip], 1u);
+        if (filter) tab[pi] = sh;
+        else { out[pi] = sh; if (sh != 0) atomicOr(&anys[strip], 1u); }
       }
     }
   }
   __syncthreads();
+  if (filter) {
+    // neighbour test, then the strip's quorum: a strip runs the shifted variant - all its row groups pay for it - only
+    // when at least an eighth of its groups carry a shift; fewer are flukes of the noise (91 groups at 721 rows: one
+    // false positive in a thousand groups would otherwise send one strip in eleven to the slower variant)
+    for (int pi = threadIdx.x; pi < npairs; pi += 256) {
+      const int strip = pi / NG, gi = pi - strip * NG;
+      const int sh = tab[pi];
+      if (sh != 0) {
+        const int tol = max(4, abs(sh) / 2);
+        const int lo = gi > 0 ? tab[pi - 1] : 0, hi = gi + 1 < NG ? tab[pi + 1] : 0;
+        const bool ok = (lo != 0 && abs(lo - sh) <= tol) || (hi != 0 && abs(hi - sh) <= tol);
+        if (ok) atomicAdd(&anys[strip], 1u);
+        keep[pi] = ok ? 1 : 0;
+      } else {
+        keep[pi] = 0;
+      }
+    }
+    __syncthreads();
+    for (int pi = threadIdx.x; pi < npairs; pi += 256) {
+      const int strip = pi / NG;
+      out[pi] = (keep[pi] && 8u * anys[strip] >= (unsigned)NG) ? tab[pi] : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < strips; i += 256) cls[(size_t)plane * strips + i] = 8u * anys[i] >= (unsigned)NG ? 1u : 0u;
+    return;
+  }
   for (int i = threadIdx.x; i < strips; i += 256) cls[(size_t)plane * strips + i] = anys[i];
 }
 
@@ -2217,10 +2253,13 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
                     const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                     int64_t gf_bs, int64_t guv_bs, int hx, int strips, unsigned long long* __restrict__ gacc,
                     const unsigned* __restrict__ pmax, unsigned* __restrict__ queue, unsigned* __restrict__ counts,
-                    const int* __restrict__ shifts, const unsigned* __restrict__ cls) {
+                    const int* __restrict__ shifts, const unsigned* __restrict__ cls, const unsigned* __restrict__ wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ unsigned qcount;
   if ((cls[blockIdx.x] != 0u) != SH) return;          // (two variants launched back to back: workgroup-uniform)
+  // tall grids: the 32-row ring (two workgroups per CU) for planes whose latitude displacements it covers, the 64-row
+  // ring (one) for the others - the plane's class word (adv_dy_class_kernel); NULL = this launch takes every plane
+  if (wide != nullptr && (wide[blockIdx.x / strips] != 0u) != (R == 64)) return;
   using Ring = StripRing<MODE, R>;
   constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -3221,7 +3260,8 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   } else if (separable(flags, lat_cells) && strip_ok(W, flags)) {
     const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_bwd(W), true);
     const int strips = (W + STRIP_W - 1) / STRIP_W;
-    const size_t slds = ((size_t)ring * (STRIP_W + 2 * hx + NT) * 3 + 8 + ring) * sizeof(float);   // (+ the slots' window shifts)
+    auto slds_of = [&](int r) { return ((size_t)r * (STRIP_W + 2 * hx + NT) * 3 + 8 + r) * sizeof(float); };   // (+ the slots' window shifts)
+    const size_t slds = slds_of(ring);
     PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
     PD_REQUIRE((int64_t)planes * strips < (1ll << 31), "sl_advect_bwd: too many strips");
     PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_bwd: halo too wide");
@@ -3236,15 +3276,20 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
         return 2;
 #undef RESERVE_STRIP
     }
-#define LAUNCH_STRIP_BWD1(M, R_, D, SH_)                                                                            \
-    hipLaunchKernelGGL((sl_advect_bwd_strip<M, R_, D, SH_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS), slds, st, \
+#define LAUNCH_STRIP_BWD1(M, R_, D, SH_, WIDE_)                                                                     \
+    hipLaunchKernelGGL((sl_advect_bwd_strip<M, R_, D, SH_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS),   \
+                       slds_of(R_), st,                                                                                \
                        gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,      \
                        (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, hx, strips, gacc, (const unsigned*)pmax, \
-                       queue, counts, (const int*)shifts, (const unsigned*)cls)
-#define LAUNCH_STRIP_BWD(M, R_, D) do { LAUNCH_STRIP_BWD1(M, R_, D, false); LAUNCH_STRIP_BWD1(M, R_, D, true); } while (0)
+                       queue, counts, (const int*)shifts, (const unsigned*)cls, (const unsigned*)(WIDE_))
+#define LAUNCH_STRIP_BWD(M, R_, D, WIDE_) do { LAUNCH_STRIP_BWD1(M, R_, D, false, WIDE_); LAUNCH_STRIP_BWD1(M, R_, D, true, WIDE_); } while (0)
+    // tall grids (64-row ring: 126 KB, one workgroup per CU): planes whose latitude displacements fit the 32-row ring
+    // (63 KB, two workgroups per CU) run in it - adv_dy_class_kernel names the class of every plane (round 5)
+    unsigned* wide = nullptr;
 #define LAUNCH_STRIP_BWD_R(M, D)                                                                                     \
     do {                                                                                                               \
-      if (ring == 32) LAUNCH_STRIP_BWD(M, 32, D); else LAUNCH_STRIP_BWD(M, 64, D);                                    \
+      if (ring == 32) LAUNCH_STRIP_BWD(M, 32, D, nullptr);                                                            \
+      else { LAUNCH_STRIP_BWD(M, 32, D, wide); LAUNCH_STRIP_BWD(M, 64, D, wide); }                                    \
       hipLaunchKernelGGL((sl_advect_bwd_strip_fixup<M, D>), dim3((unsigned)(planes * strips)), dim3(256), 0, st, gout, \
                          field, u, v, gfield, gu, gv, sin_lat, cos_lat, lon, (const float*)fmeans, (const float*)gmeans, \
                          K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, strips, gacc, (const unsigned*)pmax,                 \
@@ -3260,6 +3305,12 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
     hipLaunchKernelGGL(adv_strip_shift_kernel, dim3((unsigned)planes), dim3(256), 0, st, u, v, sin_lat, cos_lat,
                        shifts, cls, K, g, uv_bs, strips, (H + STRIP_ROWS - 1) / STRIP_ROWS,
                        std::max(SHIFT_MIN_MEAN, 0.5f * (float)hx));
+    if (ring == 64) {
+      wide = counts + (size_t)planes * strips;      // class word per plane: behind the counts (adv_ws_queue)
+      const int hyl = mode == PARADIS_INTERP_BICUBIC ? 6 : 7;     // rows the 32-row ring covers below an arrival row
+      hipLaunchKernelGGL(adv_dy_class_kernel, dim3(planes), dim3(256), 0, st, v, wide, K, H, W, uv_bs,
+                         (float)hyl / (g.cy * fabsf(dt)));
+    }
     if (gacc) { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, true); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, true); }
     else { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, false); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, false); }
 #undef LAUNCH_STRIP_BWD_R
