@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 8: paradis_pw_gemm_wgrad_slabs, paradis_sl_advect_ws_shift_offset (queries; no signature changed); 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 8: PARADIS_GEMM_BF16 scheme, paradis_pw_gemm_wgrad_slabs (query); no signature changed; 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -83,12 +83,6 @@ int paradis_sl_advect_fwd(const float* field, const float* u, const float* v, fl
  * gather point; for the strip schedule it includes the lists of points whose taps leave the window: 12 bytes per gather
  * point). */
 size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W, int flags);
-/* Strip schedule, departure-centred windows (round 5, ABI 8): every group of eight arrival rows of a 128-column strip
- * samples its window around the mean longitude displacement of the group (a pre-pass over u, v writes the table;
- * coherent flow only).  Diagnostic query: byte offset inside the workspace of  int shifts[strips][ceil(H/8)]  followed by
- * unsigned cls[strips] (1 = the strip ran with shifted windows), strips = B K ceil(W/128), as the last forward /
- * backward call left them; 0 when the shape / flags do not run the strip schedule. */
-size_t paradis_sl_advect_ws_shift_offset(int B, int K, int H, int W, int flags);
 int paradis_sl_advect_bwd(const float* gout, const float* field, const float* u, const float* v,
                           float* gfield, float* gu, float* gv,
                           const float* sin_lat, const float* cos_lat, const float* lat_cells, const float* lon,

@@ -34,7 +34,6 @@ SIGNATURES = {
     "paradis_geocyclic_pad_bwd": (I, [P, P, L, I, I, I, P]),
     "paradis_sl_advect_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, F, F, F, F, F, I, I, P, P]),
     "paradis_sl_advect_ws_bytes": (S, [I, I, I, I, I]),
-    "paradis_sl_advect_ws_shift_offset": (S, [I, I, I, I, I]),
     "paradis_sl_advect_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L,
                                   F, F, F, F, F, I, I, P, P]),
     "paradis_dwconv_geo_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -1707,32 +1707,20 @@ __device__ __forceinline__ StripRow strip_row(int pr, int H, int p) {
   return r;
 }
 
-// column c + shift on the latitude circle (|shift| < W, c in [0, W))
-__device__ __forceinline__ int wrap_col(int c, int W) {
-  c += c < 0 ? W : 0;
-  c -= c >= W ? W : 0;
-  return c;
-}
-// shp: the row's window shift in columns (departure-centred windows, round 5; wave-uniform; 0 = the window sits on
-// the strip's own columns)
 __device__ __forceinline__ void strip_load_row(const float* __restrict__ F, int pr, int H, int W, int p, const StripCols& cs,
-                                               int nch, float (&pre)[STRIP_CH], int shp = 0) {
+                                               int nch, float (&pre)[STRIP_CH]) {
   const StripRow r = strip_row(pr, H, p);
   const global_ptr<const float> row = srow(F + (int64_t)r.sr * W);
 #pragma unroll
   for (int i = 0; i < STRIP_CH; ++i)
-    if (i < nch) {
-      const int c = (int)(r.mir ? (cs.pk[i] >> 16) : (cs.pk[i] & 0xffffu));
-      pre[i] = row[(unsigned)(shp == 0 ? c : wrap_col(c + shp, W))];
-    }
+    if (i < nch) pre[i] = row[r.mir ? (cs.pk[i] >> 16) : (cs.pk[i] & 0xffffu)];
 }
 
 __device__ __forceinline__ void strip_store_row(float* __restrict__ ring, int pr, int RMASK, int WS, int H, int p, float m0,
                                                 float m1, unsigned lane, int nch, const float (&pre)[STRIP_CH],
-                                                int cfirst = 0, int* rowsh = nullptr, int shp = 0) {
+                                                int cfirst = 0) {
   const StripRow r = strip_row(pr, H, p);
   float* dst = ring + (pr & RMASK) * WS;
-  if (rowsh != nullptr && lane == 0) rowsh[pr & RMASK] = shp;      // the slot remembers the window shift of its row
 #pragma unroll
   for (int i = 0; i < STRIP_CH; ++i)
     if (i < nch) {
@@ -1866,147 +1854,6 @@ __device__ __forceinline__ void strip_defer(bool defer, unsigned idx, unsigned* 
   }
 }
 
-// The same against a ring whose rows carry their own window shift (departure-centred windows): cw = window column of
-// tap (0, 0) relative to the window origin wx0f passed in (the strip's origin + the ARRIVAL row's shift), wrapped onto
-// the latitude circle but not clamped - every tap row adds its own (arrival shift - row shift) and checks its range.
-// Returns the row-range / plane-clamp part of the test.
-template <int MODE>
-__device__ __forceinline__ bool tap_block_ring_u(float ix, float iy, float Hpf, float Wpf, float Wf, float wx0f, float WSf,
-                                                 float rlof, float rhif, float& tx, float& ty, int& r0, int& cw) {
-  constexpr int NT = Interp<MODE>::NT, OFF0 = Interp<MODE>::OFF0;
-  tx = __builtin_amdgcn_fractf(ix);
-  ty = __builtin_amdgcn_fractf(iy);
-  const float x0f = ix - tx, y0f = iy - ty;
-  const float xc = __builtin_amdgcn_fmed3f(x0f, (float)(-OFF0), Wpf - (float)(NT + OFF0));
-  const float yc = __builtin_amdgcn_fmed3f(y0f, (float)(-OFF0), Hpf - (float)(NT + OFF0));
-  float rx = (xc + (float)OFF0) - wx0f;
-  const float ry = yc + (float)OFF0;
-  rx = rx < 0.f ? rx + Wf : (rx > WSf - (float)NT ? rx - Wf : rx);
-  const float ryc = __builtin_amdgcn_fmed3f(ry, rlof, rhif - (float)(NT - 1));
-  r0 = (int)ryc;
-  cw = (int)rx;           // (|rx| < 2 W: exact; a NaN came out of the clamps as a finite number)
-  return xc == x0f && yc == y0f && ryc == ry;
-}
-
-// ---- departure-centred windows (round 5) ---------------------------------------------------------------------------
-// The ring window of a strip sits on the strip's own columns (+- hx).  A coherent flow - a 12-cell zonal jet of a
-// trained model, not the white noise of a model at random init - moves EVERY point of a row group out of a 10 / 16
-// column halo and onto the deferred path (round 4: 721 x 1440 backward 20.7 -> 30.5 ms).  So every group of eight
-// arrival rows of a strip gets a window SHIFT in columns: the rounded mean longitude displacement of 64 sampled points
-// of the group (its middle row, the 64 centre columns of the strip; 0.5 B of extra traffic per gather point), taken
-// only where the flow is coherent: |mean| >= 3 columns and |mean| >= half the standard deviation of the sample (white
-// noise: a 4 sigma event).  A padded row is staged with the shift of the row group it belongs to and its ring slot
-// remembers it; a tap row is addressed relative to ITS shift.  Strips whose shifts are all zero run the kernels of
-// round 4 unchanged (cls = 0; the shifted variants are launched behind them and return at once, and vice versa).
-// Any shift table is correct - a point whose taps miss the shifted window is deferred like before.
-constexpr float SHIFT_MIN_MEAN = 3.0f, SHIFT_CLAMP = 96.f;
-constexpr int SHIFT_BATCH = 6;          // passes of sixteen (strip, row group) pairs whose samples a workgroup has in flight
-constexpr int SHIFT_MAX_STRIPS = 256;   // strips per plane the class words of one workgroup cover (W <= 32768)
-constexpr int SHIFT_MAX_PAIRS = 8192;   // (strip, row group) pairs of a plane whose shifts pass through LDS (32 KB)
-// One workgroup per PLANE (a launch of planes x strips workgroups with a handful of loads each cost 0.12 ms at
-// 721 x 1440: pure latency): its sixteen 16-lane groups walk the plane's (strip, row group) pairs.
-// Samples of a pair: two clusters of eight consecutive columns (one 32-byte sector of u and of v each) at a quarter and
-// at three quarters of the strip, the group's middle row - 0.125 B of extra traffic per gather point.
-// What counts as COHERENT (a model at random init produces velocity NOISE with a correlation length of a few cells - the
-// 5 x 5 stencils of the velocity network - and 9-40 column displacements: sixteen adjacent samples of that look coherent
-// one time in ten):
-//   * the two clusters, 64 columns apart, agree: |mA - mB| <= |mean| / 2, and neither scatters more than the mean;
-//   * |mean| >= min_mean, relative to the longitude halo of the kernel that will use the table (the shifted forward
-//     variants cost ~20 % more per point: a 12-column jet inside a 32-column halo needs no shift);
-//   * the row group is further than 6 degrees from a pole (displacements there scatter over the whole circle);
-//   * a NEIGHBOURING row group of the strip carries a similar shift (within max(4, |shift| / 2) columns): a flow is
-//     smooth in latitude, a fluke is not.
-__global__ void __launch_bounds__(256)
-adv_strip_shift_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ sin_lat,
-                       const float* __restrict__ cos_lat, int* __restrict__ shifts, unsigned* __restrict__ cls, int K,
-                       AdvGeom g, int64_t uv_bs, int strips, int NG, float min_mean) {
-  __shared__ unsigned anys[SHIFT_MAX_STRIPS];
-  __shared__ int tab[SHIFT_MAX_PAIRS];
-  __shared__ unsigned char keep[SHIFT_MAX_PAIRS];
-  const int H = g.H, W = g.W, P = H * W;
-  const int plane = blockIdx.x;
-  const int b = plane / K, k = plane - b * K;
-  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
-  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
-  const int lane = threadIdx.x & 63;
-  const int sl = lane & 15, quad = threadIdx.x >> 4;           // 16 quads of sixteen lanes; lanes 0-7 / 8-15: clusters A / B
-  const int npairs = strips * NG;
-  const bool filter = npairs <= SHIFT_MAX_PAIRS;               // (larger planes: no neighbour test)
-  int* out = shifts + (size_t)plane * npairs;
-  for (int i = threadIdx.x; i < strips; i += 256) anys[i] = 0u;
-  __syncthreads();
-  for (int p0 = quad; p0 < npairs; p0 += 16 * SHIFT_BATCH) {
-    float lu[SHIFT_BATCH], lv[SHIFT_BATCH];
-#pragma unroll
-    for (int j = 0; j < SHIFT_BATCH; ++j) {
-      const int pi = min(p0 + 16 * j, npairs - 1);
-      const int strip = pi / NG, gi = pi - strip * NG;
-      const int x0 = strip * STRIP_W, tw = min(STRIP_W, W - x0);
-      const int y = min(8 * gi + 4, H - 1);
-      const int xs = x0 + min(max((sl < 8 ? tw / 4 : (3 * tw) / 4) - 4 + (sl & 7), 0), tw - 1);
-      lu[j] = U[y * W + xs]; lv[j] = V[y * W + xs];
-    }
-#pragma unroll
-    for (int j = 0; j < SHIFT_BATCH; ++j) {
-      const int pi = p0 + 16 * j;
-      const int pc = min(pi, npairs - 1);
-      const int strip = pc / NG, gi = pc - strip * NG;
-      const int tw = min(STRIP_W, W - strip * STRIP_W);
-      const int y = min(8 * gi + 4, H - 1);
-      const float lam = lu[j] * g.ndt, phi = lv[j] * g.ndt;
-      // longitude displacement in columns, small-angle form of atan2(cos phi' sin lam', cos phi' cos lam' cos lat -
-      // sin phi' sin lat): an estimate is all that is needed (any shift is correct)
-      const float ca = cos_lat[y * W];
-      const float den = ca - phi * sin_lat[y * W];
-      float dx = lam * g.cx / (fabsf(den) > 0.02f ? den : 0.02f);
-      dx = fminf(fmaxf(dx, -SHIFT_CLAMP), SHIFT_CLAMP);                // (a NaN becomes -SHIFT_CLAMP: finite)
-      float s1 = dx, s2 = dx * dx;                                     // sums over this lane's cluster of eight
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      const float m = s1 * 0.125f, var = fmaxf(s2 * 0.125f - m * m, 0.f);
-      const float mo = __shfl_xor(m, 8, 64), varo = __shfl_xor(var, 8, 64);      // the other cluster's
-      const float mean = 0.5f * (m + mo);
-      int sh = (int)rintf(mean);
-      if (!(tw >= 64 && fabsf(mean) >= min_mean && fabsf(m - mo) <= 0.5f * fabsf(mean) && fmaxf(var, varo) <= mean * mean &&
-            fabsf(ca) > 0.1f))
-        sh = 0;
-      sh = min(max(sh, -(W / 2 - 1)), W / 2 - 1);
-      if (pi < npairs && sl == 0) {
-        if (filter) tab[pi] = sh;
-        else { out[pi] = sh; if (sh != 0) atomicOr(&anys[strip], 1u); }
-      }
-    }
-  }
-  __syncthreads();
-  if (filter) {
-    // neighbour test, then the strip's quorum: a strip runs the shifted variant - all its row groups pay for it - only
-    // when at least an eighth of its groups carry a shift; fewer are flukes of the noise (91 groups at 721 rows: one
-    // false positive in a thousand groups would otherwise send one strip in eleven to the slower variant)
-    for (int pi = threadIdx.x; pi < npairs; pi += 256) {
-      const int strip = pi / NG, gi = pi - strip * NG;
-      const int sh = tab[pi];
-      if (sh != 0) {
-        const int tol = max(4, abs(sh) / 2);
-        const int lo = gi > 0 ? tab[pi - 1] : 0, hi = gi + 1 < NG ? tab[pi + 1] : 0;
-        const bool ok = (lo != 0 && abs(lo - sh) <= tol) || (hi != 0 && abs(hi - sh) <= tol);
-        if (ok) atomicAdd(&anys[strip], 1u);
-        keep[pi] = ok ? 1 : 0;
-      } else {
-        keep[pi] = 0;
-      }
-    }
-    __syncthreads();
-    for (int pi = threadIdx.x; pi < npairs; pi += 256) {
-      const int strip = pi / NG;
-      out[pi] = (keep[pi] && 8u * anys[strip] >= (unsigned)NG) ? tab[pi] : 0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < strips; i += 256) cls[(size_t)plane * strips + i] = 8u * anys[i] >= (unsigned)NG ? 1u : 0u;
-    return;
-  }
-  for (int i = threadIdx.x; i < strips; i += 256) cls[(size_t)plane * strips + i] = anys[i];
-}
-
 // geometry of the ring: rows resident while the arrival rows [8 s, 8 s + 8) are computed
 template <int MODE, int R>
 struct StripRing {
@@ -2027,18 +1874,15 @@ struct StripRing {
 #ifndef STRIP_FWD_INLINE_FIXUP     // 1: a strip's workgroup processes its own deferred points; 0: a second launch does
 #define STRIP_FWD_INLINE_FIXUP 1
 #endif
-// SH: rows carry their own window shift (departure-centred windows); the strip runs in the variant its class word names
-template <int MODE, int R, bool SH>
-__global__ void __launch_bounds__(STRIP_THREADS, SH ? 6 : STRIP_FWD_WAVES)      // (shifted rows: 80 registers, no scratch)
+template <int MODE, int R>
+__global__ void __launch_bounds__(STRIP_THREADS, STRIP_FWD_WAVES)
 sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
                     float* __restrict__ out, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
                     const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
                     int K, AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int hx, int strips,
-                    unsigned* __restrict__ queue, unsigned* __restrict__ counts, const int* __restrict__ shifts,
-                    const unsigned* __restrict__ cls) {
+                    unsigned* __restrict__ queue, unsigned* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ unsigned qcount;
-  if ((cls[blockIdx.x] != 0u) != SH) return;          // (two variants launched back to back: workgroup-uniform)
   using Ring = StripRing<MODE, R>;
   constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
   const int H = g.H, W = g.W, p = g.p, P = H * W, Hp = H + 2 * p, Wp = W + 2 * p;
@@ -2054,17 +1898,10 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
   const int x0 = strip * STRIP_W, tw = min(STRIP_W, W - x0);
   const int WS = STRIP_W + 2 * hx + NT, wx0 = x0 + p - hx, nch = (WS + 63) >> 6;
   float* ring = smem;
-  int* const rowsh = SH ? reinterpret_cast<int*>(smem + R * WS) : nullptr;     // [R] window shift of the row in each slot
   const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
   const StripLane tl(wave & 1, lane, x0, tw, W);
   const int rw = wave >> 1;                          // this wave's arrival rows of a step: rw and rw + 4
   const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
-  const int* const shv = SH ? shifts + (size_t)blockIdx.x * nsteps : nullptr;
-  // window shift of padded row pr: that of the group of eight arrival rows it belongs to (wave-uniform)
-  auto shift_of = [&](int pr) -> int {
-    if constexpr (!SH) return 0;
-    else return __builtin_amdgcn_readfirstlane(shv[min(max((pr - p) >> 3, 0), nsteps - 1)]);
-  };
   const StripCols cs = strip_cols(wx0, WS, W, p, lane);
   const size_t qcap = (size_t)H * STRIP_W;
   unsigned* const q = queue + (size_t)blockIdx.x * 3 * qcap;    // this strip's lists of deferred points: index, ix, iy
@@ -2082,21 +1919,20 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
   float pre[STRIP_CH], pre2[STRIP_CH];
   const int lo0 = Ring::lo(0, p);
   for (int r8 = 0; r8 < RW; r8 += 2 * STRIP_ROWS) {
-    const int pa = lo0 + r8 + wave, pb = pa + STRIP_ROWS;
-    strip_load_row(F, pa, H, W, p, cs, nch, pre, shift_of(pa));
-    if (r8 + STRIP_ROWS < RW) strip_load_row(F, pb, H, W, p, cs, nch, pre2, shift_of(pb));
-    strip_store_row(ring, pa, RMASK, WS, H, p, m0, m1, lane, nch, pre, 0, rowsh, shift_of(pa));
-    if (r8 + STRIP_ROWS < RW) strip_store_row(ring, pb, RMASK, WS, H, p, m0, m1, lane, nch, pre2, 0, rowsh, shift_of(pb));
+    strip_load_row(F, lo0 + r8 + wave, H, W, p, cs, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_load_row(F, lo0 + r8 + STRIP_ROWS + wave, H, W, p, cs, nch, pre2);
+    strip_store_row(ring, lo0 + r8 + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_store_row(ring, lo0 + r8 + STRIP_ROWS + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre2);
   }
-  strip_load_row(F, lo0 + RW + wave, H, W, p, cs, nch, pre, shift_of(lo0 + RW + wave));      // the rows that enter at step 1
+  strip_load_row(F, lo0 + RW + wave, H, W, p, cs, nch, pre);      // the rows that enter at step 1
   __syncthreads();
 
   const float Hpf = (float)Hp, Wpf = (float)Wp, Wf = (float)W, wx0f = (float)wx0, WSf = (float)WS;
   for (int s = 0; s < nsteps; ++s) {
     const int lo = Ring::lo(s, p);
     // rows [lo + RW, lo + R): ring slots nobody reads during this step
-    strip_store_row(ring, lo + RW + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre, 0, rowsh, shift_of(lo + RW + wave));
-    if (s + 1 < nsteps) strip_load_row(F, lo + R + wave, H, W, p, cs, nch, pre, shift_of(lo + R + wave));
+    strip_store_row(ring, lo + RW + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (s + 1 < nsteps) strip_load_row(F, lo + R + wave, H, W, p, cs, nch, pre);
     const float rlof = (float)lo, rhif = (float)(lo + RW - 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -2111,14 +1947,7 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
         float ix, iy, tx, ty;
         departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
         int r0, c0;
-        bool fast;
-        int shy = 0;
-        if constexpr (SH) {
-          shy = shift_of(y + p);
-          fast = tap_block_ring_u<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f + (float)shy, WSf, rlof, rhif, tx, ty, r0, c0);
-        } else {
-          fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
-        }
+        const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
         // (a tap block outside the window reads a clamped, valid address; its value is dropped)
         float wx[NT], wy[NT];
         Interp<MODE>::weights(tx, wx);
@@ -2126,14 +1955,7 @@ sl_advect_fwd_strip(const float* __restrict__ field, const float* __restrict__ u
         float acc = 0.f;
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
-          const int slot = (r0 + a) & RMASK;
-          int cc = c0;
-          if constexpr (SH) {          // this tap row's window: the arrival row's column + (arrival shift - row shift)
-            const int c = c0 + shy - rowsh[slot];
-            cc = min(max(c, 0), WS - NT);
-            fast = fast && cc == c;
-          }
-          const float* base = ring + slot * WS + cc;
+          const float* base = ring + ((r0 + a) & RMASK) * WS + c0;
           float rowacc = 0.f;
 #pragma unroll
           for (int bb = 0; bb < NT; ++bb) rowacc = fmaf(base[bb], wx[bb], rowacc);
@@ -2244,7 +2066,7 @@ __device__ __forceinline__ int fixed_exponent(unsigned bits) {
   return e < -80 ? -80 : (e > 80 ? 80 : e);
 }
 
-template <int MODE, int R, bool DET, bool SH>
+template <int MODE, int R, bool DET>
 __global__ void __launch_bounds__(STRIP_THREADS, STRIP_BWD_WAVES)
 sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ field, const float* __restrict__ u,
                     const float* __restrict__ v, float* __restrict__ gfield, float* __restrict__ gu,
@@ -2253,12 +2075,12 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
                     const float* __restrict__ gmeans, int K, AdvGeom g, int64_t go_bs, int64_t f_bs, int64_t uv_bs,
                     int64_t gf_bs, int64_t guv_bs, int hx, int strips, unsigned long long* __restrict__ gacc,
                     const unsigned* __restrict__ pmax, unsigned* __restrict__ queue, unsigned* __restrict__ counts,
-                    const int* __restrict__ shifts, const unsigned* __restrict__ cls, const unsigned* __restrict__ wide) {
+                    const unsigned* __restrict__ wide) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ unsigned qcount;
-  if ((cls[blockIdx.x] != 0u) != SH) return;          // (two variants launched back to back: workgroup-uniform)
-  // tall grids: the 32-row ring (two workgroups per CU) for planes whose latitude displacements it covers, the 64-row
-  // ring (one) for the others - the plane's class word (adv_dy_class_kernel); NULL = this launch takes every plane
+  // tall grids (round 5): the 32-row ring (63 KB: two workgroups per CU) for planes whose latitude displacements it
+  // covers, the 64-row ring (126 KB: one) for the others - two launches back to back, a plane runs in the one its class
+  // word names (adv_dy_class_kernel), the other returns at once; NULL = this launch takes every plane
   if (wide != nullptr && (wide[blockIdx.x / strips] != 0u) != (R == 64)) return;
   using Ring = StripRing<MODE, R>;
   constexpr int NT = Interp<MODE>::NT, RW = Ring::RW, RMASK = R - 1;
@@ -2282,17 +2104,11 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);    // [R][WS] fixed-point sums
   float* ring = smem + 2 * wn;                                               // [R][WS] field window
   unsigned* stepmax = reinterpret_cast<unsigned*>(ring + wn);                // [3] max |cotangent| bits of a step
-  int* const rowsh = SH ? reinterpret_cast<int*>(stepmax + 4) : nullptr;     // [R] window shift of the row in each slot
   const float m0 = fmeans[2 * plane], m1 = fmeans[2 * plane + 1];
   const float gm0 = gmeans[2 * plane], gm1 = gmeans[2 * plane + 1];
   const StripLane tl(wave & 1, lane, x0, tw, W);
   const int rw = wave >> 1;
   const int nsteps = (H + STRIP_ROWS - 1) / STRIP_ROWS;
-  const int* const shv = SH ? shifts + (size_t)blockIdx.x * nsteps : nullptr;
-  auto shift_of = [&](int pr) -> int {       // window shift of padded row pr (see sl_advect_fwd_strip)
-    if constexpr (!SH) return 0;
-    else return __builtin_amdgcn_readfirstlane(shv[min(max((pr - p) >> 3, 0), nsteps - 1)]);
-  };
   const StripCols cs = strip_cols(wx0, WS, W, p, lane);
   unsigned* const q = queue + (size_t)blockIdx.x * 3 * (size_t)(H * STRIP_W);    // deferred points (see the forward)
   if (tid == 0) qcount = 0u;
@@ -2310,13 +2126,12 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
   float pre[STRIP_CH], pre2[STRIP_CH];
   const int lo0 = Ring::lo(0, p);
   for (int r8 = 0; r8 < RW; r8 += 2 * STRIP_ROWS) {
-    const int pa = lo0 + r8 + wave, pb = pa + STRIP_ROWS;
-    strip_load_row(F, pa, H, W, p, cs, nch, pre, shift_of(pa));
-    if (r8 + STRIP_ROWS < RW) strip_load_row(F, pb, H, W, p, cs, nch, pre2, shift_of(pb));
-    strip_store_row(ring, pa, RMASK, WS, H, p, m0, m1, lane, nch, pre, 0, rowsh, shift_of(pa));
-    if (r8 + STRIP_ROWS < RW) strip_store_row(ring, pb, RMASK, WS, H, p, m0, m1, lane, nch, pre2, 0, rowsh, shift_of(pb));
+    strip_load_row(F, lo0 + r8 + wave, H, W, p, cs, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_load_row(F, lo0 + r8 + STRIP_ROWS + wave, H, W, p, cs, nch, pre2);
+    strip_store_row(ring, lo0 + r8 + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (r8 + STRIP_ROWS < RW) strip_store_row(ring, lo0 + r8 + STRIP_ROWS + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre2);
   }
-  strip_load_row(F, lo0 + RW + wave, H, W, p, cs, nch, pre, shift_of(lo0 + RW + wave));
+  strip_load_row(F, lo0 + RW + wave, H, W, p, cs, nch, pre);
   __syncthreads();
   // bound on |cotangent| of step 0 (the pole rows' means ride along: they are what pole rows scatter)
   {
@@ -2343,7 +2158,6 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
     const StripRow r = strip_row(pr, H, p);
     unsigned long long* arow = acc + (pr & RMASK) * WS;
     const double inv = (double)inv_scale;
-    const int shp = shift_of(pr);
 #pragma unroll
     for (int i = 0; i < STRIP_CH; ++i)
       if (i < nch) {
@@ -2353,9 +2167,7 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
           if (sv != 0) {
             arow[lc] = 0ull;
             if (r.valid) {
-              int col = (int)(r.mir ? (cs.pk[i] >> 16) : (cs.pk[i] & 0xffffu));
-              if constexpr (SH) col = wrap_col(col + shp, W);
-              const int cell = r.sr * W + col;
+              const int cell = r.sr * W + (int)(r.mir ? (cs.pk[i] >> 16) : (cs.pk[i] & 0xffffu));
               if constexpr (DET) atomicAdd(&GA[cell], (unsigned long long)sv);
               else atomicAdd(&GF[cell], (float)((double)sv * inv));
             }
@@ -2383,8 +2195,8 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
     }
     // rows that left the window after step s - 1 go out; the rows entering at step s + 1 take their slots
     if (s > 0) flush_row(lo - STRIP_ROWS + wave);
-    strip_store_row(ring, lo + RW + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre, 0, rowsh, shift_of(lo + RW + wave));
-    if (s + 1 < nsteps) strip_load_row(F, lo + R + wave, H, W, p, cs, nch, pre, shift_of(lo + R + wave));
+    strip_store_row(ring, lo + RW + wave, RMASK, WS, H, p, m0, m1, lane, nch, pre);
+    if (s + 1 < nsteps) strip_load_row(F, lo + R + wave, H, W, p, cs, nch, pre);
     const float rlof = (float)lo, rhif = (float)(lo + RW - 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -2400,22 +2212,7 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
         DepState st;
         departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, &st);
         int r0, c0;
-        bool fast;
-        int cca[NT];
-        if constexpr (SH) {
-          const int shy = shift_of(y + p);
-          fast = tap_block_ring_u<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f + (float)shy, WSf, rlof, rhif, tx, ty, r0, c0);
-#pragma unroll
-          for (int a = 0; a < NT; ++a) {        // each tap row against its own window (see the forward)
-            const int c = c0 + shy - rowsh[(r0 + a) & RMASK];
-            cca[a] = min(max(c, 0), WS - NT);
-            fast = fast && cca[a] == c;
-          }
-        } else {
-          fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
-#pragma unroll
-          for (int a = 0; a < NT; ++a) cca[a] = c0;
-        }
+        const bool fast = tap_block_ring<MODE>(ix, iy, Hpf, Wpf, Wf, wx0f, WSf, rlof, rhif, tx, ty, r0, c0);
         const float gval = (y == 0) ? gm0 : ((y == H - 1) ? gm1 : cgo);
         float gix = 0.f, giy = 0.f;
         // (the sample coordinates ride along, as in the forward: the fix-up evaluates the gradient where the forward sampled)
@@ -2431,7 +2228,7 @@ sl_advect_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fi
             for (int bb = 0; bb < NT; ++bb) wxd[bb] = (double)wx[bb];
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
-              const int rb = ((r0 + a) & RMASK) * WS + cca[a];
+              const int rb = ((r0 + a) & RMASK) * WS + c0;
               float sxv = 0.f, sdx = 0.f;
               const double gwy = (double)(gs_ * wy[a]);
 #pragma unroll
@@ -2935,16 +2732,11 @@ static bool adv_uses_strips(int H, int W, int p, int flags) {
   return (flags & PARADIS_ADVECT_SEPARABLE) && !(flags & PARADIS_ADVECT_GENERIC) && strip_ok(W, flags) &&
          use_tiled(bwd_whole_lds((size_t)(H + 2 * p) * (W + 2 * p)), flags);
 }
-// window shifts of the strips' row groups + one class word per strip (departure-centred windows), behind the lists
-static size_t adv_ws_shift_bytes(size_t strips, int H) {
-  return ((strips * (size_t)((H + STRIP_ROWS - 1) / STRIP_ROWS + 1) * sizeof(int) + 255) & ~(size_t)255) + 256;
-}
 extern "C" size_t paradis_sl_advect_ws_bytes(int B, int K, int H, int W, int flags) {
   size_t n = adv_ws_base_bytes(B, K) + adv_ws_det_bytes(B, K, H, W) + 256;
   if (adv_uses_strips(H, W, 2, flags) || adv_uses_strips(H, W, 1, flags)) {
     const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
     n += 3 * strips * (size_t)H * STRIP_W * sizeof(unsigned) + (((strips + (size_t)B * K) * sizeof(unsigned) + 255) & ~(size_t)255) + 256;
-    n += adv_ws_shift_bytes(strips, H);
   }
   return n;
 }
@@ -2955,26 +2747,6 @@ static unsigned* adv_ws_queue(void* workspace, int B, int K, int H, int W, unsig
   const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
   *counts = (unsigned*)base;
   return (unsigned*)(base + (((strips + (size_t)B * K) * sizeof(unsigned) + 255) & ~(size_t)255));   // counts, class words, lists
-}
-// shift table [strips][NG] and class words [strips] (NG = row groups of eight)
-static int* adv_ws_shifts(void* workspace, int B, int K, int H, int W, unsigned** cls) {
-  unsigned* counts = nullptr;
-  unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
-  const size_t strips = (size_t)B * K * ((W + STRIP_W - 1) / STRIP_W);
-  char* base = (char*)(queue + 3 * strips * (size_t)H * STRIP_W);
-  base = (char*)(((uintptr_t)base + 255) & ~(uintptr_t)255);
-  const size_t NG = (size_t)(H + STRIP_ROWS - 1) / STRIP_ROWS;
-  *cls = (unsigned*)base + strips * NG;
-  return (int*)base;
-}
-// byte offset of the shift table inside the workspace (0 = this shape / these flags do not run the strip schedule):
-// int shifts[strips][NG] (NG = ceil(H / 8) row groups, strips = B K ceil(W / 128)), then unsigned cls[strips].
-// For tests and tools/adv_disp_stats.py: which strips ran with departure-centred windows, and where.
-extern "C" size_t paradis_sl_advect_ws_shift_offset(int B, int K, int H, int W, int flags) {
-  if (B < 1 || K < 1 || H < 4 || W < 4) return 0;
-  if (!(adv_uses_strips(H, W, 2, flags) || adv_uses_strips(H, W, 1, flags))) return 0;
-  unsigned* cls = nullptr;
-  return (size_t)((char*)adv_ws_shifts(nullptr, B, K, H, W, &cls) - (char*)nullptr);
 }
 inline int stream_blocks_adv(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 256 * 32); }
 
@@ -3058,40 +2830,25 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
     const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_fwd(W), false);
     const int strips = (W + STRIP_W - 1) / STRIP_W;
     const size_t slds = (size_t)ring * (STRIP_W + 2 * hx + NT) * sizeof(float);
-    const size_t slds_sh = slds + (size_t)ring * sizeof(int);          // + the slots' window shifts
     PD_REQUIRE((int64_t)planes * strips < (1ll << 31), "sl_advect_fwd: too many strips");
     PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_fwd: halo too wide");
     static PerDeviceOnce once_row;
     if (once_row.first()) {
-#define RESERVE_STRIP_FWD(M, R_) (reserve_lds(&sl_advect_fwd_strip<M, R_, false>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) || \
-                                  reserve_lds(&sl_advect_fwd_strip<M, R_, true>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX))
-      if (RESERVE_STRIP_FWD(PARADIS_INTERP_BICUBIC, 32) || RESERVE_STRIP_FWD(PARADIS_INTERP_BILINEAR, 32) ||
-          RESERVE_STRIP_FWD(PARADIS_INTERP_BICUBIC, 64) || RESERVE_STRIP_FWD(PARADIS_INTERP_BILINEAR, 64))
+      if (reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 32>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 32>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BICUBIC, 64>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX) ||
+          reserve_lds(&sl_advect_fwd_strip<PARADIS_INTERP_BILINEAR, 64>, "sl_advect_fwd: cannot reserve LDS", STRIP_LDS_MAX))
         return 2;
-#undef RESERVE_STRIP_FWD
     }
-    // departure-centred windows: the row groups' shifts and the strips' class words, then both variants of the strip
-    // kernel back to back (a strip runs in the one its class names, the other returns at once)
-    unsigned* cls = nullptr;
-    int* shifts = adv_ws_shifts(workspace, B, K, H, W, &cls);
-    // (forward: shifted rows cost ~20 % per point and a point beyond the halo is deferred at ~2.5 x the in-window cost:
-    //  worth it only for flows that leave the halo altogether)
-    PD_REQUIRE(strips <= SHIFT_MAX_STRIPS, "sl_advect_fwd: too many strips per plane");
-    hipLaunchKernelGGL(adv_strip_shift_kernel, dim3((unsigned)planes), dim3(256), 0, st, u, v, sin_lat, cos_lat,
-                       shifts, cls, K, g, uv_bs, strips, (H + STRIP_ROWS - 1) / STRIP_ROWS,
-                       std::max(SHIFT_MIN_MEAN, 1.5f * (float)hx));
-#define LAUNCH_STRIP_FWD1(M, R_, SH_)                                                                             \
-    hipLaunchKernelGGL((sl_advect_fwd_strip<M, R_, SH_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS),   \
-                       SH_ ? slds_sh : slds, st,                                                                    \
+#define LAUNCH_STRIP_FWD(M, R_)                                                                                   \
+    hipLaunchKernelGGL((sl_advect_fwd_strip<M, R_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS), slds, st, \
                        field, u, v, out, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans, K, g, f_bs, uv_bs,   \
-                       o_bs, hx, strips, queue, counts, (const int*)shifts, (const unsigned*)cls)
-#define LAUNCH_STRIP_FWD(M, R_) do { LAUNCH_STRIP_FWD1(M, R_, false); LAUNCH_STRIP_FWD1(M, R_, true); } while (0)
+                       o_bs, hx, strips, queue, counts)
     unsigned* counts = nullptr;
     unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
     if (mode == PARADIS_INTERP_BICUBIC) { if (ring == 32) LAUNCH_STRIP_FWD(PARADIS_INTERP_BICUBIC, 32); else LAUNCH_STRIP_FWD(PARADIS_INTERP_BICUBIC, 64); }
     else { if (ring == 32) LAUNCH_STRIP_FWD(PARADIS_INTERP_BILINEAR, 32); else LAUNCH_STRIP_FWD(PARADIS_INTERP_BILINEAR, 64); }
 #undef LAUNCH_STRIP_FWD
-#undef LAUNCH_STRIP_FWD1
     // the points whose tap block left the window, densely
     if (mode == PARADIS_INTERP_BICUBIC)
       hipLaunchKernelGGL((sl_advect_fwd_strip_fixup<PARADIS_INTERP_BICUBIC>), dim3((unsigned)(planes * strips)), dim3(256), 0, st,
@@ -3260,15 +3017,14 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
   } else if (separable(flags, lat_cells) && strip_ok(W, flags)) {
     const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_bwd(W), true);
     const int strips = (W + STRIP_W - 1) / STRIP_W;
-    auto slds_of = [&](int r) { return ((size_t)r * (STRIP_W + 2 * hx + NT) * 3 + 8 + r) * sizeof(float); };   // (+ the slots' window shifts)
+    auto slds_of = [&](int r) { return ((size_t)r * (STRIP_W + 2 * hx + NT) * 3 + 8) * sizeof(float); };
     const size_t slds = slds_of(ring);
     PD_REQUIRE(slds <= (size_t)STRIP_LDS_MAX, "sl_advect_bwd: window does not fit LDS");
     PD_REQUIRE((int64_t)planes * strips < (1ll << 31), "sl_advect_bwd: too many strips");
     PD_REQUIRE(STRIP_W + 2 * hx + NT <= STRIP_MAX_WS, "sl_advect_bwd: halo too wide");
     static PerDeviceOnce once_strip;
     if (once_strip.first()) {
-#define RESERVE_STRIP(M, R_, D) (reserve_lds(&sl_advect_bwd_strip<M, R_, D, false>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX) || \
-                                 reserve_lds(&sl_advect_bwd_strip<M, R_, D, true>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX))
+#define RESERVE_STRIP(M, R_, D) reserve_lds(&sl_advect_bwd_strip<M, R_, D>, "sl_advect_bwd: cannot reserve LDS", STRIP_LDS_MAX)
       if (RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 32, false) || RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 32, true) ||
           RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 64, false) || RESERVE_STRIP(PARADIS_INTERP_BICUBIC, 64, true) ||
           RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 32, false) || RESERVE_STRIP(PARADIS_INTERP_BILINEAR, 32, true) ||
@@ -3276,16 +3032,13 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
         return 2;
 #undef RESERVE_STRIP
     }
-#define LAUNCH_STRIP_BWD1(M, R_, D, SH_, WIDE_)                                                                     \
-    hipLaunchKernelGGL((sl_advect_bwd_strip<M, R_, D, SH_>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS),   \
+#define LAUNCH_STRIP_BWD(M, R_, D, WIDE_)                                                                           \
+    hipLaunchKernelGGL((sl_advect_bwd_strip<M, R_, D>), dim3((unsigned)(planes * strips)), dim3(STRIP_THREADS),        \
                        slds_of(R_), st,                                                                                \
                        gout, field, u, v, gfield, gu, gv, sin_lat, cos_lat, lat_cells, lon, (const float*)fmeans,      \
                        (const float*)gmeans, K, g, go_bs, f_bs, uv_bs, gf_bs, guv_bs, hx, strips, gacc, (const unsigned*)pmax, \
-                       queue, counts, (const int*)shifts, (const unsigned*)cls, (const unsigned*)(WIDE_))
-#define LAUNCH_STRIP_BWD(M, R_, D, WIDE_) do { LAUNCH_STRIP_BWD1(M, R_, D, false, WIDE_); LAUNCH_STRIP_BWD1(M, R_, D, true, WIDE_); } while (0)
-    // tall grids (64-row ring: 126 KB, one workgroup per CU): planes whose latitude displacements fit the 32-row ring
-    // (63 KB, two workgroups per CU) run in it - adv_dy_class_kernel names the class of every plane (round 5)
-    unsigned* wide = nullptr;
+                       queue, counts, (const unsigned*)(WIDE_))
+    unsigned* wide = nullptr;       // class word per plane on tall grids (64-row ring), see sl_advect_bwd_strip
 #define LAUNCH_STRIP_BWD_R(M, D)                                                                                     \
     do {                                                                                                               \
       if (ring == 32) LAUNCH_STRIP_BWD(M, 32, D, nullptr);                                                            \
@@ -3297,15 +3050,9 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
     } while (0)
     unsigned* counts = nullptr;
     unsigned* queue = adv_ws_queue(workspace, B, K, H, W, &counts);
-    unsigned* cls = nullptr;
-    int* shifts = adv_ws_shifts(workspace, B, K, H, W, &cls);      // departure-centred windows (see the forward)
-    // (backward: the shifted variant is no slower - 109 registers against 122 - and a deferred point costs sixteen
-    //  global float atomics: shift from half a halo on)
-    PD_REQUIRE(strips <= SHIFT_MAX_STRIPS, "sl_advect_bwd: too many strips per plane");
-    hipLaunchKernelGGL(adv_strip_shift_kernel, dim3((unsigned)planes), dim3(256), 0, st, u, v, sin_lat, cos_lat,
-                       shifts, cls, K, g, uv_bs, strips, (H + STRIP_ROWS - 1) / STRIP_ROWS,
-                       std::max(SHIFT_MIN_MEAN, 0.5f * (float)hx));
     if (ring == 64) {
+      // planes whose sampled |v dt| stays inside the 32-row ring's latitude halo (more than 15/16 of the points) run in
+      // it at two workgroups per CU: 721 x 1440 backward 20.7 -> 13.4 ms at small velocities (tools/advect_bench.py)
       wide = counts + (size_t)planes * strips;      // class word per plane: behind the counts (adv_ws_queue)
       const int hyl = mode == PARADIS_INTERP_BICUBIC ? 6 : 7;     // rows the 32-row ring covers below an arrival row
       hipLaunchKernelGGL(adv_dy_class_kernel, dim3(planes), dim3(256), 0, st, v, wide, K, H, W, uv_bs,
@@ -3315,7 +3062,6 @@ extern "C" int paradis_sl_advect_bwd(const float* gout, const float* field, cons
     else { if (cubic) LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BICUBIC, false); else LAUNCH_STRIP_BWD_R(PARADIS_INTERP_BILINEAR, false); }
 #undef LAUNCH_STRIP_BWD_R
 #undef LAUNCH_STRIP_BWD
-#undef LAUNCH_STRIP_BWD1
   } else if (separable(flags, lat_cells)) {
     if (gacc) { if (cubic) LAUNCH_TILEROW(PARADIS_INTERP_BICUBIC, true); else LAUNCH_TILEROW(PARADIS_INTERP_BILINEAR, true); }
     else { if (cubic) LAUNCH_TILEROW(PARADIS_INTERP_BICUBIC, false); else LAUNCH_TILEROW(PARADIS_INTERP_BILINEAR, false); }
