@@ -1624,6 +1624,9 @@ int launch_split_wide(const GemmArgs& d, int NT, hipStream_t st) {
 int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
   const int NT = (d.N + BN - 1) / BN;
   if (scheme == PARADIS_GEMM_BF16) {
+    // (a 256 x 128 tile - two M-tiles sharing one fp32 activation tile, 16 instead of 20 KB through L2 per tile pair -
+    //  measured SLOWER in the bf16-mixed step, 95.9 against 91.6 ms: with four MFMAs per wave and barrier the kernel is
+    //  bound by its per-tile latency chain, not by bytes; round 5, removed)
     if (NT < 2) return launch_split_np<1>(d, st);
     return launch_split_wide<1>(d, NT, st);
   }

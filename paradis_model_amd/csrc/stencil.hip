@@ -703,142 +703,6 @@ dwconv_geo_bwd_planes_kernel(const float* __restrict__ gy, const float* __restri
   }
 }
 
-// The same one-pass backward on TILED grids (round 5; 128 x 256 and up): the weight-gradient kernel's workgroup - one
-// channel, a chunk of the channel's (sample, tile) items, the K*K + 1 sums in registers across items - stages TWO
-// tiles per item, the cotangent with its geocyclic extension and x with its halo, and writes the item's tile of the
-// data gradient on the way.  The cotangent is read once (with its halo) instead of twice.  Same arithmetic in the same
-// order as dwconv_geo_dgrad_kernel and dwconv_geo_wgrad_kernel: bit-identical results.
-template <int K, bool ADD>
-__global__ void __launch_bounds__(256, 4)
-dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
-                            const float* __restrict__ addend, float* __restrict__ gx, float* __restrict__ partial,
-                            int B, int C, int H, int W, int tiles_x, int tiles, int chunks) {
-  constexpr int P = (K - 1) / 2, LW = TW + K - 1, NW = K * K + 1, TN = (TH + K - 1) * (TW + K - 1);
-  __shared__ float tg[TN], tx[TN];
-  __shared__ float red[4][NW];
-  const int c = blockIdx.x / chunks, chunk = blockIdx.x - c * chunks;
-  const int items = B * tiles;
-  const int xl = threadIdx.x & 63, wave = threadIdx.x >> 6, r0 = wave * RPT;
-  const float* wc = w + (int64_t)c * K * K;
-  float accw[K * K];
-#pragma unroll
-  for (int i = 0; i < K * K; ++i) accw[i] = 0.f;
-  float gsum = 0.f;
-  const int half = W >> 1;
-  for (int item = chunk; item < items; item += chunks) {
-    const int n = item / tiles, t = item - n * tiles;
-    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
-    const int64_t off = ((int64_t)n * C + c) * (int64_t)H * W;
-    const float* g = gy + off;
-    __syncthreads();
-    stage_tile<K, true>(tg, g, H, W, ty0, tx0);
-    stage_tile<K, true>(tx, x + off, H, W, ty0, tx0);
-    __syncthreads();
-    const int xx = tx0 + xl;
-    // ---- data gradient of this tile (dwconv_geo_dgrad_kernel)
-    {
-      float wr[K * K];
-#pragma unroll
-      for (int j = 0; j < K * K; ++j) wr[j] = wc[j];
-      float acc[RPT];
-#pragma unroll
-      for (int o = 0; o < RPT; ++o) acc[o] = 0.f;
-#pragma unroll
-      for (int rr = 0; rr < RPT + K - 1; ++rr) {
-        const int ii = ty0 + r0 + rr - P;   // image row of this tile row (wave-uniform)
-        float val[K];
-#pragma unroll
-        for (int b = 0; b < K; ++b) val[b] = tg[(r0 + rr) * LW + xl + b];
-        if (ii >= 0 && ii < H) {
-#pragma unroll
-          for (int a = 0; a < K; ++a) {
-            const int o = rr - a;
-            if (o >= 0 && o < RPT) {
-#pragma unroll
-              for (int b = 0; b < K; ++b) acc[o] += wr[(K - 1 - a) * K + (K - 1 - b)] * val[b];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < K; ++a) {
-            const int o = rr - a;
-            if (o >= 0 && o < RPT) {
-              const int yy = ty0 + r0 + o;
-              const bool feeds = (ii < 0) ? (yy >= 1) : (yy <= H - 2);
-              if (feeds) {
-#pragma unroll
-                for (int b = 0; b < K; ++b) acc[o] += wr[a * K + (K - 1 - b)] * val[b];
-              }
-            }
-          }
-        }
-      }
-      if (xx < W) {
-#pragma unroll
-        for (int o = 0; o < RPT; ++o) {
-          const int yy = ty0 + r0 + o;
-          if (yy < H) {
-            float extra = 0.f;
-            const bool south = yy >= 1 && yy <= P, north = yy >= H - 1 - P && yy <= H - 2;
-            if (south || north) {
-              const int a = south ? P - yy : P + (H - 1 - yy);
-              const int prow = south ? 0 : H - 1;
-#pragma unroll
-              for (int b = 0; b < K; ++b) {
-                int col = xx + P - b + half;
-                if (col >= W) col -= W;
-                if (col >= W) col -= W;
-                const float pv = tiles == 1 ? tg[(prow + P) * LW + col + P] : g[(int64_t)prow * W + col];
-                extra += wc[a * K + b] * pv;
-              }
-            }
-            const int64_t at = off + (int64_t)yy * W + xx;
-            gx[at] = ADD ? (acc[o] + extra) + addend[at] : acc[o] + extra;
-          }
-        }
-      }
-    }
-    // ---- weight gradient: this tile's share of the channel's sums (dwconv_geo_wgrad_kernel)
-    {
-      float gg[RPT];
-#pragma unroll
-      for (int o = 0; o < RPT; ++o) {
-        const int yy = ty0 + r0 + o;
-        gg[o] = (xx < W && yy < H) ? tg[(r0 + o + P) * LW + xl + P] : 0.f;
-        gsum += gg[o];
-      }
-#pragma unroll
-      for (int rr = 0; rr < RPT + K - 1; ++rr) {
-        float val[K];
-#pragma unroll
-        for (int b = 0; b < K; ++b) val[b] = tx[(r0 + rr) * LW + xl + b];
-#pragma unroll
-        for (int a = 0; a < K; ++a) {
-          const int o = rr - a;
-          if (o >= 0 && o < RPT) {
-#pragma unroll
-            for (int b = 0; b < K; ++b) accw[a * K + b] += gg[o] * val[b];
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < K * K; ++i) {
-    float sv = wave_sum_dpp(accw[i]);
-    if (xl == 0) red[wave][i] = sv;
-  }
-  {
-    float sv = wave_sum_dpp(gsum);
-    if (xl == 0) red[wave][K * K] = sv;
-  }
-  __syncthreads();
-  if (threadIdx.x < NW) {
-    float sv = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    partial[((int64_t)c * chunks + chunk) * NW + threadIdx.x] = sv;
-  }
-}
-
 __global__ void __launch_bounds__(256)
 dwconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ gw,
                     float* __restrict__ gbias, int C, int KK, int chunks) {
@@ -1116,27 +980,11 @@ extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const flo
   const bool fused = DWCONV_BWD_FUSED && DWCONV_PLANES && B > 0 && whole_plane_vec4(gy, H, W, k) &&
                      whole_plane_vec4(x, H, W, k) && (reinterpret_cast<uintptr_t>(gx) & 3) == 0 &&
                      (reinterpret_cast<uintptr_t>(addend) & 3) == 0;
-#ifndef DWCONV_BWD_TILES      // (0: the two kernels on tiled grids, for A/B runs)
-#define DWCONV_BWD_TILES 1
-#endif
   if (!fused) {
-    const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
-    if (DWCONV_BWD_TILES && B > 0 && k == 5 && tiles > 1) {
-      // tiled grids: one kernel, the cotangent read once (round 5); geocyclic staging of both tiles
-      const int chunks = wgrad_chunks(B, C, tiles);
-      float* partial = (float*)workspace;
-      hipStream_t st = (hipStream_t)stream;
-      if (addend)
-        hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend, gx,
-                           partial, B, C, H, W, tx, tiles, chunks);
-      else
-        hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, false>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend, gx,
-                           partial, B, C, H, W, tx, tiles, chunks);
-      const int n = C * (k * k + 1);
-      hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias, C, k * k, chunks);
-      PD_CHECK_LAUNCH("dwconv_geo_bwd(tiles)");
-      return 0;
-    }
+    // (tiled grids: a one-pass kernel in the weight-gradient kernel's shape - one channel per workgroup, (sample, tile)
+    //  items in a loop, both tiles staged per item - was built and measured in round 5: 1004 us per call at 128 x 256,
+    //  B = 8, C = 1024 (2014 us with the addend) against 628 + 483 us for the two kernels: a workgroup stages, waits,
+    //  computes, and 2,048 of them do not overlap that the way 131,072 one-tile workgroups of the data gradient do)
     if (int e = dwconv_geo_dgrad_launch(gy, w, addend, gx, B, C, H, W, k, stream)) return e;
     return paradis_dwconv_geo_wgrad(gy, x, gw, gbias, B, C, H, W, k, workspace, stream);
   }

@@ -192,16 +192,16 @@ def test_dwconv_geo_skip_adds_the_other_gradient_in_the_dgrad_kernel(ops, k, B, 
 
 @pytest.mark.parametrize("B,C,H,W,k", [(2, 6, 32, 64, 5), (5, 3, 16, 64, 5), (3, 1030, 32, 64, 5), (2, 5, 33, 64, 5),
                                        (2, 6, 12, 16, 3),
-                                       # tiled grids (round 5: dwconv_geo_bwd_tiles_kernel): several tiles, ragged tiles,
-                                       # pole rows in different tiles than the rows they mirror onto, many channels
+                                       # tiled grids: several tiles, ragged tiles, pole rows in different tiles than the
+                                       # rows they mirror onto, many channels
                                        (2, 6, 128, 256, 5), (1, 3, 70, 130, 5), (3, 5, 65, 64, 5), (2, 2100, 40, 72, 5),
                                        (1, 4, 181, 360, 5)])
 @pytest.mark.parametrize("add", [False, True])
 @pytest.mark.parametrize("bias", [False, True])
 def test_dwconv_geo_bwd_one_pass_is_bit_identical_to_the_two_kernels(ops, B, C, H, W, k, add, bias):
-    """paradis_dwconv_geo_bwd (ONE kernel reading the cotangent once: whole-plane grids since round 4, tiled grids with
-    k = 5 since round 5; other kernel sizes: the two kernels): same bits as dgrad (+ addend) and wgrad run apart - which
-    tests/test_dwconv_geo pins to the oracle."""
+    """paradis_dwconv_geo_bwd (whole-plane grids: ONE kernel reading the cotangent once; tiled grids: the two kernels - a
+    one-pass tiled kernel was built in round 5, bit-identical on exactly these shapes, and removed: 14 % slower):
+    same bits as dgrad (+ addend) and wgrad run apart - which tests/test_dwconv_geo pins to the oracle."""
     gy, x, w = seeded(1, B, C, H, W).cuda(), seeded(2, B, C, H, W).cuda(), seeded(3, C, 1, k, k, scale=1.0 / k).cuda()
     ad = seeded(4, B, C, H, W).cuda() if add else None
     gx, gw, gb = ops._dwconv_geo_bwd(gy, x, w, ad, bias)
