@@ -312,6 +312,9 @@ def main():
                          "not reference-width arithmetic, labelled as such in the output")
     ap.add_argument("--no-extra-legs", "--no-exact-leg", dest="no_extra_legs", action="store_true",
                     help="skip the extra timed loops (exact_f32_gemm, f16x2_emulated)")
+    ap.add_argument("--amp", action="store_true",
+                    help="run the HEADLINE leg in the reference's bf16-mixed mode (torch.autocast(bfloat16): one-product bf16 "
+                         "GEMMs) - a diagnostic: NOT reference-width arithmetic, labelled as such; skips the extra legs")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the bounded legs of the other BASELINE configs (other_configs: S = 6 rollout, 128x256 B = 8, "
                          "721x1440 forward)")
@@ -372,6 +375,8 @@ def main():
     torch.manual_seed(cfg.init.seed)
     model = Paradis(stub_datamodule(cfg), cfg, lg, og).to(dev)
     loss_fn = build_loss(cfg, lat_deg).to(dev)
+    if args.amp:
+        args.no_extra_legs = True
     if args.graph:
         if args.optimizer != "adamw":
             raise SystemExit("--graph: AdamW only")
@@ -381,7 +386,7 @@ def main():
     ddp = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, static_graph=args.static_graph,
                    capturable=args.graph)
     step = TrainStep(ddp, loss_fn, cfg, num_common=lay.num_common_features,
-                     n_inputs=cfg.dataset.n_time_inputs, capturable=args.graph)
+                     n_inputs=cfg.dataset.n_time_inputs, capturable=args.graph, amp=args.amp)
     batch = synthetic_batch(nlat, nlon, poles, B, S, seed=1234 + rank, device=dev)
     if args.graph and not args.forward_only:
         from paradis_model_amd.harness import GraphedTrainStep
@@ -582,7 +587,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.gemm != "f16x2" else "f32 storage, f16x2 block-exponent GEMM emulation", "data": "synthetic",
+        "dtype": ("bf16-mixed (NOT reference-width: the reference's AMP mode; one-product bf16 GEMMs, fp32 storage)" if args.amp
+                  else "f32" if args.gemm != "f16x2" else "f32 storage, f16x2 block-exponent GEMM emulation"),
+        "data": "synthetic",
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
                    "optimizer": args.optimizer, "parallelism": f"dp{world}",

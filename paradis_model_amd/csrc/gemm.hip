@@ -980,10 +980,6 @@ pw_gemm_split_kernel(GemmArgs g) {
       flip8(xs, x, flip);          // sign checkerboard: odd 64-column blocks are staged negated
       split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
-    } else if constexpr (NP == 1) {
-      float xs[8];
-      flip8(xs, x, flip);
-      o[0] = round8(xs);
     } else {
       u32x4 h, l;
       split8_f16(x, sc_b, h, l);   // (the column's sign rides on the scale)
@@ -1039,7 +1035,7 @@ pw_gemm_split_kernel(GemmArgs g) {
     if (dmaA) issueA(t + DA);
     if (ldB) fetchB(t + 2, xload);
     // xsplit (tile t+1) was loaded a step ago; younger operations: this step's NP DMA and 8 loads
-    if (dmaA && ldB) { if constexpr (NP == 3) USE_X(xsplit, 11); else if constexpr (NP == 2) USE_X(xsplit, 10); else USE_X(xsplit, 9); }
+    if (dmaA && ldB) { if constexpr (NP == 3) USE_X(xsplit, 11); else USE_X(xsplit, 10); }
     else if (ldB) USE_X(xsplit, 8);
     else USE_X(xsplit, 0);
     // The fragment reads sit in the block of the MFMAs (behind the branches above the compiler's lgkmcnt
@@ -1052,13 +1048,11 @@ pw_gemm_split_kernel(GemmArgs g) {
     split_tile_mfma<NP>(f, acc);
     split_store(xsplit, Bst + (cur ^ 1) * SIMG);
     // without this pinning, the training step 0.9 % slower (tools/ab_step.sh, same box, 3 of 3 rounds).
-    if constexpr (NP > 1) {
     __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
 #pragma unroll
     for (int i = 0; i < (NP == 3 ? 24 : 12); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 3 : 2, 0);
-    }
     }
     // weight tile t+1 landed (its DMA is DA steps old: 8 loads of that step + 8 + NP operations per step since
     // are younger), own ds_writes done, the loads of t+2 and the younger DMAs still in flight
@@ -1106,8 +1100,7 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
 
   // the weight tile (SIMG = 256 NP chunks of 16 bytes) goes by LDS-DMA, one chunk per thread and piece: f16x2 one
   // piece of 512 chunks (the first 512 threads), bf16x3 a piece of 512 and a piece of 256 (waves 0-3)
-  // (one plane: a piece of 256 chunks, waves 0-3)
-  const bool doA = NP == 1 ? wave < 4 : (NSUB == 2 || wave < 8);     // wave-uniform
+  const bool doA = NSUB == 2 || wave < 8;            // wave-uniform
   const bool doA2 = NP == 3 && wave < 4;             // wave-uniform: second piece
   const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + (tid & 511);
   const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
@@ -1154,10 +1147,6 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
       flip8(xs, x, flip);
       split8(xs, h, m, l);
       o[0] = h; o[2 * SCH] = m; o[4 * SCH] = l;
-    } else if constexpr (NP == 1) {
-      float xs[8];
-      flip8(xs, x, flip);
-      o[0] = round8(xs);
     } else {
       u32x4 h, l;
       split8_f16(x, sc_b, h, l);   // (the column's sign rides on the scale)
@@ -1246,13 +1235,11 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
       split_tile_read<NP, 2 * SCH, 2 * SCH>(As, Bs, f);
       split_tile_mfma<NP>(f, acc);
       split_store(xsplit, Bst + (cur ^ 1) * SIMG);
-      if constexpr (NP == 2) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);   // all fragment reads first, in first-use order
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     }
     // weight tile t+1 landed (8 loads of this step are younger), own ds_writes done, the loads of t+2 in flight
@@ -1278,6 +1265,123 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
 // counted waits), the two splits of tile t+1 between the MFMAs of tile t, raw barriers, one MFMA block
 // per tile.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// PARADIS_GEMM_BF16 forward / dgrad (the reference's bf16-mixed mode): operands rounded to bf16, ONE
+// product.  The 128 x 256 workgroup tile of pw_gemm_split_wide_kernel (two 128-column halves sharing one weight tile),
+// but with 32-deep k-tiles: with one product per k the k16 structure leaves four MFMAs per wave between two barriers and
+// 32 KB of fp32 activations in flight per workgroup - the kernel then waits on its own per-tile chain, not on the
+// matrix pipe or on bytes.  Here a tile is two k16 SLICES: eight MFMAs per wave and barrier, sixteen loads per thread and
+// tile in flight two tiles ahead.  Images: weights [m-tile][k32-tile][slice][k-half][128 rows] chunks of 8 bf16
+// (= two consecutive k16 tiles of the one-plane layout, K padded to a multiple of 32 with zeros), activations the same
+// per stage in LDS.  48 KiB of LDS, <= 128 VGPRs: two 8-wave workgroups per CU.  Rows of the activation tile beyond K
+// re-read row K - 1 against the zero padding of the weight image.
+constexpr int BK32_SL = 2;                       // k16 slices per tile
+__global__ void __launch_bounds__(512, 4)
+pw_gemm_bf16_k32_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SIMG = simg(BK32_SL), SA = 2, KT = SBK * BK32_SL;
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 subs][2 activation stages][SIMG] | [SA weight stages][SIMG]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = __builtin_amdgcn_readfirstlane(wave >> 2), lw = wave & 3, ltid = tid & 255;
+  const int wm = lw >> 1, wn = lw & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN, NT2 = (NT + 1) / 2;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt2 = (L / MT) % NT2, bz = L / (MT * NT2);
+  const bool live = 2 * nt2 + sub < NT;              // wave-uniform
+  const int nt = min(2 * nt2 + sub, NT - 1);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T = (g.K + KT - 1) / KT;
+
+  // the weight tile (SIMG = 512 chunks of 16 bytes) goes by LDS-DMA, one chunk per thread
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * SIMG + tid;
+  const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
+  const float* Bb;
+  {
+    const uint64_t a = reinterpret_cast<uint64_t>(g.B + (int64_t)bz * g.b_bs);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    Bb = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  }
+  const int bn = min(n0 + (ltid & 127), g.N - 1);
+  const uint32_t flip = split_flip_mask(ltid & 127);
+  // ONE register set for the activations of the next tile (two sets of 2 x 8 next to 64 accumulators spilled 228 bytes
+  // per lane at the 128 registers two workgroups per CU allow): tile t + 1 is loaded at the top of step t, converted
+  // and stored behind the eight MFMAs of tile t - ~1,000 cycles at four waves per SIMD, the latency of an L2 hit
+  float xb[BK32_SL][8] = {};
+  auto issueA = [&](int t) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * SIMG), (lds_ptr_t)(img + (4 + t % SA) * SIMG + wave * 64), 16, 0, 0);
+  };
+  auto round_store = [&](const float (&x)[BK32_SL][8], u32x4* o) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < BK32_SL; ++sl) {
+      float xs[8];
+      flip8(xs, x[sl], flip);       // sign checkerboard: odd 64-column blocks are staged negated
+      o[sl * 2 * SCH] = round8(xs);
+    }
+  };
+  const uint32_t boff = (uint32_t)bn * 4u;
+  auto fetchB = [&](int t, float (&x)[BK32_SL][8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < BK32_SL; ++sl) {
+      const int k0 = t * KT + sl * SBK + bh * 8;
+      const float* p = Bb + (int64_t)min(k0, g.K - 1) * g.ldb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        asm volatile("global_load_dword %0, %1, %2" : "=&v"(x[sl][j]) : "v"(boff), "s"(p) : "memory");
+        p += (k0 + j + 1 < g.K) ? g.ldb : 0;
+      }
+    }
+  };
+#define USE_X16(x, N) do { asm volatile("s_waitcnt vmcnt(" #N ")" :: "v"(x[0][0]), "v"(x[0][1]), "v"(x[0][2]), "v"(x[0][3]), \
+                                        "v"(x[0][4]), "v"(x[0][5]), "v"(x[0][6]), "v"(x[0][7]), "v"(x[1][0]), "v"(x[1][1]),     \
+                                        "v"(x[1][2]), "v"(x[1][3]), "v"(x[1][4]), "v"(x[1][5]), "v"(x[1][6]), "v"(x[1][7])      \
+                                        : "memory");                                                                           \
+                           __builtin_amdgcn_sched_barrier(0); } while (0)
+  u32x4* const Bst = img + sub * 2 * SIMG + bh * SCH + (ltid & 127);   // this thread's chunk in its sub's stage 0
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issueA(0);
+  fetchB(0, xb);
+  USE_X16(xb, 0);
+  round_store(xb, Bst);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    const u32x4* As = img + (4 + cur) * SIMG + lh * SCH + wm * 64 + li;
+    const u32x4* Bs = img + (sub * 2 + cur) * SIMG + lh * SCH + wn * 64 + li;
+    const bool more = t + 1 < T;                      // workgroup-uniform
+    if (more) { issueA(t + 1); fetchB(t + 1, xb); }
+#pragma unroll
+    for (int sl = 0; sl < BK32_SL; ++sl) {          // one slice's fragments at a time: 16 registers
+      const u32x4 a0 = As[sl * 2 * SCH], a1 = As[sl * 2 * SCH + 32], b0 = Bs[sl * 2 * SCH], b1 = Bs[sl * 2 * SCH + 32];
+      SPLIT_MFMA(a0, b0, acc[0][0]); SPLIT_MFMA(a0, b1, acc[0][1]);
+      SPLIT_MFMA(a1, b0, acc[1][0]); SPLIT_MFMA(a1, b1, acc[1][1]);
+    }
+    if (more) {
+      USE_X16(xb, 0);                                 // (the DMA piece of this step is older than the loads: landed too)
+      round_store(xb, Bst + (cur ^ 1) * SIMG);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#undef USE_X16
+  if (live) {
+    split_unflip(acc, wn);
+    gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+  }
+}
 
 // Soft rendezvous of the tiles of a K-range slab (round 5).  The MT x NT workgroups of a slab stream the same rows of
 // dY (the NT tiles of an m-tile) and of X (the MT tiles of an n-tile) through one XCD's L2; nothing keeps them in step,
@@ -1565,8 +1669,13 @@ constexpr int AMAX_WORDS = PARADIS_AMAX_PARTIALS;
 // f16x2 weight image: the planes, then 16 bytes ([0] = bits of max |W|), then the amax partials of W
 constexpr size_t F16_TAIL_BYTES = 16 + (size_t)AMAX_WORDS * 4;
 
+// k16 tiles of an image: the one-plane (bf16) layout is read in pairs of tiles (pw_gemm_bf16_k32_kernel): an even count
+int split_image_ktiles(int K, int np) {
+  const int kt = (K + SBK - 1) / SBK;
+  return np == 1 ? (kt + 1) & ~1 : kt;
+}
 int64_t split_image_chunks(int M, int K, int np = 3) {
-  return (int64_t)((M + BM - 1) / BM) * ((K + SBK - 1) / SBK) * simg(np);
+  return (int64_t)((M + BM - 1) / BM) * split_image_ktiles(K, np) * simg(np);
 }
 
 bool known_scheme(int scheme) {
@@ -1624,11 +1733,13 @@ int launch_split_wide(const GemmArgs& d, int NT, hipStream_t st) {
 int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
   const int NT = (d.N + BN - 1) / BN;
   if (scheme == PARADIS_GEMM_BF16) {
-    // (a 256 x 128 tile - two M-tiles sharing one fp32 activation tile, 16 instead of 20 KB through L2 per tile pair -
-    //  measured SLOWER in the bf16-mixed step, 95.9 against 91.6 ms: with four MFMAs per wave and barrier the kernel is
-    //  bound by its per-tile latency chain, not by bytes; round 5, removed)
-    if (NT < 2) return launch_split_np<1>(d, st);
-    return launch_split_wide<1>(d, NT, st);
+    // (round 5: the k16 kernels with one plane ran the bf16-mixed step at 91.6 ms; a 256 x 128 tile - two M-tiles
+    //  sharing one fp32 activation tile, 16 instead of 20 KB through L2 per tile pair - at 95.9 ms: with four MFMAs per
+    //  wave and barrier the kernel is bound by its per-tile latency chain, not by bytes.  Hence 32-deep tiles.)
+    const size_t lds = (size_t)(2 * 2 + 2) * simg(BK32_SL) * 16;
+    const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;
+    hipLaunchKernelGGL(pw_gemm_bf16_k32_kernel, dim3(grid), dim3(512), lds, st, d);
+    return 0;
   }
   if (scheme != PARADIS_GEMM_F16X2) {
 #if SPLIT_WIDE_BF16X3
@@ -1686,7 +1797,7 @@ extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int t
   PD_REQUIRE(scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_F16X2 || scheme == PARADIS_GEMM_BF16,
              "pw_gemm_split_weights: unknown scheme %d", scheme);
   const int AM = transpose ? K : M, AK = transpose ? M : K;
-  const int KT = (AK + SBK - 1) / SBK;
+  const int KT = split_image_ktiles(AK, scheme == PARADIS_GEMM_BF16 ? 1 : 3);
   const int64_t units = (int64_t)((AM + BM - 1) / BM) * KT * 256;
   const int blocks = (int)std::min<int64_t>((units + 255) / 256, 4096);
   if (scheme == PARADIS_GEMM_F16X2) {
