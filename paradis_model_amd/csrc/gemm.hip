@@ -57,10 +57,9 @@ struct GemmArgs {
   // f16x2 scheme: where the operands' max |value| comes from.  a_amax: one word (bits of max |A|, weight
   // image tail) for fwd/dgrad, PARADIS_AMAX_PARTIALS words for wgrad; b_amax: PARADIS_AMAX_PARTIALS words.
   const uint32_t* a_amax; const uint32_t* b_amax;
-  // PARADIS_GEMM_BF16 (the reference's bf16-mixed mode): the result is rounded to bf16 where the reference's autocast
-  // conv2d rounds it - the pre-activation and the activated value (fwd), the activation-gradient product (dgrad) -
-  // before the fp32 residual / blend.  Stored as fp32.
-  int round16;
+  // (PARADIS_GEMM_BF16, the reference's bf16-mixed mode: the result is rounded to bf16 where the reference's autocast
+  //  conv2d rounds it - the pre-activation and the activated value (fwd), the activation-gradient product (dgrad) -
+  //  before the fp32 residual / blend; a compile-time property of pw_gemm_bf16_k32_kernel's epilogue.  Stored as fp32.)
   // wgrad: one word per K-range slab for the soft rendezvous of the slab's tiles (NULL = none), see WGRAD_SYNC_T
   unsigned* sync;
 };
@@ -160,6 +159,9 @@ __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; 
 //   v = gate ? res + sigmoid(gate[m]) (v - res) : v + res; C = v
 // Interior tiles take a path without per-element guards in which all loads of one 32-row group are
 // issued back to back (the guarded form serialises every load behind an s_waitcnt vmcnt(0)).
+// R16 (compile time: only the bf16-mixed kernel instantiates it, the fp32 schemes' epilogue is the round-4 code): round
+// the pre-activation and the activated / activation-gradient value to bf16 (see the note in GemmArgs)
+template <bool R16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int bz, int m0,
                                               int n0, int wm, int wn, int li, int lh) {
   float* Cb = g.C + (int64_t)bz * g.c_bs;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += t[q];
           }
-          if (g.round16) {
+          if constexpr (R16) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
           }
@@ -210,9 +212,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = act_apply(v[q], g.act);
           }
-          if (g.round16 && (zmulb || g.act)) {
+          if constexpr (R16) {
+            if (zmulb || g.act) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
+              for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
+            }
           }
           if (resb) {
 #pragma unroll
@@ -253,11 +257,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const int64_t off = (int64_t)m * g.ldc + n;
         float v = acc[tm][tn][r] + bv;
         if (g.map) v += g.map[off];
-        if (g.round16) v = round_bf16(v);
+        if constexpr (R16) v = round_bf16(v);
         if (zoutb) zoutb[off] = v;
         if (zmulb) v *= act_grad(zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
-        if (g.round16 && (zmulb || g.act)) v = round_bf16(v);
+        if constexpr (R16) { if (zmulb || g.act) v = round_bf16(v); }
         if (resb) {
           const float r = resb[off];
           v = g.gate ? fmaf(gate_sigmoid(g.gate[m]), v - r, r) : v + r;
@@ -1379,7 +1383,7 @@ pw_gemm_bf16_k32_kernel(GemmArgs g) {
 #undef USE_X16
   if (live) {
     split_unflip(acc, wn);
-    gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+    gemm_epilogue<true>(g, acc, bz, m0, n0, wm, wn, li, lh);
   }
 }
 
@@ -1836,7 +1840,6 @@ namespace {
 int run_split(GemmArgs d, const void* img, int AM, int AK, int scheme, const uint32_t* b_amax, const char* what,
               hipStream_t st) {
   d.A = (const float*)img; d.a_bs = 0;
-  d.round16 = scheme == PARADIS_GEMM_BF16;
   if (scheme == PARADIS_GEMM_F16X2) {
     if (b_amax == nullptr) { paradis_set_error(what); return 1; }
     d.a_amax = reinterpret_cast<const uint32_t*>((const char*)img + (size_t)split_image_chunks(AM, AK, 2) * 16);

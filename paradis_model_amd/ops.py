@@ -948,7 +948,7 @@ def autocast_scheme(default: int) -> int:
 # keyed on the parameter object, its data pointer, its autograd version (every torch in-place update
 # bumps it) and WEIGHT_EPOCH, which every optimiser step bumps (the HIP optimisers write through raw
 # pointers, and foreign optimisers / EMA helpers may write through ``.data``: a global optimizer-step
-# post-hook covers both).  Raw writes outside an optimiser step (a user kernel, ``p.data.copy_``) must be
+# post-hook, registered when the first image is cached, covers both).  Raw writes outside an optimiser step (a user kernel, ``p.data.copy_``) must be
 # followed by ``ops.weights_updated()``.
 WEIGHT_EPOCH = 0
 _IMAGES = {}     # (id(weight), transpose, scheme) -> (weakref, data_ptr, version, epoch, image)
@@ -965,9 +965,17 @@ def _optimizer_step_hook(optimizer, args, kwargs) -> None:
     weights_updated()
 
 
-from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_post_hook  # noqa: E402
+_STEP_HOOK = None
 
-_register_step_post_hook(_optimizer_step_hook)
+
+def _ensure_step_hook() -> None:
+    """The process-wide optimiser post-hook exists from the moment the first weight image is cached, not from import
+    (rounds 1-4 registered it at import time): a process that imports the package and never runs a split GEMM keeps
+    torch.optim untouched."""
+    global _STEP_HOOK
+    if _STEP_HOOK is None:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        _STEP_HOOK = register_optimizer_step_post_hook(_optimizer_step_hook)
 
 
 def _drop_images(wid: int) -> None:
@@ -1009,6 +1017,7 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int,
                                                 stream_ptr()), "pw_gemm_split_weights")
     if cacheable:
         wid = id(weight)
+        _ensure_step_hook()
         try:
             ref = weakref.ref(weight, lambda _r, wid=wid: _drop_images(wid))
             _IMAGES[key] = (ref, weight.data_ptr(), ver, WEIGHT_EPOCH, out)

@@ -186,11 +186,13 @@ def test_weight_image_cache_invalidation():
     and by ``ops.weights_updated()``; inference tensors have no version counter and must not raise."""
     import torch
     from paradis_model_amd import ops
+    ops._ensure_step_hook()       # (registered when the first weight image is cached - not at import: round 5)
+    ops._ensure_step_hook()       # idempotent
     e0 = ops.WEIGHT_EPOCH
     p = torch.nn.Parameter(torch.zeros(3))
     p.grad = torch.ones(3)
     torch.optim.SGD([p], lr=0.1).step()                                   # a foreign optimiser
-    assert ops.WEIGHT_EPOCH > e0
+    assert ops.WEIGHT_EPOCH == e0 + 1
     e1 = ops.WEIGHT_EPOCH
     ops.weights_updated()
     assert ops.WEIGHT_EPOCH == e1 + 1

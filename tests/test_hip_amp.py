@@ -160,3 +160,42 @@ def test_bf16_mixed_training_step_runs_and_is_captured():
     pg = torch.cat([p.detach().flatten() for p in mg.parameters()])
     assert max_rel(pg, pe) <= 1e-6
     assert le[-1] < le[0]            # and it trains
+
+
+def test_fullgraph_trace_under_bf16_autocast_pins_the_one_product_scheme():
+    """`torch.compile(fullgraph=True)` (reference trainer.py:261-267) inside torch.autocast(bfloat16): still ONE graph of
+    paradis:: ops; every pointwise GEMM node carries scheme = GEMM_BF16 as a constant argument (a traced graph keeps the
+    arithmetic it was traced with), outside autocast the default scheme; compiled == eager in both modes."""
+    import collections
+    from paradis_model_amd import ops
+    from paradis_model_amd.config import stub_datamodule
+    from paradis_model_amd.model import Paradis
+    from tests._util import make_grid, max_rel
+    cfg = reduced_config()
+    _, lg, og = make_grid(16, 32, False)
+    torch.manual_seed(42)
+    m = Paradis(stub_datamodule(cfg), cfg, lg, og).cuda()
+    graphs = []
+
+    def backend(gm, example_inputs):
+        graphs.append(gm)
+        return gm.forward
+
+    def schemes(gm):
+        out = collections.Counter()
+        for n in gm.graph.nodes:
+            if n.op == "call_function" and str(n.target) == "paradis.pointwise.default":
+                out[n.args[12]] += 1
+        return dict(out)
+
+    x = seeded(3, 2, 186, 16, 32).cuda()
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            want = m(x)
+            got = torch.compile(m, backend=backend, fullgraph=True, dynamic=False)(x)
+        assert len(graphs) == 1 and schemes(graphs[0]) == {ops.GEMM_BF16: 24}, schemes(graphs[0])
+        assert max_rel(got, want) <= 1e-6
+        torch._dynamo.reset()
+        got32 = torch.compile(m, backend=backend, fullgraph=True, dynamic=False)(x)
+        assert schemes(graphs[-1]) == {ops.GEMM_SCHEME: 24}, schemes(graphs[-1])
+        assert max_rel(got32, m(x)) <= 1e-6 and 1e-4 < max_rel(got, got32) < 1e-1

@@ -67,9 +67,13 @@ def test_per_module_compile_matches_eager():
     assert keys == set(eager.state_dict())
 
 
-def test_autocast_runs_the_fp32_kernels():
-    """precision="bf16-mixed" (reference train.py:56): the ops cast their inputs to fp32 - never a
-    narrower arithmetic than the reference's - so the result equals the fp32 run."""
+def test_autocast_modes():
+    """precision="bf16-mixed" (reference train.py:56, its shipped default).  Rounds 1-4: every op widened its inputs to
+    fp32 and the result equalled the fp32 run.  Round 5: the pointwise GEMMs - autocast's conv2d - run the one-product
+    bf16 scheme inside bfloat16 autocast (tests/test_hip_amp.py pins it); every other op still widens (never narrower than
+    the reference, which keeps grid_sampler in fp32 too), outputs stay fp32 tensors, a bf16 input is widened, not
+    rejected; under FLOAT16 autocast nothing changes: the fp32 result bit for bit."""
+    from paradis_model_amd import ops
     cfg = reduced_config()
     model = _build(cfg)
     x = seeded(3, 1, 186, 16, 32).cuda()
@@ -77,9 +81,17 @@ def test_autocast_runs_the_fp32_kernels():
         y0 = model(x)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y1 = model(x)
-            y2 = model(x.to(torch.bfloat16))      # a bf16 input is widened, not rejected
-    assert y1.dtype == torch.float32 and torch.equal(y1, y0)
+            y2 = model(x.to(torch.bfloat16))
+            f = seeded(4, 1, 6, 16, 32).cuda()
+            w = seeded(5, 6, 1, 5, 5).cuda()
+            with torch.autocast("cuda", enabled=False):
+                ref = ops.dwconv_geo(f, w)
+            assert torch.equal(ops.dwconv_geo(f, w), ref)              # a non-GEMM op: fp32 inside bf16 autocast
+        with torch.autocast("cuda", dtype=torch.float16):
+            y3 = model(x)
+    assert y1.dtype == torch.float32 and 1e-4 < max_rel(y1, y0) < 0.05     # the bf16 path ran
     assert y2.dtype == torch.float32 and max_rel(y2, y0) < 0.05
+    assert y3.dtype == torch.float32 and torch.equal(y3, y0)
 
 
 def test_non_fp32_and_cpu_tensors_raise():
