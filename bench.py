@@ -52,7 +52,8 @@ def _library_sha256():
 
 # suffix of the profile tags of each workload (tools/profile_round.sh <tag> [bench args]): profiles/r03b_* is the
 # default workload, profiles/r03a_cfg3_* the 128x256 one ...
-PROFILE_SUFFIX = {"era5_5.625deg_32x64_S1_B32": "", "era5_5.625deg_32x64_S6_B32": "_cfg2",
+# (the S = 6 rollout launches the kernels of the S = 1 step six times over, same shapes: it reads the default profile)
+PROFILE_SUFFIX = {"era5_5.625deg_32x64_S1_B32": "", "era5_5.625deg_32x64_S6_B32": "",
                   "era5_1.4deg_128x256_S1_B8": "_cfg3", "era5_0.25deg_721x1440_fwd_B1": "_cfg4"}
 WORKLOAD = "era5_5.625deg_32x64_S1_B32"     # set by main()
 
@@ -98,10 +99,12 @@ def pmc_mfma_busy():
     return {"values": vals, "source": src}
 
 
-def pmc_traffic(substr: str):
+def pmc_traffic(substr: str, per_call: bool = False):
     """HBM bytes per launch of the kernels whose name contains `substr` from the committed rocprofv3 PMC
     passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 2x read-side correction of
-    MI355X_MICROARCH.md); launch-weighted mean.  Counters cannot be collected inside a timed run, so
+    MI355X_MICROARCH.md); launch-weighted mean - or, `per_call`, per CALL of an op that launches several of
+    them (the windowed advection: strip kernel(s) + the fix-up of the deferred points): the bytes of all matching
+    kernels over the launches of the most frequent one.  Counters cannot be collected inside a timed run, so
     this is a read-back: returns (bytes, source) with the provenance, (None, None) without a usable profile."""
     data, src = _profile("traffic")
     if not data:
@@ -111,7 +114,7 @@ def pmc_traffic(substr: str):
     for name, rec in data.items():
         if substr in name and "hbm_bytes_per_launch" in rec:
             num += rec["hbm_bytes_per_launch"] * rec.get("launches", 1)
-            den += rec.get("launches", 1)
+            den = max(den, rec.get("launches", 1)) if per_call else den + rec.get("launches", 1)
             names.append(name)
     if not den or not _kernels_exist(names):
         return None, None
@@ -214,7 +217,7 @@ def _rooflines(s, elapsed_s, gemm):
         if key in s:
             r = s[key]
             ach = r["work"] / (r["ms"] * 1e-3) / 1e9
-            tr, tr_src = pmc_traffic(key)
+            tr, tr_src = pmc_traffic(key, per_call=True)
             out[name] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
                          "launches": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
