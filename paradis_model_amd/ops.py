@@ -34,6 +34,13 @@ MODE_CODES = {"bilinear": 1, "bicubic": 2}
 
 _DEF = torch.library.Library("paradis", "DEF")
 OPS = {}            # op name -> OpOverload (torch.ops.paradis.<name>.default)
+RAW = {}            # op name -> the Python function behind its HIP kernel (eager backward formulas call it directly)
+
+
+def _plain(t) -> bool:
+    """a real device tensor in an eager, un-traced call: the kernels' Python functions may be called directly (fake /
+    functional / subclass tensors - FakeTensorMode, make_fx, torch.export - must go through the dispatcher)"""
+    return type(t) is Tensor and not torch.is_grad_enabled()
 
 
 def _define(schema: str, autocast: bool = True):
@@ -42,6 +49,7 @@ def _define(schema: str, autocast: bool = True):
     _DEF.define(schema)
 
     def deco(fn):
+        RAW[name] = fn
         _DEF.impl(name, fn, "CUDA")
         if autocast:
             torch.library.register_autocast(f"paradis::{name}", "cuda", torch.float32)
@@ -314,8 +322,8 @@ def _advv_setup(ctx, inputs, output):
     ctx.geom = inputs[6:]
 
 
-def _advv_backward(ctx, gout):
-    gf, gvel = _sl_advect_vel_backward(gout, *ctx.saved_tensors, *ctx.geom)
+def _advv_backward(ctx, gout, raw=False):
+    gf, gvel = (RAW if raw else OPS)["sl_advect_vel_backward"](gout, *ctx.saved_tensors, *ctx.geom)
     return (gf, gvel) + (None,) * 11
 
 
@@ -349,11 +357,28 @@ def _geom_args(geom: AdvectGeometry, device, dt: float, mode: str, flags: Option
     return sl, cl, lc, lo, float(dt), geom.min_lat, geom.min_lon, geom.d_lat, geom.d_lon, MODE_CODES[mode], flags
 
 
+class _AdvectVelEager(torch.autograd.Function):
+    """``paradis::sl_advect_vel`` with its registered setup / backward, for eager recording calls (see ``_PointwiseEager``)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        out = _sl_advect_vel(*args)
+        _advv_setup(ctx, args, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        return _advv_backward(ctx, gout, raw=_plain(gout))
+
+
 def sl_advect_vel(field, vel, geom: AdvectGeometry, dt: float, mode: str = "bicubic", flags: Optional[int] = None):
     require_hip(field, vel)
     B, K, H, W = field.shape
     assert vel.shape == (B, 2 * K, H, W) and (H, W) == (geom.H, geom.W)
-    return _sl_advect_vel(field, vel, *_geom_args(geom, field.device, dt, mode, flags))
+    args = (field, vel, *_geom_args(geom, field.device, dt, mode, flags))
+    if torch.is_grad_enabled() and not torch.compiler.is_compiling():
+        return _AdvectVelEager.apply(*args)
+    return _sl_advect_vel(*args)
 
 
 def sl_advect(field, u, v, geom: AdvectGeometry, dt: float, mode: str = "bicubic", flags: Optional[int] = None):
@@ -464,17 +489,19 @@ def _(gy, x, weight, addend, has_bias):
     return gy.new_empty(gy.shape), x.new_empty(C, 1, k, k), x.new_empty(C if has_bias else 0)
 
 
-def _dw_grads(ctx, gy, x, w, addend):
-    """input / weight / bias gradients as the context needs them (one fused call when it needs both kinds)"""
+def _dw_grads(ctx, gy, x, w, addend, raw=False):
+    """input / weight / bias gradients as the context needs them (one fused call when it needs both kinds);
+    ``raw``: an eager backward - the kernels' Python functions directly (see ``_pw_backward``)"""
+    K = RAW if raw else OPS
     need_x = ctx.needs_input_grad[0]
     need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
     gx = gw = gb = None
     if need_x and need_w:
-        gx, gw, gb = _dwconv_geo_bwd(gy, x, w, addend, ctx.has_bias)
+        gx, gw, gb = K["dwconv_geo_bwd"](gy, x, w, addend, ctx.has_bias)
     elif need_x:
-        gx = _dwconv_geo_dgrad(gy, w) if addend is None else _dwconv_geo_dgrad_add(gy, w, addend)
+        gx = K["dwconv_geo_dgrad"](gy, w) if addend is None else K["dwconv_geo_dgrad_add"](gy, w, addend)
     elif need_w:
-        gw, gb = _dwconv_geo_wgrad(gy, x, w.shape[-1], ctx.has_bias)
+        gw, gb = K["dwconv_geo_wgrad"](gy, x, w.shape[-1], ctx.has_bias)
     if not ctx.has_bias:
         gb = None
     return gx, gw, gb
@@ -518,7 +545,7 @@ class _DwconvSkip(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if gy is None:          # only the skip path was used
             return gskip, None, None
-        return _dw_grads(ctx, gy, x, w, gskip)
+        return _dw_grads(ctx, gy, x, w, gskip, raw=_plain(gy))
 
 
 def dwconv_geo_skip(x, weight, bias=None):
@@ -744,7 +771,8 @@ class _ChannelNormSkip(torch.autograd.Function):
         x1, x2, weight, mean, rstd = ctx.saved_tensors
         if gy is None:          # only the skip path was used
             return gskip, None, None, None, None
-        gx1, gx2, gw, gb = _channel_norm_backward(gy, x1, x2, weight, mean, rstd, gskip)
+        bwd = RAW["channel_norm_backward"] if _plain(gy) else _channel_norm_backward
+        gx1, gx2, gw, gb = bwd(gy, x1, x2, weight, mean, rstd, gskip)
         return gx1, (gx2 if x2 is not None else None), gw, gb, None
 
 
@@ -1249,7 +1277,11 @@ def _pw_setup(ctx, inputs, output):
     ctx.set_materialize_grads(False)
 
 
-def _pw_backward(ctx, gy, gz=None, gamax=None):
+def _pw_backward(ctx, gy, gz=None, gamax=None, raw=False):
+    """``raw``: called from ``_PointwiseEager.backward`` - an eager, un-traced backward: the HIP kernels' Python functions
+    are called directly instead of through the dispatcher (~250 op calls per training step at ~12 us each of dispatcher
+    -> autograd key -> autocast key -> Python kernel; the arithmetic is the same code)."""
+    K = RAW if raw else OPS          # name -> the kernel's Python function / the OpOverload
     x, weight, z, x_pre, m8, pw, x_amax, res_saved, y_saved, gate = ctx.saved_tensors
     act, has_bias, has_map, has_res, x_act, deferred, scheme = ctx.meta
     need = ctx.needs_input_grad
@@ -1260,41 +1292,57 @@ def _pw_backward(ctx, gy, gz=None, gamax=None):
     if gate is not None:
         # gradient of the blend: d residual, d (activated GEMM output) - what the rest of this backward continues
         # with - and d gate, in one pass over (gy, residual, y)
-        gres, gy, ggate = _gated_blend_backward_out(gy, res_saved, y_saved, gate)
+        gres, gy, ggate = K["gated_blend_backward_out"](gy, res_saved, y_saved, gate)
         ggate = ggate.reshape(gate.shape)
     else:
         gres = gy if has_res else None
     if act != 0 and not deferred:
-        dz = _act_backward(gy, z, act)
+        dz = K["act_backward"](gy, z, act)
     else:
         dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
     gx = gw = gb = gmap = gm8 = gpw = None
     # f16x2: one read pass over dz serves both of its GEMMs
-    dz_amax = _amax_partials(dz) if (scheme == GEMM_F16X2 and (need[0] or need[1])) else None
+    dz_amax = K["amax_partials"](dz) if (scheme == GEMM_F16X2 and (need[0] or need[1])) else None
     if need[0]:
-        gx = _pw_gemm_dgrad(dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme)
+        gx = K["pw_gemm_dgrad"](dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme)
     want_b = has_bias and need[2]
     want_p = has_proj and (need[9] or need[10])
     want_m = (has_map and need[3]) or want_p
     if need[1]:
         fused_b = want_b and not want_m     # bias gradient = row sums of dz: fused into the wgrad GEMM
-        gw, gbf = _pw_gemm_wgrad(dz, x, fused_b, dz_amax, x_amax, scheme)
+        gw, gbf = K["pw_gemm_wgrad"](dz, x, fused_b, dz_amax, x_amax, scheme)
         gw = gw.reshape(weight.shape)
         if fused_b:
             gb, want_b = gbf, False
     if want_b or want_m:
-        gb2, gmap = _bias_grads(dz, want_b, want_m)
+        gb2, gmap = K["bias_grads"](dz, want_b, want_m)
         if want_b:
             gb = gb2
         if not want_m:
             gmap = None
     if want_p:   # adjoint of the fused projection: gmap -> (gPw, gm8); the full map only lives here
-        gpw, gm8 = _global_bias_proj_backward(gmap, m8, pw)
+        gpw, gm8 = K["global_bias_proj_backward"](gmap, m8, pw)
         gmap = None
     return gx, gw, gb, gmap, gres, None, None, None, None, gm8, gpw, None, None, ggate, None
 
 
 _autograd("pointwise", _pw_setup, _pw_backward)
+
+
+class _PointwiseEager(torch.autograd.Function):
+    """``paradis::pointwise`` with its registered setup / backward, for eager recording calls (see ``pointwise``)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        # (inside autocast the op's autocast rule widens bf16 / fp16 inputs: through the dispatcher; otherwise straight
+        #  to the kernel's Python function - same checks, same launch)
+        out = RAW["pointwise"](*args) if (_plain(args[0]) and not torch.is_autocast_enabled("cuda")) else _pointwise(*args)
+        _pw_setup(ctx, args, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy, gz=None, gamax=None):
+        return _pw_backward(ctx, gy, gz, gamax, raw=_plain(gy))
 
 
 def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pre=None, x_act=None,
@@ -1320,10 +1368,14 @@ def pointwise(x, weight, bias=None, bias_map=None, residual=None, act=None, x_pr
     if code != 0 and not save_z and torch.is_grad_enabled():
         save_z = any(t is not None and t.requires_grad for t in (x, weight, bias, bias_map, m8, pw))
     # (grad mode is off inside the op's own forward: the hint is computed here and travels as an argument)
-    want_wt = (not torch.compiler.is_compiling()) and torch.is_grad_enabled() and \
-        (x.requires_grad or (x_pre is not None and x_pre.requires_grad))
-    y, z, _ = _pointwise(x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw,
-                         save_z, autocast_scheme(GEMM_SCHEME) if scheme is None else int(scheme), gate, bool(want_wt))
+    eager = not torch.compiler.is_compiling()
+    want_wt = eager and torch.is_grad_enabled() and (x.requires_grad or (x_pre is not None and x_pre.requires_grad))
+    args = (x, weight, bias, bias_map, residual, code, x_pre, ACT_CODES[x_act], bool(defer_act_grad), m8, pw,
+            save_z, autocast_scheme(GEMM_SCHEME) if scheme is None else int(scheme), gate, bool(want_wt))
+    # eager + recording: the same forward / setup / backward through a plain autograd.Function - torch.library's generic
+    # autograd wrapper spends ~30 us per call of this 15-argument op rebuilding the schema's argument list
+    # (torch/_library/utils.py fill_defaults; tools/host_profile.py: 78 calls per step).  Traced graphs keep the op.
+    y, z, _ = _PointwiseEager.apply(*args) if (eager and torch.is_grad_enabled()) else _pointwise(*args)
     return (y, z) if defer_act_grad else y
 
 
