@@ -703,6 +703,285 @@ dwconv_geo_bwd_planes_kernel(const float* __restrict__ gy, const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------- staged tiles of the larger grids
+// Grids of more than one tile (128x256, 721x1440, ...; k = 5): the whole-plane kernels' structure - 16-byte loads from
+// per-thread offsets computed once, the next item's loads in flight under the current item's arithmetic - on 32x64
+// tiles that are always FULL: the last tile row / column starts at H - 32 / W - 64, overlapping its neighbour, and
+// owns (stores, and counts in the weight gradient) only the rows / columns its neighbour does not.  A full tile has
+// one fixed shape: 512 aligned float4 of interior and a 400-cell halo ring through the index map, two of each per
+// thread, whatever the position.
+template <int K>
+struct TileStager {
+  static constexpr int P = (K - 1) / 2, LW = TW + K - 1;
+  unsigned vsrc[2], hsrc[2];
+  int vdst[2], hdst[2];
+  __device__ __forceinline__ void init(int H, int W, int ty0, int tx0) {
+    constexpr int w4 = TW / 4, hc = 2 * P, nhalo_rows = 2 * P * LW, nhalo = nhalo_rows + TH * hc;
+    static_assert(TH * w4 == 512 && nhalo <= 512, "two interior vectors and two halo cells per thread");
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = threadIdx.x + 256 * j;
+      const int y = v / w4, x4 = v - y * w4;
+      vsrc[j] = (unsigned)((ty0 + y) * W + tx0 + 4 * x4) * 4u;          // byte offsets in the plane
+      vdst[j] = (y + P) * LW + P + 4 * x4;
+      const int kk = threadIdx.x + 256 * j, k = min(kk, nhalo - 1);
+      int lr, lc;
+      if (k < nhalo_rows) {
+        const int rr = k / LW;
+        lc = k - rr * LW;
+        lr = rr < P ? rr : TH + rr;
+      } else {
+        const int e = k - nhalo_rows, rr = e / hc, cc = e - rr * hc;
+        lr = rr + P;
+        lc = cc < P ? cc : TW + cc;
+      }
+      int sr, sc;
+      geo_src(ty0 + lr - P, tx0 + lc - P, H, W, sr, sc);
+      hsrc[j] = (unsigned)(sr * W + sc) * 4u;
+      hdst[j] = kk < nhalo ? lr * LW + lc : -1;
+    }
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ F, f32x4 (&q)[2], float (&hv)[2]) const {
+    const ubase_t b = uniform_base(F);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { q[j] = load_at<f32x4>(b, vsrc[j]); hv[j] = load_at<float>(b, hsrc[j]); }
+  }
+  __device__ __forceinline__ void store(float* tile, const f32x4 (&q)[2], const float (&hv)[2]) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float2* d = reinterpret_cast<float2*>(tile + vdst[j]);      // 8-byte aligned (P, LW even)
+      d[0] = make_float2(q[j].x, q[j].y);
+      d[1] = make_float2(q[j].z, q[j].w);
+      if (hdst[j] >= 0) tile[hdst[j]] = hv[j];
+    }
+  }
+};
+
+// position of tile t: (ty0, tx0) = where it is staged from, (ny0, nx0) = the first row / column it owns
+struct TilePos { int ty0, tx0, ny0, nx0; };
+__device__ __forceinline__ TilePos tile_pos(int t, int tiles_x, int H, int W) {
+  const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+  TilePos p;
+  p.ny0 = tyi * TH; p.nx0 = txi * TW;
+  p.ty0 = min(p.ny0, H - TH); p.tx0 = min(p.nx0, W - TW);
+  return p;
+}
+
+// consecutive workgroup ids go round the eight XCDs; hand every XCD a contiguous range of logical ids instead: the
+// tiles of a plane chunk - neighbours that share halo cells - then run behind one L2
+__device__ __forceinline__ int xcd_contiguous(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+// forward: a workgroup walks PLANE_CHUNK planes at one tile position
+template <int K>
+__global__ void __launch_bounds__(256, 5)
+dwconv_geo_fwd_tiles_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                            float* __restrict__ y, int C, int H, int W, int tiles_x, int tiles, int64_t planes) {
+  __shared__ float tile[(TH + K - 1) * (TW + K - 1)];
+  const int L = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int chunk = L / tiles, t = L - chunk * tiles;
+  const TilePos tp = tile_pos(t, tiles_x, H, W);
+  const int xl = threadIdx.x & 63, r0l = (threadIdx.x >> 6) * RPT;
+  const int64_t first = (int64_t)chunk * PLANE_CHUNK, PS = (int64_t)H * W;
+  const int n = (int)min((int64_t)PLANE_CHUNK, planes - first);
+  TileStager<K> sg;
+  sg.init(H, W, tp.ty0, tp.tx0);
+  f32x4 q[2];
+  float hv[2];
+  sg.load(x + first * PS, q, hv);
+  const unsigned o0 = (unsigned)((tp.ty0 + r0l) * W + tp.tx0 + xl) * 4u;
+  const bool col_owned = tp.tx0 + xl >= tp.nx0;
+  const int own0 = tp.ny0 - tp.ty0 - r0l;           // rows o >= own0 of this thread's strip are owned
+  for (int i = 0; i < n; ++i) {
+    const int64_t plane = first + i;
+    const int c = (int)(plane % C);
+    sg.store(tile, q, hv);
+    __syncthreads();
+    if (i + 1 < n) sg.load(x + (plane + 1) * PS, q, hv);
+    float acc[RPT];
+    tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
+    const float bv = bias ? bias[c] : 0.f;
+    const ubase_t yp = uniform_base(y + plane * PS);
+#pragma unroll
+    for (int o = 0; o < RPT; ++o)
+      if (col_owned && o >= own0) store_at<float>(yp + (int64_t)o * W * 4, o0, acc[o] + bv);
+    __syncthreads();
+  }
+}
+
+// item -> (tile, sample) of a channel's B x tiles items.  Tile fastest: a workgroup's contiguous range of items walks
+// the tiles of one plane in row-major order, so the halo cells a tile shares with its left neighbour were read by the
+// same CU one item earlier (L2 hits); sample fastest would keep the stager's offsets across items instead.
+#ifndef DWCONV_BWD_TFAST         // (A/B builds)
+#define DWCONV_BWD_TFAST 1
+#endif
+__device__ __forceinline__ void item_of(int item, int B, int tiles, int& t, int& n) {
+  if (DWCONV_BWD_TFAST) { n = item / tiles; t = item - n * tiles; }
+  else { t = item / B; n = item - t * B; }
+}
+
+// both gradients in one pass (dwconv_geo_bwd_planes_kernel's arithmetic on tiles): workgroup (channel c, chunk) walks a
+// contiguous range of the channel's B x tiles items (item_of); the 26 sums stay in registers across items.  The data gradient is the same sum in the same
+// order as dwconv_geo_dgrad_kernel's (bit-identical); the weight gradient partitions its sum differently from
+// dwconv_geo_wgrad_kernel (same terms, another - fixed - order).
+template <int K, bool ADD>
+__global__ void __launch_bounds__(256, 4)
+dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
+                            const float* __restrict__ addend, float* __restrict__ gx, float* __restrict__ partial,
+                            int B, int C, int H, int W, int tiles_x, int tiles, int chunks, int per) {
+  constexpr int P = (K - 1) / 2, LW = TW + K - 1, NW = K * K + 1, TN = (TH + K - 1) * (TW + K - 1);
+  __shared__ float tg[TN], tx[TN];
+  __shared__ float red[4][NW];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x - c * chunks;
+  const int items = B * tiles, i0 = chunk * per, i1 = min(items, i0 + per);
+  const int xl = threadIdx.x & 63, wave = threadIdx.x >> 6, r0 = wave * RPT;
+  const float* wc = w + (int64_t)c * K * K;
+  const int64_t PS = (int64_t)H * W;
+  const int half = W >> 1;
+  float accw[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) accw[i] = 0.f;
+  float gsum = 0.f;
+  TileStager<K> sg;
+  f32x4 qg[2], qx[2];
+  float hg[2], hx[2];
+  int staged_t = -1;
+  auto fetch = [&](int item) __attribute__((always_inline)) {
+    int t, n;
+    item_of(item, B, tiles, t, n);
+    if (t != staged_t) {                                       // (wave-uniform)
+      const TilePos np = tile_pos(t, tiles_x, H, W);
+      sg.init(H, W, np.ty0, np.tx0);
+      staged_t = t;
+    }
+    const int64_t off = ((int64_t)n * C + c) * PS;
+    sg.load(gy + off, qg, hg);
+    sg.load(x + off, qx, hx);
+  };
+  if (i0 < i1) fetch(i0);
+  for (int item = i0; item < i1; ++item) {
+    int t, n;
+    item_of(item, B, tiles, t, n);
+    const TilePos tp = tile_pos(t, tiles_x, H, W);
+    const int64_t off = ((int64_t)n * C + c) * PS;
+    const float* gpl = gy + off;
+    sg.store(tg, qg, hg);
+    sg.store(tx, qx, hx);
+    __syncthreads();
+    if (item + 1 < i1) fetch(item + 1);
+    const unsigned o0 = (unsigned)((tp.ty0 + r0) * W + tp.tx0 + xl) * 4u;
+    const int xx = tp.tx0 + xl;
+    const bool col_owned = xx >= tp.nx0;
+    const int own0 = tp.ny0 - tp.ty0 - r0;
+    float av[RPT];
+    if (ADD) {
+      const ubase_t ab = uniform_base(addend + off);
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) av[o] = load_at<float>(ab + (int64_t)o * W * 4, o0);
+    }
+    // ---- data gradient of this tile (dwconv_geo_dgrad_kernel)
+    {
+      float wr[K * K];
+#pragma unroll
+      for (int j = 0; j < K * K; ++j) wr[j] = wc[j];
+      float acc[RPT];
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) acc[o] = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RPT + K - 1; ++rr) {
+        const int ii = tp.ty0 + r0 + rr - P;   // image row of this tile row (wave-uniform)
+        float val[K];
+#pragma unroll
+        for (int b = 0; b < K; ++b) val[b] = tg[(r0 + rr) * LW + xl + b];
+        if (ii >= 0 && ii < H) {
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            const int o = rr - a;
+            if (o >= 0 && o < RPT) {
+#pragma unroll
+              for (int b = 0; b < K; ++b) acc[o] += wr[(K - 1 - a) * K + (K - 1 - b)] * val[b];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            const int o = rr - a;
+            if (o >= 0 && o < RPT) {
+              const int yy = tp.ty0 + r0 + o;
+              const bool feeds = (ii < 0) ? (yy >= 1) : (yy <= H - 2);
+              if (feeds) {
+#pragma unroll
+                for (int b = 0; b < K; ++b) acc[o] += wr[a * K + (K - 1 - b)] * val[b];
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const ubase_t gp = uniform_base(gx + off);
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) {
+        const int yy = tp.ty0 + r0 + o;
+        float extra = 0.f;
+        const bool south = yy >= 1 && yy <= P, north = yy >= H - 1 - P && yy <= H - 2;
+        if (south || north) {                   // (wave-uniform; the W/2-shifted pole row comes from memory)
+          const int a = south ? P - yy : P + (H - 1 - yy);
+          const int prow = south ? 0 : H - 1;
+#pragma unroll
+          for (int b = 0; b < K; ++b) {
+            int col = xx + P - b + half;
+            if (col >= W) col -= W;
+            if (col >= W) col -= W;
+            extra += wc[a * K + b] * gpl[(int64_t)prow * W + col];
+          }
+        }
+        if (col_owned && o >= own0)
+          store_at<float>(gp + (int64_t)o * W * 4, o0, ADD ? (acc[o] + extra) + av[o] : acc[o] + extra);
+      }
+    }
+    // ---- weight gradient: the owned points' share of the channel's sums
+    {
+      float g[RPT];
+#pragma unroll
+      for (int o = 0; o < RPT; ++o) {
+        g[o] = (col_owned && o >= own0) ? tg[(r0 + o + P) * LW + xl + P] : 0.f;
+        gsum += g[o];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPT + K - 1; ++rr) {
+        float val[K];
+#pragma unroll
+        for (int b = 0; b < K; ++b) val[b] = tx[(r0 + rr) * LW + xl + b];
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          const int o = rr - a;
+          if (o >= 0 && o < RPT) {
+#pragma unroll
+            for (int b = 0; b < K; ++b) accw[a * K + b] += g[o] * val[b];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) {
+    float s = wave_sum_dpp(accw[i]);
+    if (xl == 0) red[wave][i] = s;
+  }
+  {
+    float s = wave_sum_dpp(gsum);
+    if (xl == 0) red[wave][K * K] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NW) {
+    float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    partial[((int64_t)c * chunks + chunk) * NW + threadIdx.x] = s;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 dwconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ gw,
                     float* __restrict__ gbias, int C, int KK, int chunks) {
@@ -864,12 +1143,34 @@ int wgrad_chunks(int B, int C, int tiles) {
   return std::max(1, std::min(chunks, items));
 }
 
+// staged-tiles backward: items per workgroup and workgroups per channel (~8192 workgroups: 8 resident sets of the chip)
+int bwd_tiles_per(int B, int C, int tiles) {
+  const int items = std::max(1, B * tiles);
+  const int chunks = std::max(1, std::min((8192 + C - 1) / C, items));
+  return (items + chunks - 1) / chunks;
+}
+int bwd_tiles_chunks(int B, int C, int tiles) {
+  const int items = std::max(1, B * tiles), per = bwd_tiles_per(B, C, tiles);
+  return (items + per - 1) / per;
+}
+
 }  // namespace
 
 // whole padded plane == one tile and the 16-byte staging path applies (even halo: k = 5)
 static int whole_plane_vec4(const float* src, int H, int W, int k) {
   return k == 5 && W == TW && H <= TH && ((int64_t)H * W) % 4 == 0 &&
          (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+}
+
+#ifndef DWCONV_TILES             // (A/B builds: 0 = the one-tile-per-workgroup kernels on every larger grid)
+#define DWCONV_TILES 1
+#endif
+// more than one tile, and the staged full-tile kernels apply: k = 5, at least one full tile each way, rows of whole
+// float4, 16-byte aligned tensors (every plane then is), byte offsets in a plane fit 32 bits
+static bool staged_tiles(const void* a, const void* b, int H, int W, int k) {
+  return DWCONV_TILES && k == 5 && H >= TH && W >= TW && (H > TH || W > TW) && W % 4 == 0 &&
+         (int64_t)H * W * 4 < (1ll << 32) && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(b) & 15) == 0;
 }
 
 #define DISPATCH_K(k, CALL)          \
@@ -891,6 +1192,13 @@ extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const floa
   if (DWCONV_PLANES && whole_plane_vec4(x, H, W, k)) {     // (k == 5 there)
     hipLaunchKernelGGL(dwconv_geo_fwd_planes_kernel<5>, dim3((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK)),
                        dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, H, planes);
+    PD_CHECK_LAUNCH("dwconv_geo_fwd");
+    return 0;
+  }
+  if (staged_tiles(x, y, H, W, k)) {
+    const int64_t nwg = (planes + PLANE_CHUNK - 1) / PLANE_CHUNK * tiles;
+    hipLaunchKernelGGL(dwconv_geo_fwd_tiles_kernel<5>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       y, C, H, W, tx, tiles, planes);
     PD_CHECK_LAUNCH("dwconv_geo_fwd");
     return 0;
   }
@@ -942,7 +1250,8 @@ extern "C" int paradis_dwconv_geo_dgrad_add(const float* gy, const float* w, con
 
 extern "C" size_t paradis_dwconv_geo_wgrad_ws_bytes(int B, int C, int H, int W, int k) {
   const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-  return (size_t)C * wgrad_chunks(B, C, tiles) * (k * k + 1) * sizeof(float) + 256;
+  const int chunks = std::max(wgrad_chunks(B, C, tiles), bwd_tiles_chunks(B, C, tiles));
+  return (size_t)C * chunks * (k * k + 1) * sizeof(float) + 256;
 }
 
 extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* gw, float* gbias,
@@ -968,8 +1277,10 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
 }
 
 // Both gradients of the stencil from one call: gx = dgrad(gy) (+ addend), gw / gbias.  On the whole-plane path
-// (k = 5, W = 64, H <= 32, aligned tensors: the reference grids at 5.625 degrees) ONE kernel reads gy once; elsewhere
-// the two kernels of paradis_dwconv_geo_dgrad / _wgrad run one after the other.  Results are bit-identical to theirs.
+// (k = 5, W = 64, H <= 32, aligned tensors: the reference grids at 5.625 degrees) and on the staged-tiles path (k = 5,
+// larger grids with W % 4 == 0) ONE kernel reads gy once; elsewhere the two kernels of paradis_dwconv_geo_dgrad / _wgrad
+// run one after the other.  gx is bit-identical to paradis_dwconv_geo_dgrad(_add)'s on every path; gw / gbias are
+// bit-identical to paradis_dwconv_geo_wgrad's except on the staged-tiles path (same terms, another fixed order).
 // workspace: paradis_dwconv_geo_wgrad_ws_bytes.  addend, gbias: nullable.
 extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const float* w, const float* addend, float* gx,
                                       float* gw, float* gbias, int B, int C, int H, int W, int k, void* workspace,
@@ -980,11 +1291,28 @@ extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const flo
   const bool fused = DWCONV_BWD_FUSED && DWCONV_PLANES && B > 0 && whole_plane_vec4(gy, H, W, k) &&
                      whole_plane_vec4(x, H, W, k) && (reinterpret_cast<uintptr_t>(gx) & 3) == 0 &&
                      (reinterpret_cast<uintptr_t>(addend) & 3) == 0;
+  if (B > 0 && staged_tiles(gy, x, H, W, k) && staged_tiles(gx, addend, H, W, k)) {
+    const int tx = (W + TW - 1) / TW, tiles = tx * ((H + TH - 1) / TH);
+    const int per = bwd_tiles_per(B, C, tiles), chunks = bwd_tiles_chunks(B, C, tiles);
+    float* partial = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (addend)
+      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend, gx,
+                         partial, B, C, H, W, tx, tiles, chunks, per);
+    else
+      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, false>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend, gx,
+                         partial, B, C, H, W, tx, tiles, chunks, per);
+    const int n = C * (k * k + 1);
+    hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias, C, k * k, chunks);
+    PD_CHECK_LAUNCH("dwconv_geo_bwd");
+    return 0;
+  }
   if (!fused) {
-    // (tiled grids: a one-pass kernel in the weight-gradient kernel's shape - one channel per workgroup, (sample, tile)
-    //  items in a loop, both tiles staged per item - was built and measured in round 5: 1004 us per call at 128 x 256,
-    //  B = 8, C = 1024 (2014 us with the addend) against 628 + 483 us for the two kernels: a workgroup stages, waits,
-    //  computes, and 2,048 of them do not overlap that the way 131,072 one-tile workgroups of the data gradient do)
+    // (what is left here: k != 5, rows that are not whole float4, grids smaller than a tile one way.  A first one-pass
+    //  kernel for the larger grids - one channel per workgroup, (sample, tile) items strided over two workgroups, both
+    //  tiles staged synchronously per item - measured 1004 us per call at 128 x 256, B = 8, C = 1024 against 628 + 483 us
+    //  for these two kernels; dwconv_geo_bwd_tiles_kernel above - next item's loads in flight, tile-fastest item order,
+    //  ~8192 workgroups - takes 822 us)
     if (int e = dwconv_geo_dgrad_launch(gy, w, addend, gx, B, C, H, W, k, stream)) return e;
     return paradis_dwconv_geo_wgrad(gy, x, gw, gbias, B, C, H, W, k, workspace, stream);
   }
