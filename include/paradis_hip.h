@@ -105,8 +105,7 @@ int paradis_dwconv_geo_dgrad_add(const float* gy, const float* w, const float* a
                                  int B, int C, int H, int W, int k, void* stream);
 /* Both gradients from one call (autograd of the same module): gx = dgrad(gy) (+ addend, nullable), gw [C,k,k],
  * gbias [C] or NULL.  k = 5 with 16-byte aligned tensors and W = 64, H <= 32 (one tile) or H >= 32, W >= 64, W % 4 == 0
- * (several tiles): one kernel that reads gy once; otherwise the two kernels above.  gx bit-identical to theirs; gw /
- * gbias too, except on the several-tiles path (same terms, another fixed order of summation).
+ * (several tiles): one kernel that reads gy once; otherwise the two kernels above.  Bit-identical to them.
  * workspace: paradis_dwconv_geo_wgrad_ws_bytes.  (ABI 7) */
 int paradis_dwconv_geo_bwd(const float* gy, const float* x, const float* w, const float* addend, float* gx,
                            float* gw, float* gbias, int B, int C, int H, int W, int k, void* workspace, void* stream);

@@ -823,10 +823,11 @@ __device__ __forceinline__ void item_of(int item, int B, int tiles, int& t, int&
 }
 
 // both gradients in one pass (dwconv_geo_bwd_planes_kernel's arithmetic on tiles): workgroup (channel c, chunk) walks a
-// contiguous range of the channel's B x tiles items (item_of); the 26 sums stay in registers across items.  The data gradient is the same sum in the same
-// order as dwconv_geo_dgrad_kernel's (bit-identical); the weight gradient partitions its sum differently from
-// dwconv_geo_wgrad_kernel (same terms, another - fixed - order).
-template <int K, bool ADD>
+// contiguous range of the channel's B x tiles items (item_of); the 26 sums stay in registers across items.  The
+// standalone entry points run the same kernel with one half compiled out: whichever way the gradients are asked for,
+// the bits are the same.  (The data gradient is also the one-tile-per-workgroup kernel's sum in the same order; the
+// weight gradient partitions its sum differently from dwconv_geo_wgrad_kernel: same terms, another fixed order.)
+template <int K, bool ADD, bool DG, bool WG>   // DG: data gradient, WG: weight gradient (either alone = the standalone entry points)
 __global__ void __launch_bounds__(256, 4)
 dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
                             const float* __restrict__ addend, float* __restrict__ gx, float* __restrict__ partial,
@@ -858,7 +859,7 @@ dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restric
     }
     const int64_t off = ((int64_t)n * C + c) * PS;
     sg.load(gy + off, qg, hg);
-    sg.load(x + off, qx, hx);
+    if (WG) sg.load(x + off, qx, hx);
   };
   if (i0 < i1) fetch(i0);
   for (int item = i0; item < i1; ++item) {
@@ -868,7 +869,7 @@ dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restric
     const int64_t off = ((int64_t)n * C + c) * PS;
     const float* gpl = gy + off;
     sg.store(tg, qg, hg);
-    sg.store(tx, qx, hx);
+    if (WG) sg.store(tx, qx, hx);
     __syncthreads();
     if (item + 1 < i1) fetch(item + 1);
     const unsigned o0 = (unsigned)((tp.ty0 + r0) * W + tp.tx0 + xl) * 4u;
@@ -882,7 +883,7 @@ dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restric
       for (int o = 0; o < RPT; ++o) av[o] = load_at<float>(ab + (int64_t)o * W * 4, o0);
     }
     // ---- data gradient of this tile (dwconv_geo_dgrad_kernel)
-    {
+    if constexpr (DG) {
       float wr[K * K];
 #pragma unroll
       for (int j = 0; j < K * K; ++j) wr[j] = wc[j];
@@ -942,7 +943,7 @@ dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restric
       }
     }
     // ---- weight gradient: the owned points' share of the channel's sums
-    {
+    if constexpr (WG) {
       float g[RPT];
 #pragma unroll
       for (int o = 0; o < RPT; ++o) {
@@ -966,6 +967,7 @@ dwconv_geo_bwd_tiles_kernel(const float* __restrict__ gy, const float* __restric
     }
     __syncthreads();
   }
+  if (!WG) return;
 #pragma unroll
   for (int i = 0; i < K * K; ++i) {
     float s = wave_sum_dpp(accw[i]);
@@ -1228,6 +1230,19 @@ static int dwconv_geo_dgrad_launch(const float* gy, const float* w, const float*
     PD_CHECK_LAUNCH("dwconv_geo_dgrad");
     return 0;
   }
+  if (staged_tiles(gy, gx, H, W, k) && staged_tiles(gy, addend, H, W, k)) {     // the one-pass kernel's data-gradient half
+    const int per = bwd_tiles_per(B, C, tiles), chunks = bwd_tiles_chunks(B, C, tiles);
+    const float* none = nullptr;
+    float* nopart = nullptr;
+    if (addend)
+      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, true, true, false>), dim3(C * chunks), dim3(256), 0,
+                         (hipStream_t)stream, gy, none, w, addend, gx, nopart, B, C, H, W, tx, tiles, chunks, per);
+    else
+      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, false, true, false>), dim3(C * chunks), dim3(256), 0,
+                         (hipStream_t)stream, gy, none, w, addend, gx, nopart, B, C, H, W, tx, tiles, chunks, per);
+    PD_CHECK_LAUNCH("dwconv_geo_dgrad");
+    return 0;
+  }
   const unsigned grid = (unsigned)((int64_t)B * C * tiles);
   DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_dgrad_kernel<KK>, dim3(grid), dim3(256), 0,
                                    (hipStream_t)stream, gy, w, addend, gx, C, H, W, tx, tiles,
@@ -1260,10 +1275,16 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
   if (int e = check_dw("dwconv_geo_wgrad", B, C, H, W, k)) return e;
   PD_REQUIRE(workspace != nullptr, "dwconv_geo_wgrad: workspace required");
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
-  const int chunks = B == 0 ? 1 : wgrad_chunks(B, C, tiles);
+  const bool staged = B > 0 && staged_tiles(gy, x, H, W, k);       // the one-pass kernel's weight-gradient half
+  const int chunks = B == 0 ? 1 : (staged ? bwd_tiles_chunks(B, C, tiles) : wgrad_chunks(B, C, tiles));
   float* partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  if (DWCONV_PLANES && whole_plane_vec4(x, H, W, k) && (reinterpret_cast<uintptr_t>(gy) & 3) == 0)
+  if (staged) {
+    const float* none = nullptr;
+    float* nogx = nullptr;
+    hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, false, false, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, none,
+                       none, nogx, partial, B, C, H, W, tx, tiles, chunks, bwd_tiles_per(B, C, tiles));
+  } else if (DWCONV_PLANES && whole_plane_vec4(x, H, W, k) && (reinterpret_cast<uintptr_t>(gy) & 3) == 0)
     hipLaunchKernelGGL(dwconv_geo_wgrad_planes_kernel<5>, dim3(C * chunks), dim3(256), 0, st, gy, x, partial, B, C,
                        H, chunks);
   else
@@ -1279,8 +1300,7 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
 // Both gradients of the stencil from one call: gx = dgrad(gy) (+ addend), gw / gbias.  On the whole-plane path
 // (k = 5, W = 64, H <= 32, aligned tensors: the reference grids at 5.625 degrees) and on the staged-tiles path (k = 5,
 // larger grids with W % 4 == 0) ONE kernel reads gy once; elsewhere the two kernels of paradis_dwconv_geo_dgrad / _wgrad
-// run one after the other.  gx is bit-identical to paradis_dwconv_geo_dgrad(_add)'s on every path; gw / gbias are
-// bit-identical to paradis_dwconv_geo_wgrad's except on the staged-tiles path (same terms, another fixed order).
+// run one after the other.  Bit-identical to paradis_dwconv_geo_dgrad(_add) and paradis_dwconv_geo_wgrad on every path.
 // workspace: paradis_dwconv_geo_wgrad_ws_bytes.  addend, gbias: nullable.
 extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const float* w, const float* addend, float* gx,
                                       float* gw, float* gbias, int B, int C, int H, int W, int k, void* workspace,
@@ -1297,11 +1317,11 @@ extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const flo
     float* partial = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     if (addend)
-      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend, gx,
-                         partial, B, C, H, W, tx, tiles, chunks, per);
+      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, true, true, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w,
+                         addend, gx, partial, B, C, H, W, tx, tiles, chunks, per);
     else
-      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, false>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend, gx,
-                         partial, B, C, H, W, tx, tiles, chunks, per);
+      hipLaunchKernelGGL((dwconv_geo_bwd_tiles_kernel<5, false, true, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w,
+                         addend, gx, partial, B, C, H, W, tx, tiles, chunks, per);
     const int n = C * (k * k + 1);
     hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias, C, k * k, chunks);
     PD_CHECK_LAUNCH("dwconv_geo_bwd");

@@ -465,8 +465,7 @@ def _(gy, x, k, has_bias):
 @_define("dwconv_geo_bwd(Tensor gy, Tensor x, Tensor weight, Tensor? addend, bool has_bias) -> (Tensor, Tensor, Tensor)")
 def _dwconv_geo_bwd(gy, x, weight, addend, has_bias):
     """(gx (+ addend), gw, gb) of the stencil in one call: with k = 5 on the reference grids one kernel that reads gy
-    once (paradis_dwconv_geo_bwd); gx bit-identical to ``dwconv_geo_dgrad`` (``_add``), gw / gb to ``dwconv_geo_wgrad``
-    except on grids of several tiles (same terms, another fixed summation order)."""
+    once (paradis_dwconv_geo_bwd); bit-identical to ``dwconv_geo_dgrad`` (``_add``) + ``dwconv_geo_wgrad``."""
     _f32(gy, x, weight, addend)
     gy, x, w = gy.contiguous(), x.contiguous(), weight.contiguous()
     if addend is not None:
