@@ -40,7 +40,9 @@ RAW = {}            # op name -> the Python function behind its HIP kernel (eage
 def _plain(t) -> bool:
     """a real device tensor in an eager, un-traced call: the kernels' Python functions may be called directly (fake /
     functional / subclass tensors - FakeTensorMode, make_fx, torch.export - must go through the dispatcher)"""
-    return type(t) is Tensor and not torch.is_grad_enabled()
+    return (type(t) is Tensor and not torch.is_grad_enabled()
+            and torch._C._len_torch_dispatch_stack() == 0                    # make_fx(tracing_mode="real"), any TorchDispatchMode
+            and torch._C._functorch.peek_interpreter_stack() is None)        # vmap / functional grad: plain-looking wrappers
 
 
 def _define(schema: str, autocast: bool = True):

@@ -135,3 +135,22 @@ def test_fake_kernels_of_backward_ops_give_the_right_shapes():
         assert O.slice_channels(e(B, 7, H, W), 3, 4).shape == (B, 4, H, W)
         loss, grad = O.paradis_loss(e(B, C, H, W), e(B, C, H, W), e(C), e(H), 1, 1.0, True)
         assert loss.shape == () and grad.shape == (B, C, H, W)
+
+
+def test_direct_kernel_calls_only_for_plain_untraced_tensors():
+    """The eager front ends call a kernel's Python function directly (``ops.RAW``) only where nothing could be watching
+    the dispatcher: a real ``torch.Tensor``, grad mode off (inside ``autograd.Function`` forward / a first-order
+    backward), no TorchDispatchMode (FakeTensorMode, ``make_fx`` - also with real tensors), no functorch transform."""
+    from torch.fx.experimental.proxy_tensor import make_fx
+    t = torch.randn(3)
+    assert not ops._plain(t)                        # grad mode on: a recording call, or create_graph=True
+    seen = []
+    with torch.no_grad():
+        assert ops._plain(t)
+        assert not ops._plain(torch.nn.Parameter(t))
+        make_fx(lambda x: (seen.append(ops._plain(x)), x * 2)[1], tracing_mode="real")(t)
+        torch.func.vmap(lambda x: (seen.append(ops._plain(x)), x.sum())[1])(torch.randn(2, 3))
+        with FakeTensorMode():
+            seen.append(ops._plain(torch.empty(2)))
+    assert seen == [False, False, False]
+    assert set(ops.RAW) == set(ops.OPS)
