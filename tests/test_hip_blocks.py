@@ -132,7 +132,7 @@ def test_weight_images_pair_launch_equals_the_two_single_launches(ops, M, K):
 # ----------------------------------------------------------------------------------- depthwise
 @pytest.mark.parametrize("k", [1, 3, 5, 7, 9, 11])
 @pytest.mark.parametrize("B,C,H,W", [(2, 6, 12, 16), (2, 5, 33, 64), (1, 3, 70, 130), (2, 4, 9, 8),
-                                     (2, 6, 32, 64), (3, 5, 16, 64), (1, 3, 96, 200)])   # whole-plane 16-byte staging (2), staged tiles (33x64, 96x200 at k = 5)
+                                     (2, 6, 32, 64), (3, 5, 16, 64), (1, 3, 96, 200), (2, 3, 32, 68)])   # whole-plane 16-byte staging (2), staged tiles (33x64, 96x200, 32x68 at k = 5)
 @pytest.mark.parametrize("bias", [False, True])
 def test_dwconv_geo(ops, k, B, C, H, W, bias):
     if (k - 1) // 2 > H - 2 or k - 1 > W or (k > 7 and (H < 2 * k or W < 2 * k)):
@@ -197,7 +197,7 @@ def test_dwconv_geo_skip_adds_the_other_gradient_in_the_dgrad_kernel(ops, k, B, 
                                        # many channels, one item per workgroup and many, W not a multiple of 4 (the
                                        # one-tile-per-workgroup kernels)
                                        (2, 6, 128, 256, 5), (1, 3, 70, 130, 5), (3, 5, 65, 64, 5), (2, 2100, 40, 72, 5),
-                                       (1, 4, 181, 360, 5), (9, 3, 64, 128, 5), (1, 2, 721, 1440, 5)])
+                                       (1, 4, 181, 360, 5), (9, 3, 64, 128, 5), (1, 2, 721, 1440, 5), (2, 3, 32, 68, 5), (0, 4, 64, 128, 5)])
 @pytest.mark.parametrize("add", [False, True])
 @pytest.mark.parametrize("bias", [False, True])
 def test_dwconv_geo_bwd_one_pass_is_bit_identical_to_the_two_calls(ops, B, C, H, W, k, add, bias):
