@@ -106,6 +106,9 @@ small_mix_kernel(const float* __restrict__ Wm, int ldo, int ldc, const float* __
 // (Rounds 1-3 split Co over the grid and combined the chunks with float atomicAdd: run-to-run differences in the
 // last bit of the GlobalBias gradients, which AdamW's normalisation can turn into visible parameter differences.)
 constexpr int GM8_SLICES = 16;
+#ifndef GM8_BATCH                // (A/B builds)
+#define GM8_BATCH 16
+#endif
 template <int CIN>
 __global__ void __launch_bounds__(64 * GM8_SLICES)
 gbias_gm8_kernel(const float* __restrict__ Pw, const float* __restrict__ gmap, float* __restrict__ gm8,
@@ -120,7 +123,17 @@ gbias_gm8_kernel(const float* __restrict__ Pw, const float* __restrict__ gmap, f
 #pragma unroll
   for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
   int o = o0;
-  for (; o + 8 <= o1; o += 8) {      // eight independent row loads in flight
+  for (; o + GM8_BATCH <= o1; o += GM8_BATCH) {      // sixteen independent row loads in flight (round 5; eight before: the
+    float g[GM8_BATCH];                              //  wave's 64-row walk is a chain of batches, each a memory round trip)
+#pragma unroll
+    for (int j = 0; j < GM8_BATCH; ++j) g[j] = gmap[(int64_t)(o + j) * P + pc];
+#pragma unroll
+    for (int j = 0; j < GM8_BATCH; ++j)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+        if (c < Cin) acc[c] += Pw[(int64_t)(o + j) * Cin + c] * g[j];
+  }
+  for (; o + 8 <= o1; o += 8) {
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = gmap[(int64_t)(o + j) * P + pc];
@@ -162,6 +175,51 @@ gbias_gpw_kernel(const float* __restrict__ gmap, const float* __restrict__ m8,
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) gPw[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// The same sums with RW output rows per workgroup and 16-byte loads (round 5; the larger grids): a workgroup walks the
+// whole pixel range once - its RW rows of gmap come from HBM once, the Cin rows of m8 from L2 (Co / RW times 4 Cin P
+// bytes; the (o, c)-workgroup form above pulls every row of gmap Cin times: 809 MB at 128x256, Co = 1024).  RW + Cin
+// float4 loads in flight per thread and iteration.  Needs P % 4 == 0 and 16-byte aligned rows.
+template <int RW, int CIN>
+__global__ void __launch_bounds__(256)
+gbias_gpw_rows_kernel(const float* __restrict__ gmap, const float* __restrict__ m8, float* __restrict__ gPw, int Cin,
+                      int Co, int64_t P4) {
+  __shared__ float red[4][RW * CIN];
+  const int o0 = blockIdx.x * RW;
+  float acc[RW][CIN];
+#pragma unroll
+  for (int j = 0; j < RW; ++j)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[j][c] = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(gmap);
+  const float4* m4 = reinterpret_cast<const float4*>(m8);
+  for (int64_t q = threadIdx.x; q < P4; q += 256) {
+    float4 m[CIN], g[RW];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) m[c] = m4[(int64_t)min(c, Cin - 1) * P4 + q];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) g[j] = g4[(int64_t)min(o0 + j, Co - 1) * P4 + q];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+        acc[j][c] += (g[j].x * m[c].x + g[j].y * m[c].y) + (g[j].z * m[c].z + g[j].w * m[c].w);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < RW; ++j)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float sum = wave_sum_dpp(acc[j][c]);
+      if (lane == 0) red[wave][j * CIN + c] = sum;
+    }
+  __syncthreads();
+  if (threadIdx.x < RW * CIN) {
+    const int j = threadIdx.x / CIN, c = threadIdx.x - j * CIN;
+    if (o0 + j < Co && c < Cin)
+      gPw[(int64_t)(o0 + j) * Cin + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
 }
 
 // T1[c,r,h] = sum_w gm8[c,h,w] V[r,w]   (one wave per output)
@@ -384,7 +442,25 @@ bias_grads_vec4_kernel(const float* __restrict__ dz, float* __restrict__ gmap, f
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+void launch_gm8(const float* Pw, const float* gmap, float* gm8, int Cin, int Co, int64_t P, hipStream_t st) {   // Cin <= 16
+  const dim3 grid((unsigned)((P + 63) / 64)), block(64 * GM8_SLICES);
+  if (Cin <= 8) hipLaunchKernelGGL(gbias_gm8_kernel<8>, grid, block, 0, st, Pw, gmap, gm8, Cin, Co, P);
+  else hipLaunchKernelGGL(gbias_gm8_kernel<16>, grid, block, 0, st, Pw, gmap, gm8, Cin, Co, P);
+}
+#ifndef GBIAS_GPW_ROWS           // (A/B builds: 0 = one workgroup per (o, c) on every grid)
+#define GBIAS_GPW_ROWS 1
+#endif
+#ifndef GBIAS_GPW_ROWS_MINP      // smallest pixel count that takes the rows kernel
+#define GBIAS_GPW_ROWS_MINP 2048
+#endif
 void launch_gpw(const float* gmap, const float* m8, float* gPw, int Cin, int Co, int64_t P, hipStream_t st) {
+  if (GBIAS_GPW_ROWS && Cin <= 8 && P % 4 == 0 && P >= GBIAS_GPW_ROWS_MINP && aligned16(gmap) && aligned16(m8)) {
+    if (Co >= 1024)
+      hipLaunchKernelGGL((gbias_gpw_rows_kernel<4, 8>), dim3((Co + 3) / 4), dim3(256), 0, st, gmap, m8, gPw, Cin, Co, P / 4);
+    else
+      hipLaunchKernelGGL((gbias_gpw_rows_kernel<2, 8>), dim3((Co + 1) / 2), dim3(256), 0, st, gmap, m8, gPw, Cin, Co, P / 4);
+    return;
+  }
   hipLaunchKernelGGL(gbias_gpw_kernel, dim3(Co * Cin), dim3(256), 0, st, gmap, m8, gPw, Cin, P);
 }
 
@@ -434,14 +510,16 @@ extern "C" int paradis_global_bias_map_bwd(const float* gmap, const float* A, co
     launch_gpw(gmap, m8, gPw, Cin, Co, P, st);
     // gm8[c,p] = sum_o Pw[o,c] gmap[o,p]
     if (Cin <= 16) {
-      hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 63) / 64)), dim3(64 * GM8_SLICES), 0, st, Pw, gmap,
-                         gm8, Cin, Co, P);
+      launch_gm8(Pw, gmap, gm8, Cin, Co, P, st);
     } else {
       hipLaunchKernelGGL(small_mix_kernel, dim3((unsigned)((P + 255) / 256), Cin), dim3(256), 0, st, Pw, 1,
                          Cin, gmap, gm8, Cin, Co, P);
     }
     gm8_src = gm8;
   }
+  // (T1, T2 and the finish in ONE kernel - everything is local to a rank index r: R workgroups walking gm8 once, row dot
+  //  products by wave sums, column sums in registers - was built in round 5: 31.5 us per call in the 32x64 step against
+  //  9.1 + 10.5 + 9.1 us for the three wide kernels, 3.2 against 1.56 ms at 721x1440; removed)
   const int64_t nwaves = (int64_t)Cin * R * H;
   hipLaunchKernelGGL(gbias_t1_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, st,
                      gm8_src, V, T1, Cin, R, H, W);
@@ -597,8 +675,7 @@ extern "C" int paradis_global_bias_proj_bwd(const float* gmap, const float* m8, 
   PD_REQUIRE(Cin >= 1 && Cin <= 16 && Co >= 1 && P >= 1, "global_bias_proj_bwd: bad shape (Cin <= 16)");
   hipStream_t st = (hipStream_t)stream;
   launch_gpw(gmap, m8, gPw, Cin, Co, P, st);
-  hipLaunchKernelGGL(gbias_gm8_kernel<16>, dim3((unsigned)((P + 63) / 64)), dim3(64 * GM8_SLICES), 0, st, Pw, gmap, gm8,
-                     Cin, Co, P);
+  launch_gm8(Pw, gmap, gm8, Cin, Co, P, st);
   PD_CHECK_LAUNCH("global_bias_proj_bwd");
   return 0;
 }

@@ -53,7 +53,9 @@ def test_pointwise_gemm(ops, B, Ci, Co, H, W, act):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,cin,R", [(2, 10, 8, 12, 16, 4, 6), (2, 128, 160, 32, 64, 8, 16),
                                                (1, 130, 260, 17, 32, 3, 5),
-                                               (1, 32, 64, 64, 128, 8, 6)])    # last: P >= 8192, the row-wise gPw kernel
+                                               (1, 32, 64, 64, 128, 8, 6),     # P >= 8192: the row-wise gPw kernel, two rows per workgroup
+                                               (1, 16, 1028, 64, 128, 8, 6),   # ... four rows per workgroup
+                                               (1, 8, 16, 40, 300, 5, 7)])     # W > 256, odd channel / rank counts
 @pytest.mark.parametrize("act", [None, "SiLU"])
 def test_pointwise_fused_global_bias_projection(ops, B, Ci, Co, H, W, cin, R, act):
     """GlobalBias with projection applied inside the GEMM epilogue (no [Co,H,W] map in the forward)
