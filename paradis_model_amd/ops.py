@@ -37,12 +37,19 @@ OPS = {}            # op name -> OpOverload (torch.ops.paradis.<name>.default)
 RAW = {}            # op name -> the Python function behind its HIP kernel (eager backward formulas call it directly)
 
 
+# (private torch entry points, resolved once: if a torch build lacks them nothing is ever "plain" and every call takes
+#  the dispatcher - slower, never wrong)
+_dispatch_modes = getattr(torch._C, "_len_torch_dispatch_stack", None)
+_functorch_top = getattr(getattr(torch._C, "_functorch", None), "peek_interpreter_stack", None)
+_CAN_BE_PLAIN = _dispatch_modes is not None and _functorch_top is not None
+
+
 def _plain(t) -> bool:
     """a real device tensor in an eager, un-traced call: the kernels' Python functions may be called directly (fake /
     functional / subclass tensors - FakeTensorMode, make_fx, torch.export - must go through the dispatcher)"""
-    return (type(t) is Tensor and not torch.is_grad_enabled()
-            and torch._C._len_torch_dispatch_stack() == 0                    # make_fx(tracing_mode="real"), any TorchDispatchMode
-            and torch._C._functorch.peek_interpreter_stack() is None)        # vmap / functional grad: plain-looking wrappers
+    return (_CAN_BE_PLAIN and type(t) is Tensor and not torch.is_grad_enabled()
+            and _dispatch_modes() == 0                    # make_fx(tracing_mode="real"), any TorchDispatchMode
+            and _functorch_top() is None)                 # vmap / functional grad: plain-looking wrappers
 
 
 def _define(schema: str, autocast: bool = True):
