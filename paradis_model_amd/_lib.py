@@ -121,7 +121,14 @@ def dptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# the current stream's handle without building a torch.cuda.Stream object per call (7 us each, ~600 calls per training
+# step); the private entry point is resolved once, the public one is the fallback
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
