@@ -52,6 +52,14 @@ def _plain(t) -> bool:
             and _functorch_top() is None)                 # vmap / functional grad: plain-looking wrappers
 
 
+def _eager_forward(name: str, op, *args):
+    """inside an ``autograd.Function.forward`` of an eager front end: the kernel's Python function directly where nothing
+    watches the dispatcher and no autocast rule has to widen the inputs, else the registered op"""
+    if _plain(args[0]) and not torch.is_autocast_enabled("cuda"):
+        return RAW[name](*args)
+    return op(*args)
+
+
 def _define(schema: str, autocast: bool = True):
     """Register ``schema`` in the ``paradis`` namespace with the decorated function as its HIP kernel."""
     name = schema[: schema.index("(")]
@@ -371,7 +379,7 @@ class _AdvectVelEager(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *args):
-        out = _sl_advect_vel(*args)
+        out = _eager_forward("sl_advect_vel", _sl_advect_vel, *args)
         _advv_setup(ctx, args, out)
         return out
 
@@ -543,7 +551,7 @@ class _DwconvSkip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        y = _dwconv_geo(x, weight, bias)
+        y = _eager_forward("dwconv_geo", _dwconv_geo, x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)
@@ -770,7 +778,7 @@ class _ChannelNormSkip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, eps):
-        y, mean, rstd = _channel_norm(x1, x2, weight, bias, eps)
+        y, mean, rstd = _eager_forward("channel_norm", _channel_norm, x1, x2, weight, bias, eps)
         ctx.save_for_backward(x1, x2, weight, mean, rstd)
         ctx.set_materialize_grads(False)
         return y, x1
@@ -1345,7 +1353,7 @@ class _PointwiseEager(torch.autograd.Function):
     def forward(ctx, *args):
         # (inside autocast the op's autocast rule widens bf16 / fp16 inputs: through the dispatcher; otherwise straight
         #  to the kernel's Python function - same checks, same launch)
-        out = RAW["pointwise"](*args) if (_plain(args[0]) and not torch.is_autocast_enabled("cuda")) else _pointwise(*args)
+        out = _eager_forward("pointwise", _pointwise, *args)
         _pw_setup(ctx, args, out)
         return out
 
