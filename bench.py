@@ -136,7 +136,20 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, nlat, nlon, poles, batch, steps_timed=2):
+def cpu_model() -> str:
+    """CPU model string of the box ('core count and CPU model printed')"""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(cfg, nlat, nlon, poles, batch, steps_timed=2, warmup=3):
     """Oracle (CPU restatement of the reference path: same ATen/oneDNN operators) training step
     on the host cores: fwd + loss + bwd + AdamW, fp32."""
     torch.set_num_threads(usable_cores())
@@ -169,14 +182,16 @@ def cpu_baseline(cfg, nlat, nlon, poles, batch, steps_timed=2):
         O.paradis_loss(y, tgt[:, 0], fw, lw).backward()
         opt.step()
 
-    step()  # warm-up
+    for _ in range(warmup):
+        step()
     t0 = time.perf_counter()
     for _ in range(steps_timed):
         step()
     dt = (time.perf_counter() - t0) / steps_timed
-    return {"value": batch / dt, "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{steps_timed} train steps at batch {batch} on the same "
-                                      f"{nlat}x{nlon} S=1 workload (1 warm-up), {dt:.2f} s/step"}
+    return {"value": batch / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
+            "kind": "port", "batch": batch, "s_per_step": dt,
+            "sample": f"{steps_timed} train steps at batch {batch} on the same "
+                      f"{nlat}x{nlon} S=1 workload ({warmup} warm-up), {dt:.2f} s/step"}
 
 
 def _rooflines(s, elapsed_s, gemm):
@@ -189,8 +204,12 @@ def _rooflines(s, elapsed_s, gemm):
         ms = sum(g["ms"] for g in gem)
         n = sum(g["launches"] for g in gem)
         ach = flops / (ms * 1e-3) / 1e12
-        products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS}.get(gemm)
-        if gemm == "bf16x3":
+        products = {"f16x2": 3, "bf16x3": SPLIT_PRODUCTS, "bf16": 1}.get(gemm)
+        if gemm == "bf16":     # the bf16-mixed (autocast) leg: ONE product per multiply, the dense bf16 peak itself
+            kname = ("pw_gemm_bf16 kernels (fwd+dgrad+wgrad; operands rounded to bf16, 1 x v_mfma_f32_32x32x16_bf16 per "
+                     "product, fp32 accumulate) - NOT reference-width for the fp32 parity path")
+            peak = MFMA_BF16_PEAK_TFLOPS
+        elif gemm == "bf16x3":
             kname = ("pw_gemm_split_wide_kernel<2, 3>/pw_gemm_wgrad_split_kernel<3> (fwd+dgrad+wgrad; fp32 operands as "
                      "3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate)")
             peak = MFMA_BF16_PEAK_TFLOPS / products
@@ -201,18 +220,19 @@ def _rooflines(s, elapsed_s, gemm):
         else:
             kname = "pw_gemm_dma_kernel/pw_gemm_kernel (fwd+dgrad+wgrad, v_mfma_f32_32x32x2_f32)"
             peak = MFMA_F32_PEAK_TFLOPS
-        gemm_traffic, gemm_src = pmc_traffic("pw_gemm")
+        # (the committed PMC passes profiled the default arithmetic: no read-back for the bf16-mixed leg)
+        gemm_traffic, gemm_src = (None, None) if gemm == "bf16" else pmc_traffic("pw_gemm")
         out["roofline"] = {"kernel": kname,
                            "bound": "mfma", "achieved": ach, "peak": peak,
                            "unit": "TFLOP/s", "frac": ach / peak,
                            "flops": "algorithmic 2*M*N*K per GEMM (fp32-equivalent)"
                                     + (f"; executed 16-bit MFMA rate = {products}x achieved, peak = 2500/{products}"
-                                       if products else ""),
+                                       if products and products > 1 else ""),
                            "traffic": gemm_traffic, "traffic_source": gemm_src,
                            "launches": n, "avg_launch_ms": ms / n,
                            "flops_per_launch": flops / n,
                            "share_of_step": ms / (1e3 * elapsed_s),
-                           "mfma_busy_pmc": pmc_mfma_busy()}
+                           "mfma_busy_pmc": None if gemm == "bf16" else pmc_mfma_busy()}
     for key, name in (("sl_advect_fwd", "roofline_advect_fwd"), ("sl_advect_bwd", "roofline_advect_bwd")):
         if key in s:
             r = s[key]
@@ -291,6 +311,54 @@ def other_config_leg(name, n_steps, dev, gemm):
 OTHER_CONFIGS = (("era5_5.625deg_32x64_S6_B32", 2), ("era5_1.4deg_128x256_S1_B8", 3), ("era5_0.25deg_721x1440_fwd_B1", 3))
 
 
+def _launch_command(n_gpus: int, argv, port: int):
+    """torchrun command line for N ranks of this file on ONE node (the form the task contract names:
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)."""
+    child_argv = [a for a in argv if a != "--launch-only"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *child_argv]
+
+
+def _self_launch(args) -> int:
+    """Parent of a bare `python bench.py --gpus N`: spawns the ranks with torch.distributed.run as a CHILD process
+    (reference train.py:49: Lightning's strategy="ddp" does the same per-GPU process launch), relays the one JSON line
+    rank 0 printed and returns the launcher's return code.  Runs before any GPU initialisation: counting devices
+    (`torch.cuda.device_count()`) does not create a HIP context."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = _launch_command(args.gpus, sys.argv[1:], port)
+    if args.launch_only:
+        print(json.dumps({"launch": cmd, "n_gpus": args.gpus, "master_addr": "127.0.0.1", "master_port": port}))
+        return 0
+    share = os.environ.get("PARADIS_SHARE_GPU0") == "1"      # test hook: all ranks on cuda:0 over gloo
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)\n")
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env["PARADIS_BENCH_LAUNCHER"] = "bench.py self-launch (torch.distributed.run child)"
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr: inherited, streams through
+    line = None
+    for ln in proc.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            sys.stderr.write(ln + "\n")                      # launcher chatter never reaches our stdout
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a result line\n")
+        return 1
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,7 +397,18 @@ def main():
                          "implies --no-kernel-events and skips the extra legs")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the HIP-event timing of the GEMM/advection launches")
+    ap.add_argument("--launch-only", action="store_true",
+                    help="with --gpus N > 1 and no torchrun environment: print the launcher command line that would start "
+                         "the N ranks (one JSON line) and exit; nothing touches a GPU")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` called bare (no torchrun environment): start the N ranks OURSELVES, as fresh child
+    # processes, before anything in this process touches the GPU (the parent never initialises HIP, so there is no
+    # exec of a GPU-initialised process), relay rank 0's one JSON line, exit with the launcher's return code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args))
+    if args.launch_only:
+        raise SystemExit("--launch-only: nothing to launch (--gpus 1, or already inside a torchrun environment)")
 
     # The contract is ONE JSON line on stdout.  Libraries write to the C-level stdout behind Python's back (RCCL
     # announces "Librccl path : ..." when a process group initialises): everything but the final line goes to stderr.
@@ -356,12 +435,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    distinct_devices = 1
     if world > 1 and os.environ.get("PARADIS_SHARE_GPU0") != "1":
         # one process per GPU: every rank must own a distinct device of this node
         ids = [None] * world
         torch.distributed.all_gather_object(ids, (os.uname().nodename, torch.cuda.current_device()))
         if len(set(ids)) != world:
             raise SystemExit(f"ranks share a device: {ids}")
+        distinct_devices = len(set(ids))
 
     global WORKLOAD
     WORKLOAD = args.workload
@@ -590,6 +671,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ddp_efficiency_vs": None,     # never reported here: the driver divides by its own N = 1 run
         "dtype": ("bf16-mixed (NOT reference-width: the reference's AMP mode; one-product bf16 GEMMs, fp32 storage)" if args.amp
                   else "f32" if args.gemm != "f16x2" else "f32 storage, f16x2 block-exponent GEMM emulation"),
         "data": "synthetic",
@@ -597,7 +679,11 @@ def main():
                    "per_gpu_batch": B, "global_batch": world * B, "parameters": 60038475,
                    "optimizer": args.optimizer, "parallelism": f"dp{world}",
                    "ddp": ({"bucket_cap_mb": args.bucket_mb, "static_graph": bool(args.static_graph),
-                            "backend": torch.distributed.get_backend()} if world > 1 else None),
+                            "backend": torch.distributed.get_backend(),
+                            "world_size_seen": torch.distributed.get_world_size(),
+                            "distinct_devices": distinct_devices,
+                            "launcher": os.environ.get("PARADIS_BENCH_LAUNCHER", "external torchrun")}
+                           if world > 1 else None),
                    "gemm_arithmetic": args.gemm,
                    "gemm_arithmetic_detail": {
                        "f16x2": "NOT reference-width: two f16 terms of the per-tensor scaled operands (22 significand "
@@ -612,7 +698,7 @@ def main():
                    "final_loss": final_loss},
     }
     if prof is not None and rank == 0:
-        out.update(_rooflines(prof.summary(), elapsed, args.gemm))
+        out.update(_rooflines(prof.summary(), elapsed, "bf16" if args.amp else args.gemm))
     out.update(legs)
     # The other BASELINE configs that fit one GPU, as bounded legs of the same process (each frees memory first):
     # configs[2] (S = 6 rollout), configs[3]'s per-GPU shape (128x256, B = 8) and configs[4] (0.25-degree forward).
@@ -624,7 +710,15 @@ def main():
         torch.cuda.empty_cache()
         out["other_configs"] = {name: other_config_leg(name, n, dev, args.gemm) for name, n in OTHER_CONFIGS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=8)
+        # configs[0] (B = 2, the reference's own CPU case: >= 3 warm-ups) is the record; the
+        # headline's own batch (configs[1], B = 32) as a bounded second leg beside it (1 warm-up + 2 timed steps)
+        out["cpu_baseline"] = cpu_baseline(cfg, nlat, nlon, poles, args.cpu_batch, steps_timed=8, warmup=3)
+        if not args.no_extra_legs and B != args.cpu_batch and nlat * nlon * B <= 32 * 64 * 32:
+            try:
+                out["cpu_baseline"]["headline_batch_leg"] = cpu_baseline(cfg, nlat, nlon, poles, B, steps_timed=2,
+                                                                         warmup=1)
+            except Exception as exc:
+                out["cpu_baseline"]["headline_batch_leg"] = {"error": repr(exc)[:300]}
     if world > 1:
         torch.distributed.destroy_process_group()
     sys.stdout.flush()
