@@ -1294,6 +1294,73 @@ def _pw_setup(ctx, inputs, output):
     ctx.set_materialize_grads(False)
 
 
+# ---- weight gradients on a side stream (round 6) -------------------------------------------------------------
+# The weight-gradient GEMM of a pointwise layer depends on (dz, saved x) only; nothing of the dgrad chain waits for it
+# (reference model/paradis.py:228-254: per-layer chain).  Issued on a second HIP stream it runs UNDER the memory- /
+# VALU-bound kernels of the blocks that follow in backward (ChannelNorm, stencil, advection, blend) instead of in
+# series with them.  Ordering contract:
+#   * the side stream waits for an event recorded on the launching stream right after dz exists;
+#   * dz / x / amax tensors are kept referenced until the launching stream has waited for the GEMM's completion event
+#     (lagged by ``WgradSide.LAG`` launches, so that wait never stalls), so the caching allocator cannot hand their
+#     blocks to later launching-stream kernels while the side stream still reads them - no ``record_stream`` (which a
+#     graph capture would turn into memory held to the end of the capture);
+#   * gW (and the fused bias gradient) are allocated ON the side stream; whoever consumes them on the launching stream
+#     - autograd's AccumulateGrad (a pointer move while ``.grad`` is None), the optimiser, DDP's bucket copy - must be
+#     ordered after the side stream: ``WgradSide.join()`` runs as an autograd-engine callback at the end of every
+#     backward pass that used the side stream, and ``DelayedGrads`` (model/paradis.py) delivers the gradients of one
+#     ADR layer to their AccumulateGrad nodes - hence to DDP's reducer hooks - one layer late, after a join of exactly
+#     those launches.
+class WgradSide:
+    LAG = 6                    # launches kept in flight before the launching stream waits for the oldest
+    enabled = os.environ.get("PARADIS_WGRAD_STREAM", "0") == "1"
+    PRIORITY = int(os.environ.get("PARADIS_WGRAD_STREAM_PRIORITY", "0"))    # torch.cuda.Stream priority of the side stream
+    _streams = {}              # device index -> torch.cuda.Stream
+    _pending = []              # [(event, refs)] oldest first
+    _callback_queued = False
+
+    @classmethod
+    def stream(cls, device) -> "torch.cuda.Stream":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = cls._streams.get(idx)
+        if st is None:
+            st = cls._streams[idx] = torch.cuda.Stream(device=idx, priority=cls.PRIORITY)
+        return st
+
+    @classmethod
+    def launch(cls, fn, dz, x, *rest):
+        """run ``fn(dz, x, *rest)`` on the side stream, ordered after everything already enqueued on the current one"""
+        side = cls.stream(dz.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            out = fn(dz, x, *rest)
+            done = torch.cuda.Event()
+            done.record()
+        cur = torch.cuda.current_stream()
+        cls._pending.append((done, cur, (dz, x, rest)))
+        while len(cls._pending) > cls.LAG:
+            ev, st, _refs = cls._pending.pop(0)
+            st.wait_event(ev)
+        if not cls._callback_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.join)
+                cls._callback_queued = True
+            except RuntimeError:       # not inside a backward pass (a direct call of the backward op): join now
+                cls.join()
+        return out
+
+    @classmethod
+    def join(cls) -> None:
+        """the current stream waits for every side-stream launch issued so far; references are dropped"""
+        cls._callback_queued = False
+        # (the engine runs its callbacks on a worker thread whose current stream is not the launching one: every entry
+        #  remembers the stream it was launched from)
+        for ev, st, _refs in cls._pending:
+            st.wait_event(ev)
+        cls._pending.clear()
+
+
 def _pw_backward(ctx, gy, gz=None, gamax=None, raw=False):
     """``raw``: called from ``_PointwiseEager.backward`` - an eager, un-traced backward: the HIP kernels' Python functions
     are called directly instead of through the dispatcher (~250 op calls per training step at ~12 us each of dispatcher
@@ -1327,7 +1394,10 @@ def _pw_backward(ctx, gy, gz=None, gamax=None, raw=False):
     want_m = (has_map and need[3]) or want_p
     if need[1]:
         fused_b = want_b and not want_m     # bias gradient = row sums of dz: fused into the wgrad GEMM
-        gw, gbf = K["pw_gemm_wgrad"](dz, x, fused_b, dz_amax, x_amax, scheme)
+        if raw and WgradSide.enabled:
+            gw, gbf = WgradSide.launch(K["pw_gemm_wgrad"], dz, x, fused_b, dz_amax, x_amax, scheme)
+        else:
+            gw, gbf = K["pw_gemm_wgrad"](dz, x, fused_b, dz_amax, x_amax, scheme)
         gw = gw.reshape(weight.shape)
         if fused_b:
             gb, want_b = gbf, False
