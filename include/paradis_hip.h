@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 8: PARADIS_GEMM_BF16 scheme, paradis_pw_gemm_wgrad_slabs (query); no signature changed; 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 9: bf16-stored tensors of the bf16-mixed mode (paradis_pw_gemm_fwd16 / _dgrad16 / _wgrad16, paradis_bias_grads16): additions only; 8: PARADIS_GEMM_BF16 scheme, paradis_pw_gemm_wgrad_slabs (query); no signature changed; 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -197,6 +197,32 @@ int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbi
                           int B, int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
                           const uint32_t* dy_amax, const uint32_t* x_amax /* PARADIS_GEMM_F16X2 only */,
                           void* workspace, void* stream);
+
+/* ---- bf16-STORED tensors of the bf16-mixed mode (ABI 9; PARADIS_GEMM_BF16 only).  Under torch.autocast(bfloat16) the
+ * reference's nn.Conv2d calls (model/blocks.py:86,110) produce bf16 TENSORS (config/paradis_settings.yaml:75 ->
+ * train.py:56); these entry points take / write such tensors in place of the fp32 words holding bf16 values that the
+ * fp32-pointer entry points above use in this scheme: same values bit for bit, half the bytes.  `io16` says which
+ * tensors are bf16 (2 bytes per element; all strides stay in ELEMENTS); everything not named is fp32.
+ *   fwd16  : PARADIS_IO_X16 = X,  PARADIS_IO_Y16 = Y and zpre (no residual then)
+ *   dgrad16: PARADIS_IO_X16 = dY, PARADIS_IO_Y16 = dX, PARADIS_IO_Z16 = zpre
+ *   wgrad16: PARADIS_IO_X16 = X,  PARADIS_IO_DY16 = dY (dW, gbias fp32)
+ * A bf16 activation operand needs N % 8 == 0 (wgrad: N % 16 == 0) and 16-byte aligned planes: it is staged HBM -> LDS by
+ * LDS-DMA and transposed by ds_read_b64_tr_b16 (fwd / dgrad), never touching the vector ALU.  Wsplit / WTsplit: the
+ * PARADIS_GEMM_BF16 weight images of paradis_pw_gemm_split_weights. */
+#define PARADIS_IO_X16 1
+#define PARADIS_IO_Y16 2
+#define PARADIS_IO_Z16 4
+#define PARADIS_IO_DY16 8
+int paradis_pw_gemm_fwd16(const void* Wsplit, const void* X, const float* bias, const float* map, const float* m8,
+                          const float* pwT, int cin, const float* res, const float* gate /* or NULL */, void* Y,
+                          void* zpre, int B, int M, int K, int N, int64_t x_bs, int64_t res_bs, int64_t y_bs, int act,
+                          int io16, void* stream);
+int paradis_pw_gemm_dgrad16(const void* WTsplit, const void* dY, const void* zpre, void* dX, int B, int M, int K, int N,
+                            int64_t dy_bs, int64_t z_bs, int64_t dx_bs, int act, int io16, void* stream);
+int paradis_pw_gemm_wgrad16(const void* dY, const void* X, float* dW, float* gbias, int B, int M, int K, int N,
+                            int64_t dy_bs, int64_t x_bs, int io16, void* workspace, void* stream);
+/* paradis_bias_grads on a bf16-stored dz (P % 8 == 0, 16-byte aligned rows); outputs fp32 */
+int paradis_bias_grads16(const void* dz, float* gmap, float* gbias, int B, int C, int P, int64_t dz_bs, void* stream);
 
 /* ---- a8: ChannelNorm (reference model/blocks.py:118-134): per-pixel, unbiased variance.
  * x may be the virtual concatenation [x1 (C1 ch, batch stride x1_bs) ; x2 (C2 ch)] (paradis.py:249). */

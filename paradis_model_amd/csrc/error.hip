@@ -21,4 +21,4 @@ bool paradis_deterministic() {
 }
 
 extern "C" const char* paradis_last_error(void) { return g_err; }
-extern "C" int paradis_abi_version(void) { return 8; }   // 8: round-5 additions (paradis_pw_gemm_wgrad_slabs, ...); 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: advection workspace sized per flags (strip schedule); 5: amax side outputs removed (4: GEMM scheme arguments + paradis_amax_partials)
+extern "C" int paradis_abi_version(void) { return 9; }   // 9: round 6, bf16-STORED tensors of the bf16-mixed mode: paradis_pw_gemm_fwd16 / _dgrad16 / _wgrad16, paradis_bias_grads16 (additions, no signature changed; paradis_pw_gemm_wgrad_ws_bytes shrank by 4 KiB); 8: round-5 additions (paradis_pw_gemm_wgrad_slabs, ...); 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: advection workspace sized per flags (strip schedule); 5: amax side outputs removed (4: GEMM scheme arguments + paradis_amax_partials)

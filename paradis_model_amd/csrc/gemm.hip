@@ -57,11 +57,13 @@ struct GemmArgs {
   // f16x2 scheme: where the operands' max |value| comes from.  a_amax: one word (bits of max |A|, weight
   // image tail) for fwd/dgrad, PARADIS_AMAX_PARTIALS words for wgrad; b_amax: PARADIS_AMAX_PARTIALS words.
   const uint32_t* a_amax; const uint32_t* b_amax;
+  // PARADIS_GEMM_BF16 only (round 6): which tensors are STORED as bf16 (2 bytes per element; strides stay in elements).
+  // IO_B16: the activation operand B (fwd: X, dgrad: dY) - pw_gemm_b16_kernel stages it by LDS-DMA and reads it with
+  // ds_read_b64_tr_b16; IO_C16: the output C (and zout); IO_ZM16: zmul.  Residual, bias and maps are always fp32.
+  int io16;
   // (PARADIS_GEMM_BF16, the reference's bf16-mixed mode: the result is rounded to bf16 where the reference's autocast
   //  conv2d rounds it - the pre-activation and the activated value (fwd), the activation-gradient product (dgrad) -
   //  before the fp32 residual / blend; a compile-time property of pw_gemm_bf16_k32_kernel's epilogue.  Stored as fp32.)
-  // wgrad: one word per K-range slab for the soft rendezvous of the slab's tiles (NULL = none), see WGRAD_SYNC_T
-  unsigned* sync;
 };
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
@@ -153,6 +155,14 @@ __device__ __forceinline__ void gemm_add_projection(const GemmArgs& g, f32x16 (&
 __device__ __forceinline__ float gate_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
 // value of x rounded to bf16 (round to nearest even; a NaN stays a NaN: v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+constexpr int IO_B16 = 1, IO_C16 = 2, IO_ZM16 = 4, IO_A16 = 8;     // GemmArgs::io16 (IO_A16: wgrad's dY operand)
+// bf16 storage: element i of a bf16 array as a float / a bf16-VALUED float (already rounded) into a bf16 array
+__device__ __forceinline__ float ld_bf16(const void* p, int64_t i) {
+  return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16);
+}
+__device__ __forceinline__ void st_bf16(void* p, int64_t i, float v) {
+  reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(__float_as_uint(v) >> 16);
+}
 
 // ---- epilogue: C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 //   v = acc (+bias[m]) (+map[m,n]); zout = v; v = zmul ? v*act'(zmul) : act(v);
@@ -168,6 +178,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
   const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
   const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
   float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
+  // bf16-stored tensors (bf16-mixed kernels only; wave-uniform): the same element offsets on 2-byte elements
+  bool c16 = false, zm16 = false;
+  if constexpr (R16) { c16 = (g.io16 & IO_C16) != 0; zm16 = (g.io16 & IO_ZM16) != 0; }
+  const int64_t cb16 = (int64_t)bz * g.c_bs, zmb16 = (int64_t)bz * g.zmul_bs, zob16 = (int64_t)bz * g.zout_bs;
   if (g.pw) gemm_add_projection(g, acc, m0, n0, wm, wn, li, lh);
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
 #pragma unroll
@@ -200,12 +214,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
           }
           if (zoutb) {
+            if (R16 && c16) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) zoutb[base + ROWOFF(q)] = v[q];
+              for (int q = 0; q < 8; ++q) st_bf16(g.zout, zob16 + base + ROWOFF(q), v[q]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) zoutb[base + ROWOFF(q)] = v[q];
+            }
           }
           if (zmulb) {
+            if (R16 && zm16) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = zmulb[base + ROWOFF(q)];
+              for (int q = 0; q < 8; ++q) t[q] = ld_bf16(g.zmul, zmb16 + base + ROWOFF(q));
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) t[q] = zmulb[base + ROWOFF(q)];
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] *= act_grad(t[q], g.act);
           } else if (g.act) {
@@ -232,8 +256,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
               for (int q = 0; q < 8; ++q) v[q] += t[q];
             }
           }
+          if (R16 && c16) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) Cb[base + ROWOFF(q)] = v[q];
+            for (int q = 0; q < 8; ++q) st_bf16(g.C, cb16 + base + ROWOFF(q), v[q]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Cb[base + ROWOFF(q)] = v[q];
+          }
           // keep the scheduler from hoisting the next chunk's loads (register pressure)
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
@@ -258,15 +287,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         float v = acc[tm][tn][r] + bv;
         if (g.map) v += g.map[off];
         if constexpr (R16) v = round_bf16(v);
-        if (zoutb) zoutb[off] = v;
-        if (zmulb) v *= act_grad(zmulb[off], g.act);
+        if (zoutb) { if (R16 && c16) st_bf16(g.zout, zob16 + off, v); else zoutb[off] = v; }
+        if (zmulb) v *= act_grad((R16 && zm16) ? ld_bf16(g.zmul, zmb16 + off) : zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
         if constexpr (R16) { if (zmulb || g.act) v = round_bf16(v); }
         if (resb) {
           const float r = resb[off];
           v = g.gate ? fmaf(gate_sigmoid(g.gate[m]), v - r, r) : v + r;
         }
-        Cb[off] = v;
+        if (R16 && c16) st_bf16(g.C, cb16 + off, v); else Cb[off] = v;
       }
     }
   }
@@ -1387,16 +1416,127 @@ pw_gemm_bf16_k32_kernel(GemmArgs g) {
   }
 }
 
-// Soft rendezvous of the tiles of a K-range slab (round 5).  The MT x NT workgroups of a slab stream the same rows of
-// dY (the NT tiles of an m-tile) and of X (the MT tiles of an n-tile) through one XCD's L2; nothing keeps them in step,
-// and over the ~1400 k-tiles of a 128 x 256 B = 8 launch they drift apart by more than the L2 holds: every workgroup then
-// fetches its rows itself (rocprofv3 FETCH_SIZE 6.68 GB per launch for 1.8 GB of operands, round 4).  Every WGRAD_SYNC_T
-// k-tiles wave 0 of each workgroup adds one to the slab's counter and waits - BOUNDED: a fixed number of polls, then it
-// goes on regardless - until the slab's other tiles have done the same.  Correctness never depends on it; it needs all
-// workgroups co-resident to have any effect (the host enables it only for grids of one round).  0 = off.
-#ifndef WGRAD_SYNC_T
-#define WGRAD_SYNC_T 0
-#endif
+// PARADIS_GEMM_BF16 forward / dgrad with the activation operand STORED as bf16 (round 6; GemmArgs::io16 & IO_B16).
+// B is [K rows][N columns] of bf16, n-contiguous (a [C, H W] plane stack as it sits in HBM).  Nothing of it passes through
+// the vector ALU: a 32 x 256 tile (16 KB) goes HBM -> LDS by LDS-DMA, sixteen bytes per lane, and the MFMA's B fragment -
+// eight consecutive k of one column per lane - comes out of the row-major image through the hardware transpose read
+// ds_read_b64_tr_b16 (four k per read).  The weight tile is the [m-tile][k32-tile][slice][k-half][128 rows] image of
+// pw_gemm_bf16_k32_kernel, by LDS-DMA as there.  Same 128 x 256 workgroup tile, accumulator layout and epilogue.
+//   LDS: three stages of (8 KB weights + 16 KB activations) = 72 KB: two 8-wave workgroups per CU; tile t + 2 is in
+//   flight while tile t is multiplied; one barrier per k-tile.
+//   Image of the activation tile: row r (k) = 512 bytes, 16-byte chunk cc of the row stored at slot cc ^ ((r & 3) << 2):
+//   the DMA writes lane-linearly (the permutation sits in the SOURCE address of a lane), and the four rows a transposed
+//   read gathers per 16-lane group fall into the four bank quarters (conflict-free: rows 512 bytes apart would share one).
+//   Requires N % 8 == 0, ldb % 8 == 0 and 16-byte aligned planes (host-checked).  Rows of a tile beyond K re-read row
+//   K - 1 against the zero padding of the weight image; columns beyond N re-read the last eight and are never stored.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_t;
+constexpr int B16_KT = 32, B16_ST = 3;
+constexpr int B16_ACH = simg(2);                  // 512 chunks: the weight tile of one k32 step
+constexpr int B16_BCH = B16_KT * 32;              // 1024 chunks: 32 k-rows x 256 columns of bf16
+constexpr int B16_STAGE = B16_ACH + B16_BCH;      // chunks per stage (24 KB)
+constexpr size_t b16_lds_bytes() { return (size_t)B16_ST * B16_STAGE * 16; }
+__global__ void __launch_bounds__(512, 4)
+pw_gemm_b16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* img = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = wave >> 2, lw = wave & 3;
+  const int wm = lw >> 1, wn = lw & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN, NT2 = (NT + 1) / 2;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt2 = (L / MT) % NT2, bz = L / (MT * NT2);
+  const bool live = 2 * nt2 + sub < NT;              // wave-uniform
+  const int nt = min(2 * nt2 + sub, NT - 1);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T = (g.K + B16_KT - 1) / B16_KT;
+
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T * B16_ACH + tid;
+  const uint16_t* Bb = reinterpret_cast<const uint16_t*>(g.B) + (int64_t)bz * g.b_bs;
+  // this lane's two source chunks of a tile: LDS chunk c = (2 wave + j) 64 + lane -> row c >> 5, slot c & 31
+  int brow[2], bcol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = (2 * wave + j) * 64 + lane, r = c >> 5, slot = c & 31;
+    brow[j] = r;
+    bcol[j] = min(nt2 * 2 * BN + 8 * (slot ^ ((r & 3) << 2)), g.N - 8);
+  }
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    u32x4* st = img + (t % B16_ST) * B16_STAGE;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t * B16_ACH), (lds_ptr_t)(st + wave * 64), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = min(t * B16_KT + brow[j], g.K - 1);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bb + (int64_t)k * g.ldb + bcol[j]),
+                                       (lds_ptr_t)(st + B16_ACH + (2 * wave + j) * 64), 16, 0, 0);
+    }
+  };
+  // transposed reads: lane 4q + p of 16-lane group gq supplies (row 8 lh + q [+ 16 slice + 4 e], columns 4p .. 4p + 3 of the
+  // group's 16): byte offset of this lane inside a stage's activation image, one per 32-column block tn of the wave
+  const int gq = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  uint32_t boff[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int nbi = sub * 4 + wn * 2 + tn;                               // 32-column block inside the 256 columns
+    boff[tn] = (uint32_t)((8 * lh + q4) * 512 + (4 * (nbi ^ q4) + 2 * (gq & 1) + (p4 >> 1)) * 16 + 8 * (p4 & 1));
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0);
+  if (T > 1) issue(1);
+  for (int t = 0; t < T; ++t) {
+    // tile t has landed (three DMAs per tile and lane; the next tile's may stay in flight) and every wave is past tile t - 1
+    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 2 < T) issue(t + 2);
+    const u32x4* st = img + (t % B16_ST) * B16_STAGE;
+    const u32x4* As = st + lh * SCH + wm * 64 + li;
+    const char* Bs = reinterpret_cast<const char*>(st + B16_ACH);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const u32x4 a0 = As[sl * 2 * SCH], a1 = As[sl * 2 * SCH + 32];
+      u32x4 b[2];
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const char* pb = Bs + boff[tn] + sl * 16 * 512;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(pb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(pb + 4 * 512));
+        const uint64_t l64 = __builtin_bit_cast(uint64_t, lo), h64 = __builtin_bit_cast(uint64_t, hi);
+        b[tn] = (u32x4){(uint32_t)l64, (uint32_t)(l64 >> 32), (uint32_t)h64, (uint32_t)(h64 >> 32)};
+      }
+      SPLIT_MFMA(a0, b[0], acc[0][0]); SPLIT_MFMA(a0, b[1], acc[0][1]);
+      SPLIT_MFMA(a1, b[0], acc[1][0]); SPLIT_MFMA(a1, b[1], acc[1][1]);
+    }
+  }
+  if (live) {
+    // the weight image holds the rows of odd 32-row blocks negated (sign checkerboard of the register-staged kernels; the
+    // activations come straight from memory here, un-negated): block tm = 1 of every wave accumulated -C
+    if (SPLIT_SIGNED) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[1][tn][r] = -acc[1][tn][r];
+    }
+    gemm_epilogue<true>(g, acc, bz, m0, n0, wm, wn, li, lh);
+  }
+}
+
+// (A soft rendezvous of a K-range slab's tiles - round 5: FETCH_SIZE 8.48 -> 4.06 GB per launch at 128 x 256, kernel 13 %
+//  slower - was measured and removed: DESIGN_HISTORY.md section 4.1d, profiles/r05_wgrad_rendezvous.txt.)
 template <int NP>
 __global__ void __launch_bounds__(256, 3)
 pw_gemm_wgrad_split_kernel(GemmArgs g) {
@@ -1519,25 +1659,7 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
-#if WGRAD_SYNC_T
-  const int t_sync_end = (int)(total / g.nbatch);        // every tile of the slab runs at least this many k-tiles
-  const unsigned slab_tiles = (unsigned)(MT * NT);
-#endif
   for (int t = 0; t < T; t += 2) {
-#if WGRAD_SYNC_T
-    if (g.sync != nullptr && t > 0 && (t & (WGRAD_SYNC_T - 1)) == 0 && t < t_sync_end &&
-        __builtin_amdgcn_readfirstlane(wave) == 0) {
-      if (lane == 0) {
-        unsigned* cnt = g.sync + bz;
-        const unsigned target = (unsigned)(t / WGRAD_SYNC_T) * slab_tiles;
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int spin = 0; spin < 128; ++spin) {          // bounded: ~0.3 us per poll
-          if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-          __builtin_amdgcn_s_sleep(8);
-        }
-      }
-    }
-#endif
     step(t, 0, r0, r1);
     if (t + 1 < T) step(t + 1, 1, r1, r0);
   }
@@ -1556,6 +1678,139 @@ pw_gemm_wgrad_split_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
   }
   if constexpr (NP == 2) split_unscale(acc, inv_a, inv_b);
+  gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
+}
+
+// PARADIS_GEMM_BF16 weight gradient with bf16-STORED operands (round 6): pw_gemm_wgrad_split_kernel<1> with the staging
+// of a bf16 operand reduced to one 16-byte load per thread and k-tile - the eight values ARE the LDS chunk (no rounding,
+// no packing; the slab's sign alternation is an XOR on the packed sign bits) - while an fp32 operand is rounded in
+// registers as before.  A16: dY is bf16 (GemmArgs::io16 & IO_A16), B16: X is bf16 (IO_B16).  Same tiles, slabs, row sums
+// and epilogue; rows need 16-byte alignment in their own element size (host-checked).
+template <bool A16, bool B16>
+__global__ void __launch_bounds__(256, 3)
+pw_gemm_wgrad_b16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SIMGP = simgp(1);
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A|B][SIMGP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = g.K / SBK;
+  const int64_t total = (int64_t)g.inner * KT;
+  const int t_begin = (int)(total * bz / g.nbatch);
+  const int T = (int)(total * (bz + 1) / g.nbatch) - t_begin;
+
+  const int srow = tid >> 1, sh = tid & 1;
+  // byte addresses: element size 2 or 4 per operand
+  constexpr int EA = A16 ? 2 : 4, EB = B16 ? 2 : 4;
+  const char* Ag = reinterpret_cast<const char*>(g.A) + ((int64_t)min(m0 + srow, g.M - 1) * g.lda + sh * 8) * EA;
+  const char* Bg = reinterpret_cast<const char*>(g.B) + ((int64_t)min(n0 + srow, g.N - 1) * g.ldb + sh * 8) * EB;
+
+  int f_ib = t_begin / KT, f_kt = t_begin - f_ib * KT;
+  struct Regs { f32x4 a0, a1, b0, b1; };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Regs r0{zero4, zero4, zero4, zero4}, r1 = r0;
+  auto fetch = [&](Regs& r) __attribute__((always_inline)) {
+    const char* a = Ag + ((int64_t)f_ib * g.a_is + (int64_t)f_kt * SBK) * EA;
+    const char* b = Bg + ((int64_t)f_ib * g.b_is + (int64_t)f_kt * SBK) * EB;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.a0) : "v"(a) : "memory");
+    if constexpr (!A16) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(r.a1) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.b0) : "v"(b) : "memory");
+    if constexpr (!B16) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(r.b1) : "v"(b) : "memory");
+    if (++f_kt == KT) { f_kt = 0; ++f_ib; }
+  };
+  constexpr int NL = (A16 ? 1 : 2) + (B16 ? 1 : 2);      // loads per fetch
+#define USE_RN(r, S) do { asm volatile("s_waitcnt vmcnt(" S ")" :: "v"(r.a0), "v"(r.a1), "v"(r.b0), "v"(r.b1) : "memory"); \
+                          __builtin_amdgcn_sched_barrier(0); } while (0)
+  auto wait_keep_one = [&](Regs& r) __attribute__((always_inline)) {      // the younger fetch may stay in flight
+    if constexpr (NL == 4) USE_RN(r, "4"); else if constexpr (NL == 3) USE_RN(r, "3"); else USE_RN(r, "2");
+  };
+  const bool do_rowsum = g.rowsum != nullptr && nt == 0;
+  float rs = 0.f;
+  const uint32_t slab_flip = (SPLIT_SIGNED_WGRAD && (bz & 1)) ? 0x80000000u : 0u;      // workgroup-uniform
+  const uint32_t slab_flip16 = slab_flip | (slab_flip >> 16);
+  auto split_store = [&](const Regs& r, int st, bool keep) __attribute__((always_inline)) {
+    u32x4* o = img + st * 2 * SIMGP + sh * SCHP + srow;
+    if constexpr (A16) {
+      const u32x4 c = __builtin_bit_cast(u32x4, r.a0);
+      if (do_rowsum) {       // (workgroup-uniform) bias gradient: row sums of the staged dY values
+        float add = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) add += __uint_as_float(c[i] << 16) + __uint_as_float(c[i] & 0xffff0000u);
+        rs += keep ? add : 0.f;
+      }
+      o[0] = (u32x4){c[0] ^ slab_flip16, c[1] ^ slab_flip16, c[2] ^ slab_flip16, c[3] ^ slab_flip16};
+    } else {
+      const float xa[8] = {r.a0.x, r.a0.y, r.a0.z, r.a0.w, r.a1.x, r.a1.y, r.a1.z, r.a1.w};
+      const float add = ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+      rs += keep ? add : 0.f;
+      float xs[8];
+      flip8(xs, xa, slab_flip);
+      o[0] = round8(xs);
+    }
+    if constexpr (B16) {
+      o[SIMGP] = __builtin_bit_cast(u32x4, r.b0);
+    } else {
+      const float xb[8] = {r.b0.x, r.b0.y, r.b0.z, r.b0.w, r.b1.x, r.b1.y, r.b1.z, r.b1.w};
+      o[SIMGP] = round8(xb);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (T > 0) {
+    fetch(r0);
+    if (T > 1) { fetch(r1); wait_keep_one(r0); } else { USE_RN(r0, "0"); }
+    split_store(r0, 0, do_rowsum);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
+    const u32x4* As = img + cur * 2 * SIMGP + lh * SCHP + wm * 64 + li;
+    const u32x4* Bs = img + (cur * 2 + 1) * SIMGP + lh * SCHP + wn * 64 + li;
+    SplitFrags<1> f;
+    split_tile_read<1, 2 * SCHP, 2 * SCHP>(As, Bs, f);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < T) { fetch(rload); wait_keep_one(rsplit); }
+    else USE_RN(rsplit, "0");
+    split_tile_mfma<1>(f, acc);
+    split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, 0, r0, r1);
+    if (t + 1 < T) step(t + 1, 1, r1, r0);
+  }
+#undef USE_RN
+  if (do_rowsum) {
+    rs += __shfl_xor(rs, 1, 64);
+    const int m = m0 + srow;
+    if (sh == 0 && m < g.M) g.rowsum[(int64_t)bz * g.M + m] = rs;
+  }
+  if (slab_flip) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
+  }
   gemm_epilogue(g, acc, bz, m0, n0, wm, wn, li, lh);
 }
 
@@ -1742,6 +1997,16 @@ int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
     //  wave and barrier the kernel is bound by its per-tile latency chain, not by bytes.  Hence 32-deep tiles.)
     const size_t lds = (size_t)(2 * 2 + 2) * simg(BK32_SL) * 16;
     const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;
+    if (d.io16 & IO_B16) {     // activations stored as bf16: LDS-DMA + transposed reads (layout checked by the caller)
+      static PerDeviceOnce once;
+      if (once.first() && hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_b16_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds_bytes()) != hipSuccess) {
+        paradis_set_error("pw_gemm(b16): cannot reserve LDS");
+        return 2;
+      }
+      hipLaunchKernelGGL(pw_gemm_b16_kernel, dim3(grid), dim3(512), b16_lds_bytes(), st, d);
+      return 0;
+    }
     hipLaunchKernelGGL(pw_gemm_bf16_k32_kernel, dim3(grid), dim3(512), lds, st, d);
     return 0;
   }
@@ -1847,6 +2112,17 @@ int run_split(GemmArgs d, const void* img, int AM, int AK, int scheme, const uin
   }
   return launch_split(d, scheme, st);
 }
+// bf16-stored tensors exist in the bf16-mixed scheme only; the DMA'd activation operand needs whole 16-byte chunks
+int check_io16(const char* name, int io16, int scheme, const void* Bop, int64_t b_bs, int N, bool has_res) {
+  if (io16 == 0) return 0;
+  PD_REQUIRE(scheme == PARADIS_GEMM_BF16, "%s: bf16-stored tensors need the PARADIS_GEMM_BF16 scheme", name);
+  PD_REQUIRE((io16 & ~(IO_B16 | IO_C16 | IO_ZM16 | IO_A16)) == 0, "%s: unknown io16 bits %d", name, io16);
+  PD_REQUIRE(!(io16 & IO_C16) || !has_res, "%s: a bf16 output cannot carry the fp32 residual", name);
+  if (io16 & IO_B16)
+    PD_REQUIRE(N % 8 == 0 && N >= 8 && b_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(Bop) & 15) == 0,
+               "%s: a bf16 activation operand needs N %% 8 == 0 and 16-byte aligned planes", name);
+  return 0;
+}
 }  // namespace
 
 static int pw_gemm_fwd_impl(const float* Wt, const float* WtT, const void* Wsplit, int scheme,
@@ -1854,8 +2130,9 @@ static int pw_gemm_fwd_impl(const float* Wt, const float* WtT, const void* Wspli
                             const float* bias, const float* map, const float* m8,
                             const float* pwT, int cin, const float* res, const float* gate, float* Y, float* zpre,
                             int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
-                            int64_t y_bs, int act, void* stream) {
+                            int64_t y_bs, int act, void* stream, int io16 = 0) {
   if (int e = check_gemm("pw_gemm_fwd", B, M, K, N)) return e;
+  if (int e = check_io16("pw_gemm_fwd", io16, scheme, X, x_bs, N, res != nullptr)) return e;
   PD_REQUIRE(gate == nullptr || res != nullptr || B == 0, "pw_gemm_fwd: a gate needs the tensor it blends with (res)");
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_fwd: unknown activation code %d", act);
   PD_REQUIRE(known_scheme(scheme) && (Wsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
@@ -1871,6 +2148,7 @@ static int pw_gemm_fwd_impl(const float* Wt, const float* WtT, const void* Wspli
   g.bias = bias; g.map = map; g.res = res; g.res_bs = res_bs; g.zmul = nullptr; g.zout = zpre;
   g.zout_bs = (int64_t)M * N; g.act = act; g.gate = gate;
   g.stagger = g_stagger;
+  g.io16 = io16;
   const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
   if (Wsplit != nullptr) {   // split image of the weights: split kernel (any shape)
     if (int e = run_split(g, Wsplit, M, K, scheme, x_amax, "pw_gemm_fwd: the f16x2 scheme needs x_amax",
@@ -1914,6 +2192,18 @@ extern "C" int paradis_pw_gemm_fwd_gated(const float* Wt, const float* WtT, cons
   PD_REQUIRE(gate != nullptr && (res != nullptr || B == 0), "pw_gemm_fwd_gated: gate [M] and res required");
   return pw_gemm_fwd_impl(Wt, WtT, Wsplit, scheme, x_amax, X, bias, map, m8, pwT, cin, res, gate, Y, zpre, B, M, K, N,
                           x_bs, res_bs, y_bs, act, stream);
+}
+
+// PARADIS_GEMM_BF16 with bf16-STORED tensors (round 6): io16 = PARADIS_IO_X16 (X is bf16 [B][K,N]) | PARADIS_IO_Y16 (Y and
+// zpre are written as bf16; no residual then).  Everything else as paradis_pw_gemm_fwd / _gated (gate may be NULL).
+extern "C" int paradis_pw_gemm_fwd16(const void* Wsplit, const void* X, const float* bias, const float* map,
+                                     const float* m8, const float* pwT, int cin, const float* res, const float* gate,
+                                     void* Y, void* zpre, int B, int M, int K, int N, int64_t x_bs, int64_t res_bs,
+                                     int64_t y_bs, int act, int io16, void* stream) {
+  PD_REQUIRE((io16 & ~(IO_B16 | IO_C16)) == 0, "pw_gemm_fwd16: io16 may name X (1) and Y (2)");
+  PD_REQUIRE(Wsplit != nullptr, "pw_gemm_fwd16: weight image required");
+  return pw_gemm_fwd_impl(nullptr, nullptr, Wsplit, PARADIS_GEMM_BF16, nullptr, (const float*)X, bias, map, m8, pwT, cin,
+                          res, gate, (float*)Y, (float*)zpre, B, M, K, N, x_bs, res_bs, y_bs, act, stream, io16);
 }
 
 // Plain batched GEMM  C_b[M,N] = A_b[M,K] B_b[K,N]  (row-major, batch strides in elements) on the same
@@ -1961,13 +2251,14 @@ extern "C" int paradis_bgemm(const float* A, const float* AT, const float* Bm, f
   return 0;
 }
 
-extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme, const uint32_t* dy_amax,
-                                     const float* dY, const float* zpre,
-                                     const float* addend, float* dX, int B, int M, int K, int N,
-                                     int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
-                                     int act, void* stream) {
+static int pw_gemm_dgrad_impl(const float* Wt, const void* WTsplit, int scheme, const uint32_t* dy_amax,
+                              const float* dY, const float* zpre,
+                              const float* addend, float* dX, int B, int M, int K, int N,
+                              int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
+                              int act, void* stream, int io16) {
   // W is [M,K] (M = Co, K = Ci); result dX is [K,N] per sample: GEMM with M' = K, K' = M.
   if (int e = check_gemm("pw_gemm_dgrad", B, K, M, N)) return e;
+  if (int e = check_io16("pw_gemm_dgrad", io16, scheme, dY, dy_bs, N, addend != nullptr)) return e;
   PD_REQUIRE(act >= 0 && act <= 2, "pw_gemm_dgrad: unknown activation code %d", act);
   PD_REQUIRE(known_scheme(scheme) && (WTsplit != nullptr) == (scheme != PARADIS_GEMM_EXACT),
              "pw_gemm_dgrad: scheme %d needs %s weight image", scheme, scheme ? "a" : "no");
@@ -1978,6 +2269,7 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int s
   g.a_bs = 0; g.b_bs = dy_bs; g.c_bs = dx_bs; g.nbatch = B; g.inner = 0;
   g.res = addend; g.res_bs = add_bs; g.zmul = zpre; g.zmul_bs = z_bs; g.act = zpre ? act : 0;
   g.stagger = g_stagger;
+  g.io16 = io16;
   const int grid = ((K + BM - 1) / BM) * ((N + BN - 1) / BN) * B;
   if (WTsplit != nullptr) {   // split image of W^T
     if (int e = run_split(g, WTsplit, K, M, scheme, dy_amax, "pw_gemm_dgrad: the f16x2 scheme needs dy_amax",
@@ -1995,11 +2287,31 @@ extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int s
   return 0;
 }
 
+extern "C" int paradis_pw_gemm_dgrad(const float* Wt, const void* WTsplit, int scheme, const uint32_t* dy_amax,
+                                     const float* dY, const float* zpre,
+                                     const float* addend, float* dX, int B, int M, int K, int N,
+                                     int64_t dy_bs, int64_t z_bs, int64_t add_bs, int64_t dx_bs,
+                                     int act, void* stream) {
+  return pw_gemm_dgrad_impl(Wt, WTsplit, scheme, dy_amax, dY, zpre, addend, dX, B, M, K, N, dy_bs, z_bs, add_bs, dx_bs,
+                            act, stream, 0);
+}
+
+// PARADIS_GEMM_BF16 with bf16-STORED tensors: io16 = PARADIS_IO_X16 (dY is bf16) | PARADIS_IO_Y16 (dX is written as bf16)
+// | PARADIS_IO_Z16 (zpre is bf16).
+extern "C" int paradis_pw_gemm_dgrad16(const void* WTsplit, const void* dY, const void* zpre, void* dX, int B, int M,
+                                       int K, int N, int64_t dy_bs, int64_t z_bs, int64_t dx_bs, int act, int io16,
+                                       void* stream) {
+  PD_REQUIRE((io16 & ~(IO_B16 | IO_C16 | IO_ZM16)) == 0, "pw_gemm_dgrad16: io16 may name dY (1), dX (2) and zpre (4)");
+  PD_REQUIRE(WTsplit != nullptr, "pw_gemm_dgrad16: weight image required");
+  return pw_gemm_dgrad_impl(nullptr, WTsplit, PARADIS_GEMM_BF16, nullptr, (const float*)dY, (const float*)zpre, nullptr,
+                            (float*)dX, B, M, K, N, dy_bs, z_bs, 0, dx_bs, act, stream, io16);
+}
+
 extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
   const int b = std::max(B, 1);
   const int S = std::max({wgrad_splits(b, M, K, N, DBK, wgrad_dma_wgs()), wgrad_splits(b, M, K, N, g_bk, g_wg_per_cu),
                           wgrad_splits(b, M, K, N, SBK, 3)});
-  return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256 + 4096;   // slabs + row-sum partials + rendezvous words
+  return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256;   // slabs + row-sum partials
 }
 
 // K-range slabs the split weight-gradient kernel runs for this shape (1, or an even number: see wgrad_splits)
@@ -2011,12 +2323,20 @@ extern "C" int paradis_pw_gemm_wgrad_slabs(int B, int M, int K, int N) {
 extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, int B, int C, int P,
                                   int64_t dz_bs, void* stream);
 
-extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias, int B,
-                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
-                                     const uint32_t* dy_amax, const uint32_t* x_amax, void* workspace,
-                                     void* stream) {
+static int pw_gemm_wgrad_impl(const float* dY, const float* X, float* dW, float* gbias, int B,
+                              int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
+                              const uint32_t* dy_amax, const uint32_t* x_amax, void* workspace,
+                              void* stream, int io16) {
   // dW[M,K] = sum_b dY[b][M,N] . X[b][K,N]^T : GEMM with M'=M, N'=K, K'=N, reduced over samples.
   if (int e = check_gemm("pw_gemm_wgrad", 1, M, N, K)) return e;
+  if (io16) {
+    PD_REQUIRE(scheme == PARADIS_GEMM_BF16 && (io16 & ~(IO_A16 | IO_B16)) == 0,
+               "pw_gemm_wgrad: bf16-stored operands need the PARADIS_GEMM_BF16 scheme (io16 = dY 8 | X 1)");
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    PD_REQUIRE(N % SBK == 0 && a16(dY) && a16(X) && dy_bs % ((io16 & IO_A16) ? 8 : 4) == 0 &&
+               x_bs % ((io16 & IO_B16) ? 8 : 4) == 0,
+               "pw_gemm_wgrad: bf16-stored operands need N %% 16 == 0 and 16-byte aligned rows");
+  }
   PD_REQUIRE(known_scheme(scheme), "pw_gemm_wgrad: unknown scheme %d", scheme);
   PD_REQUIRE(scheme != PARADIS_GEMM_F16X2 || (dy_amax != nullptr && x_amax != nullptr),
              "pw_gemm_wgrad: the f16x2 scheme needs dy_amax and x_amax");
@@ -2027,7 +2347,7 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
     return 0;
   }
   // a split scheme: both operands are split in registers (same layout requirements as the LDS-DMA kernel)
-  const bool use_split = scheme != PARADIS_GEMM_EXACT && wgrad_vec_layout(N, dy_bs, x_bs, dY, X);
+  const bool use_split = io16 != 0 || (scheme != PARADIS_GEMM_EXACT && wgrad_vec_layout(N, dy_bs, x_bs, dY, X));
   const bool dma = use_split || wgrad_dma_ok(N, dy_bs, x_bs, dY, X);   // "dma" = kernels with fused row sums
   const int S = use_split ? wgrad_splits(B, M, K, N, SBK, 3)
                           : dma ? wgrad_splits(B, M, K, N, DBK, wgrad_dma_wgs())
@@ -2046,17 +2366,17 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   g.stagger = g_stagger;
   g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = ((M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-#if WGRAD_SYNC_T
-  if (use_split && S >= 2 && S <= 1024 && grid <= 768 && (int64_t)B * (N / SBK) / S >= 4 * WGRAD_SYNC_T) {
-    // rendezvous words behind the slabs and the row sums (zeroed in-stream: a kernel, see pd_zero_async)
-    unsigned* sw = reinterpret_cast<unsigned*>(((uintptr_t)(rowsum_ws + (size_t)S * M) + 63) & ~(uintptr_t)63);
-    if (pd_zero_async(sw, (size_t)S * sizeof(unsigned), st) != hipSuccess) return 2;
-    g.sync = sw;
-  }
-#endif
   if (use_split && scheme == PARADIS_GEMM_F16X2) {
     g.a_amax = dy_amax; g.b_amax = x_amax;
     hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<2>, dim3(grid), dim3(256), split_lds_wgrad(2), st, g);
+  } else if (use_split && scheme == PARADIS_GEMM_BF16 && io16) {
+    g.io16 = io16;
+    if ((io16 & IO_A16) && (io16 & IO_B16))
+      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<true, true>), dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
+    else if (io16 & IO_A16)
+      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<true, false>), dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
+    else
+      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<false, true>), dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
   } else if (use_split && scheme == PARADIS_GEMM_BF16) {
     hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<1>, dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
   } else if (use_split) {
@@ -2080,4 +2400,19 @@ extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW,
   }
   PD_CHECK_LAUNCH("pw_gemm_wgrad");
   return 0;
+}
+
+extern "C" int paradis_pw_gemm_wgrad(const float* dY, const float* X, float* dW, float* gbias, int B,
+                                     int M, int K, int N, int64_t dy_bs, int64_t x_bs, int scheme,
+                                     const uint32_t* dy_amax, const uint32_t* x_amax, void* workspace,
+                                     void* stream) {
+  return pw_gemm_wgrad_impl(dY, X, dW, gbias, B, M, K, N, dy_bs, x_bs, scheme, dy_amax, x_amax, workspace, stream, 0);
+}
+
+// PARADIS_GEMM_BF16 with bf16-STORED operands: io16 = PARADIS_IO_DY16 (dY is bf16) | PARADIS_IO_X16 (X is bf16); dW and the
+// bias gradient stay fp32.  Workspace: paradis_pw_gemm_wgrad_ws_bytes.
+extern "C" int paradis_pw_gemm_wgrad16(const void* dY, const void* X, float* dW, float* gbias, int B, int M, int K, int N,
+                                       int64_t dy_bs, int64_t x_bs, int io16, void* workspace, void* stream) {
+  return pw_gemm_wgrad_impl((const float*)dY, (const float*)X, dW, gbias, B, M, K, N, dy_bs, x_bs, PARADIS_GEMM_BF16,
+                            nullptr, nullptr, workspace, stream, io16);
 }

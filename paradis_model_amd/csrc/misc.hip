@@ -609,6 +609,48 @@ extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const 
 
 // The same gradients when the advected tensor was never materialised (paradis_pw_gemm_fwd_gated): `out` is the
 // blended output, adv - h = (out - h) / sigmoid, so galpha = (1 - sigmoid) sum gout (out - h) - no division.
+// the same on a bf16-STORED dz (bf16-mixed mode, round 6): eight columns per thread from one 16-byte load per sample
+// (P % 8 == 0, 16-byte aligned rows); fp32 sums in batch order, fp32 outputs
+__global__ void __launch_bounds__(256)
+bias_grads_b16_kernel(const uint16_t* __restrict__ dz, float* __restrict__ gmap, float* __restrict__ gbias,
+                      int B, int C, int P8, int64_t bs, int pchunks) {
+  __shared__ float red[4];
+  const int c = blockIdx.x / pchunks, chunk = blockIdx.x - c * pchunks;
+  const uint4* src = reinterpret_cast<const uint4*>(dz + (int64_t)c * P8 * 8);
+  const int64_t bs8 = bs / 8;
+  float acc = 0.f;
+  for (int q = chunk * 256 + threadIdx.x; q < P8; q += pchunks * 256) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)min(b0 + j, B - 1) * bs8 + q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (b0 + j < B) {
+          const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s[2 * i] += __uint_as_float(w[i] << 16);
+            s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    if (gmap) {
+      float4* o = reinterpret_cast<float4*>(gmap + (int64_t)c * P8 * 8) + 2 * q;
+      o[0] = make_float4(s[0], s[1], s[2], s[3]);
+      o[1] = make_float4(s[4], s[5], s[6], s[7]);
+    }
+    acc += ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  }
+  if (!gbias) return;
+  acc = wave_sum_dpp(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&gbias[c], red[0] + red[1] + red[2] + red[3]);
+}
+
 extern "C" int paradis_gated_blend_bwd_out(const float* gout, const float* h, const float* out,
                                            const float* alpha, float* gh, float* gadv, float* galpha, int B,
                                            int C, int P, void* workspace, void* stream) {
@@ -640,6 +682,30 @@ extern "C" int paradis_bias_grads(const float* dz, float* gmap, float* gbias, in
   hipLaunchKernelGGL(bias_grads_kernel, dim3((unsigned)((int64_t)C * pchunks)), dim3(256), 0, st, dz, gmap,
                      gbias, B, C, P, dz_bs, pchunks);
   PD_CHECK_LAUNCH("bias_grads");
+  return 0;
+}
+
+// dz stored as bf16 [B][C,P] (bf16-mixed mode): same outputs, fp32
+extern "C" int paradis_bias_grads16(const void* dz, float* gmap, float* gbias, int B, int C, int P,
+                                    int64_t dz_bs, void* stream) {
+  PD_REQUIRE(B >= 0 && C >= 1 && P >= 1, "bias_grads16: bad shape");
+  PD_REQUIRE(P % 8 == 0 && dz_bs % 8 == 0 && aligned16(dz) && (!gmap || aligned16(gmap)),
+             "bias_grads16: needs P %% 8 == 0 and 16-byte aligned rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (gbias && pd_zero_async(gbias, (size_t)C * sizeof(float), st) != hipSuccess) {
+    paradis_set_error("bias_grads16: memset failed");
+    return 2;
+  }
+  if ((!gmap && !gbias) || B == 0) {
+    if (gmap && pd_zero_async(gmap, (size_t)C * P * sizeof(float), st) != hipSuccess) return 2;
+    return 0;
+  }
+  const int P8 = P / 8;
+  int pch = std::max(1, std::min(2, std::min((P8 + 255) / 256, std::max(1, 2048 / C))));   // (two adds commute)
+  if (paradis_deterministic()) pch = 1;
+  hipLaunchKernelGGL(bias_grads_b16_kernel, dim3((unsigned)((int64_t)C * pch)), dim3(256), 0, st,
+                     reinterpret_cast<const uint16_t*>(dz), gmap, gbias, B, C, P8, dz_bs, pch);
+  PD_CHECK_LAUNCH("bias_grads16");
   return 0;
 }
 

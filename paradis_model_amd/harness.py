@@ -81,11 +81,15 @@ def next_input(model_input, output, num_common: int, n_inputs: int):
 
 def rollout_loss(model, loss_fn, batch, *, num_common: int, n_inputs: int, accum: int = 1,
                  detach_every: Optional[int] = None, keep_outputs: bool = False,
-                 backward: bool = True):
+                 backward: bool = True, amp: bool = False):
     """The autoregressive hot loop of ``training_step`` (reference trainer.py:508-576): per step
     assemble the input, run the model, accumulate ``loss/(S*accum)``, feed the prediction back;
     ``backward`` at chunk ends (every ``detach_every`` steps and at the last step), detaching the
-    carried input.  Returns (sum of chunk losses as a detached tensor, outputs if requested)."""
+    carried input.  Returns (sum of chunk losses as a detached tensor, outputs if requested).
+
+    ``amp``: the forward and the loss of every step run under ``torch.autocast(bfloat16)``; the ``backward`` calls run
+    OUTSIDE the autocast region, as under Lightning's ``precision="bf16-mixed"`` plugin (reference train.py:56) and
+    as the PyTorch AMP recipe prescribes."""
     input_data, true_data, forcings, constant_data = batch
     constants = constant_data[:, :1].permute(0, 1, 4, 2, 3)
     forcings = forcings.permute(0, 1, 4, 2, 3)
@@ -94,12 +98,13 @@ def rollout_loss(model, loss_fn, batch, *, num_common: int, n_inputs: int, accum
     chunk = 0.0
     outs = []
     for step in range(S):
-        mi = assemble_model_input(input_data, forcings[:, step].unsqueeze(1), constants)
-        out = model(mi)
-        if keep_outputs:
-            outs.append(out.detach())
-        chunk = chunk + loss_fn(out, true_data[:, step]) / (S * accum)
-        input_data = next_input(mi, out, num_common, n_inputs).unsqueeze(1)
+        with torch.autocast("cuda" if input_data.is_cuda else "cpu", dtype=torch.bfloat16, enabled=bool(amp)):
+            mi = assemble_model_input(input_data, forcings[:, step].unsqueeze(1), constants)
+            out = model(mi)
+            if keep_outputs:
+                outs.append(out.detach())
+            chunk = chunk + loss_fn(out, true_data[:, step]) / (S * accum)
+            input_data = next_input(mi, out, num_common, n_inputs).unsqueeze(1)
         if (detach_every is not None and (step + 1) % detach_every == 0) or step == S - 1:
             if backward:
                 chunk.backward()
@@ -148,10 +153,8 @@ class TrainStep:
 
     def __call__(self, batch):
         self.opt.zero_grad(set_to_none=True)
-        dev = "cuda" if batch[0].is_cuda else "cpu"
-        with torch.autocast(dev, dtype=torch.bfloat16, enabled=self.amp):
-            loss, _ = rollout_loss(self.model, self.loss_fn, batch, num_common=self.num_common,
-                                   n_inputs=self.n_inputs, detach_every=self.detach_every)
+        loss, _ = rollout_loss(self.model, self.loss_fn, batch, num_common=self.num_common,
+                               n_inputs=self.n_inputs, detach_every=self.detach_every, amp=self.amp)
         self.opt.step()
         return loss
 

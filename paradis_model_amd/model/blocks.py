@@ -77,9 +77,9 @@ class CLinear(nn.Module):
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size=1, bias=bias)
 
     def forward(self, x, bias_map=None, act: Optional[str] = None, residual=None, x_pre=None,
-                x_act=None, defer_act_grad=False, bias_proj=None, gate=None):
+                x_act=None, defer_act_grad=False, bias_proj=None, gate=None, out_bf16: bool = False):
         return ops.pointwise(x, self.conv.weight, self.conv.bias, bias_map, residual, act, x_pre, x_act,
-                             defer_act_grad, bias_proj, gate=gate)
+                             defer_act_grad, bias_proj, gate=gate, out_bf16=out_bf16)
 
 
 class SepConv(nn.Module):
@@ -293,9 +293,14 @@ class GMBlock(nn.Sequential):
                 hand_off = (act is not None and res is None and j < n and isinstance(mods[j], CLinear)
                             and isinstance(m, CLinear) and torch.is_grad_enabled())
                 g = gate if res is not None else None
+                # the sole consumer of this activated output is the next CLinear: under autocast(bfloat16) it is
+                # handed over as a bf16 TENSOR, as the reference's conv2d returns it there (a request; ops.pointwise
+                # honours it in the bf16-mixed scheme only)
+                chain16 = (act is not None and res is None and j < n and isinstance(mods[j], CLinear)
+                           and isinstance(m, CLinear))
                 if isinstance(m, CLinear):
                     out = m(x, bias_map=bias_map, act=act, residual=res, x_pre=pre, x_act=pre_act,
-                            defer_act_grad=hand_off, bias_proj=bias_proj, gate=g)
+                            defer_act_grad=hand_off, bias_proj=bias_proj, gate=g, out_bf16=chain16)
                 elif i == 0 and stencil_skip:
                     out, skip = m(x, bias_map=bias_map, act=act, residual=res, bias_proj=bias_proj, with_skip=True)
                 else:

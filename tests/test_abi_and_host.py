@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"{n} declared in include/paradis_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.lib.paradis_abi_version() == 8
+    assert _lib.lib.paradis_abi_version() == 9
 
 
 def test_argument_validation_without_gpu():

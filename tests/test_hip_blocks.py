@@ -117,18 +117,26 @@ def test_weight_images_pair_launch_equals_the_two_single_launches(ops, M, K):
     assert lib.paradis_pw_gemm_split_weights_pair(ops.dptr(w), M, K, ops.dptr(b), ops.dptr(bt), st) == 0
     assert torch.equal(a, b) and torch.equal(at, bt)
     assert lib.paradis_pw_gemm_split_weights_pair(ops.dptr(w), M, K, ops.dptr(b), ops.dptr(b), st) == 1
-    # the cache: a recorded forward leaves both images behind, the data gradient launches nothing more
+    # a recorded forward writes both images in one launch and hands W^T's to its backward through the autograd context;
+    # a no-grad forward writes only W's; nothing is cached across calls (round 6: no stale-image mode)
     wp = torch.nn.Parameter(w.clone().reshape(M, K, 1, 1))
     x = seeded(8, 2, K, 8, 16).cuda().requires_grad_(True)
     with torch.no_grad():
         ops.pointwise(x, wp, scheme=ops.GEMM_BF16X3)
-    assert (id(wp), False, ops.GEMM_BF16X3) in ops._IMAGES and (id(wp), True, ops.GEMM_BF16X3) not in ops._IMAGES
-    ops.weights_updated()
+    assert not ops._IMAGES and ops._take_wt(wp) is None
     y = ops.pointwise(x, wp, scheme=ops.GEMM_BF16X3)
-    img, img_t = ops._IMAGES[(id(wp), False, ops.GEMM_BF16X3)][4], ops._IMAGES[(id(wp), True, ops.GEMM_BF16X3)][4]
-    assert torch.equal(img, a) and torch.equal(img_t, at)
+    img_t = y.grad_fn.wt_image
+    assert img_t is not None and torch.equal(img_t, at)
     y.sum().backward()
-    assert ops._IMAGES[(id(wp), True, ops.GEMM_BF16X3)][4] is img_t
+    assert not ops._IMAGES
+    # opt-in cache: inside frozen_weights() the images are reused across calls and dropped on leaving
+    with ops.frozen_weights():
+        with torch.no_grad():
+            ops.pointwise(x, wp, scheme=ops.GEMM_BF16X3)
+            img = ops._IMAGES[(id(wp), False, ops.GEMM_BF16X3)][4]
+            ops.pointwise(x, wp, scheme=ops.GEMM_BF16X3)
+            assert ops._IMAGES[(id(wp), False, ops.GEMM_BF16X3)][4] is img and torch.equal(img, a)
+    assert not ops._IMAGES
 
 
 # ----------------------------------------------------------------------------------- depthwise
