@@ -17,6 +17,7 @@
 // reads for k-step kk+1 issued before the MFMAs of kk.  Work-group ids are remapped so that the
 // M-tiles that share one X tile run on the same XCD (L2 reuse of X).
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -155,6 +156,9 @@ __device__ __forceinline__ void gemm_add_projection(const GemmArgs& g, f32x16 (&
 __device__ __forceinline__ float gate_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
 // value of x rounded to bf16 (round to nearest even; a NaN stays a NaN: v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+// (An epilogue / k-loop stagger - the second workgroup of every CU of the first round starting late by 64-256 x 512 cycles,
+//  so that one workgroup's store-bound epilogue runs under the other's MFMA-bound k-loop - was measured on the bf16-mixed
+//  and the bf16x3 kernels and lost 0-10 % at every setting: profiles/r06_stagger_sweep.txt.  Not kept.)
 constexpr int IO_B16 = 1, IO_C16 = 2, IO_ZM16 = 4, IO_A16 = 8;     // GemmArgs::io16 (IO_A16: wgrad's dY operand)
 // bf16 storage: element i of a bf16 array as a float / a bf16-VALUED float (already rounded) into a bf16 array
 __device__ __forceinline__ float ld_bf16(const void* p, int64_t i) {
@@ -171,16 +175,17 @@ __device__ __forceinline__ void st_bf16(void* p, int64_t i, float v) {
 // issued back to back (the guarded form serialises every load behind an s_waitcnt vmcnt(0)).
 // R16 (compile time: only the bf16-mixed kernel instantiates it, the fp32 schemes' epilogue is the round-4 code): round
 // the pre-activation and the activated / activation-gradient value to bf16 (see the note in GemmArgs)
-template <bool R16 = false>
+template <bool R16 = false, bool C16 = false, bool ZM16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int bz, int m0,
                                               int n0, int wm, int wn, int li, int lh) {
   float* Cb = g.C + (int64_t)bz * g.c_bs;
   const float* resb = g.res ? g.res + (int64_t)bz * g.res_bs : nullptr;
   const float* zmulb = g.zmul ? g.zmul + (int64_t)bz * g.zmul_bs : nullptr;
   float* zoutb = g.zout ? g.zout + (int64_t)bz * g.zout_bs : nullptr;
-  // bf16-stored tensors (bf16-mixed kernels only; wave-uniform): the same element offsets on 2-byte elements
-  bool c16 = false, zm16 = false;
-  if constexpr (R16) { c16 = (g.io16 & IO_C16) != 0; zm16 = (g.io16 & IO_ZM16) != 0; }
+  // bf16-stored tensors (compile-time properties of the bf16-mixed kernels' instantiations - as run-time branches they
+  // cost the 128-register kernels 256 bytes of scratch and 100 us per launch): the same element offsets on 2-byte elements
+  static_assert(R16 || !(C16 || ZM16), "bf16-stored tensors exist in the bf16-mixed scheme only");
+  (void)sizeof(char[C16 + ZM16 + 1]);
   const int64_t cb16 = (int64_t)bz * g.c_bs, zmb16 = (int64_t)bz * g.zmul_bs, zob16 = (int64_t)bz * g.zout_bs;
   if (g.pw) gemm_add_projection(g, acc, m0, n0, wm, wn, li, lh);
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
@@ -214,7 +219,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             for (int q = 0; q < 8; ++q) v[q] = round_bf16(v[q]);
           }
           if (zoutb) {
-            if (R16 && c16) {
+            if constexpr (C16) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) st_bf16(g.zout, zob16 + base + ROWOFF(q), v[q]);
             } else {
@@ -223,7 +228,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             }
           }
           if (zmulb) {
-            if (R16 && zm16) {
+            if constexpr (ZM16) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) t[q] = ld_bf16(g.zmul, zmb16 + base + ROWOFF(q));
             } else {
@@ -256,7 +261,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
               for (int q = 0; q < 8; ++q) v[q] += t[q];
             }
           }
-          if (R16 && c16) {
+          if constexpr (C16) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) st_bf16(g.C, cb16 + base + ROWOFF(q), v[q]);
           } else {
@@ -287,15 +292,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         float v = acc[tm][tn][r] + bv;
         if (g.map) v += g.map[off];
         if constexpr (R16) v = round_bf16(v);
-        if (zoutb) { if (R16 && c16) st_bf16(g.zout, zob16 + off, v); else zoutb[off] = v; }
-        if (zmulb) v *= act_grad((R16 && zm16) ? ld_bf16(g.zmul, zmb16 + off) : zmulb[off], g.act);
+        if (zoutb) { if constexpr (C16) st_bf16(g.zout, zob16 + off, v); else zoutb[off] = v; }
+        if (zmulb) v *= act_grad(ZM16 ? ld_bf16(g.zmul, zmb16 + off) : zmulb[off], g.act);
         else if (g.act) v = act_apply(v, g.act);
         if constexpr (R16) { if (zmulb || g.act) v = round_bf16(v); }
         if (resb) {
           const float r = resb[off];
           v = g.gate ? fmaf(gate_sigmoid(g.gate[m]), v - r, r) : v + r;
         }
-        if (R16 && c16) st_bf16(g.C, cb16 + off, v); else Cb[off] = v;
+        if constexpr (C16) st_bf16(g.C, cb16 + off, v); else Cb[off] = v;
       }
     }
   }
@@ -1309,6 +1314,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // per stage in LDS.  48 KiB of LDS, <= 128 VGPRs: two 8-wave workgroups per CU.  Rows of the activation tile beyond K
 // re-read row K - 1 against the zero padding of the weight image.
 constexpr int BK32_SL = 2;                       // k16 slices per tile
+template <bool C16 = false, bool ZM16 = false>       // bf16-stored output (and zout) / zmul: see gemm_epilogue
 __global__ void __launch_bounds__(512, 4)
 pw_gemm_bf16_k32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1412,7 +1418,7 @@ pw_gemm_bf16_k32_kernel(GemmArgs g) {
 #undef USE_X16
   if (live) {
     split_unflip(acc, wn);
-    gemm_epilogue<true>(g, acc, bz, m0, n0, wm, wn, li, lh);
+    gemm_epilogue<true, C16, ZM16>(g, acc, bz, m0, n0, wm, wn, li, lh);
   }
 }
 
@@ -1436,6 +1442,7 @@ constexpr int B16_ACH = simg(2);                  // 512 chunks: the weight tile
 constexpr int B16_BCH = B16_KT * 32;              // 1024 chunks: 32 k-rows x 256 columns of bf16
 constexpr int B16_STAGE = B16_ACH + B16_BCH;      // chunks per stage (24 KB)
 constexpr size_t b16_lds_bytes() { return (size_t)B16_ST * B16_STAGE * 16; }
+template <bool C16, bool ZM16>
 __global__ void __launch_bounds__(512, 4)
 pw_gemm_b16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1531,7 +1538,7 @@ pw_gemm_b16_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[1][tn][r] = -acc[1][tn][r];
     }
-    gemm_epilogue<true>(g, acc, bz, m0, n0, wm, wn, li, lh);
+    gemm_epilogue<true, C16, ZM16>(g, acc, bz, m0, n0, wm, wn, li, lh);
   }
 }
 
@@ -1997,17 +2004,31 @@ int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
     //  wave and barrier the kernel is bound by its per-tile latency chain, not by bytes.  Hence 32-deep tiles.)
     const size_t lds = (size_t)(2 * 2 + 2) * simg(BK32_SL) * 16;
     const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;
+    const bool c16 = (d.io16 & IO_C16) != 0, zm16 = (d.io16 & IO_ZM16) != 0 && d.zmul != nullptr;
     if (d.io16 & IO_B16) {     // activations stored as bf16: LDS-DMA + transposed reads (layout checked by the caller)
       static PerDeviceOnce once;
-      if (once.first() && hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_b16_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds_bytes()) != hipSuccess) {
-        paradis_set_error("pw_gemm(b16): cannot reserve LDS");
-        return 2;
+      if (once.first()) {
+        const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_b16_kernel<false, false>),
+                             reinterpret_cast<const void*>(&pw_gemm_b16_kernel<true, false>),
+                             reinterpret_cast<const void*>(&pw_gemm_b16_kernel<false, true>),
+                             reinterpret_cast<const void*>(&pw_gemm_b16_kernel<true, true>)};
+        for (const void* k : ks)
+          if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds_bytes()) != hipSuccess) {
+            paradis_set_error("pw_gemm(b16): cannot reserve LDS");
+            return 2;
+          }
       }
-      hipLaunchKernelGGL(pw_gemm_b16_kernel, dim3(grid), dim3(512), b16_lds_bytes(), st, d);
+      const dim3 gr(grid), bl(512);
+      if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, true>), gr, bl, b16_lds_bytes(), st, d);
+      else if (c16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, false>), gr, bl, b16_lds_bytes(), st, d);
+      else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<false, true>), gr, bl, b16_lds_bytes(), st, d);
+      else hipLaunchKernelGGL((pw_gemm_b16_kernel<false, false>), gr, bl, b16_lds_bytes(), st, d);
       return 0;
     }
-    hipLaunchKernelGGL(pw_gemm_bf16_k32_kernel, dim3(grid), dim3(512), lds, st, d);
+    if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, true>), dim3(grid), dim3(512), lds, st, d);
+    else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, false>), dim3(grid), dim3(512), lds, st, d);
+    else if (zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<false, true>), dim3(grid), dim3(512), lds, st, d);
+    else hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<false, false>), dim3(grid), dim3(512), lds, st, d);
     return 0;
   }
   if (scheme != PARADIS_GEMM_F16X2) {
