@@ -221,6 +221,13 @@ int paradis_pw_gemm_dgrad16(const void* WTsplit, const void* dY, const void* zpr
                             int64_t dy_bs, int64_t z_bs, int64_t dx_bs, int act, int io16, void* stream);
 int paradis_pw_gemm_wgrad16(const void* dY, const void* X, float* dW, float* gbias, int B, int M, int K, int N,
                             int64_t dy_bs, int64_t x_bs, int io16, void* workspace, void* stream);
+/* the producers of a pointwise layer's input writing it as bf16 (round to nearest even: the value the GEMM rounds its
+ * operand to): ChannelNorm (model/blocks.py:118-134) and the depthwise stencil of a SepConv (:101-113) */
+int paradis_channel_norm_fwd16(const float* x1, const float* x2, const float* w, const float* b, void* y /* bf16 */,
+                               float* mean, float* rstd, int B, int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs,
+                               float eps, void* stream);
+int paradis_dwconv_geo_fwd16(const float* x, const float* w, const float* bias, void* y /* bf16 */, int B, int C, int H,
+                             int W, int k, void* stream);
 /* paradis_bias_grads on a bf16-stored dz (P % 8 == 0, 16-byte aligned rows); outputs fp32 */
 int paradis_bias_grads16(const void* dz, float* gmap, float* gbias, int B, int C, int P, int64_t dz_bs, void* stream);
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "paradis_pw_gemm_dgrad16": (I, [P, P, P, P, I, I, I, I, L, L, L, I, I, P]),
     "paradis_pw_gemm_wgrad16": (I, [P, P, P, P, I, I, I, I, L, L, I, P, P]),
     "paradis_bias_grads16": (I, [P, P, P, I, I, I, L, P]),
+    "paradis_channel_norm_fwd16": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
+    "paradis_dwconv_geo_fwd16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
     "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),
     "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P]),

@@ -25,7 +25,12 @@ struct CatSrc {
 // passes, any C).  NPXF = 32 (128-byte row segments, 36 values per thread, ~64 VGPRs) keeps two
 // workgroups per CU so that one loads while the other stores; with 64 pixels x 72 values only one
 // 1024-thread workgroup fits and its load / reduce / store phases run back to back (2.7 TB/s).
-template <int MAXV, int NPXF>
+// Y16 (round 6, bf16-mixed mode): y is written as bf16 (round to nearest even) for a consumer that is a pointwise GEMM -
+// the value that GEMM would round its operand to anyway (the reference casts the norm's output to bf16 at the conv2d,
+// model/blocks.py:86 under train.py:56), in half the bytes.
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+template <int MAXV, int NPXF, bool Y16 = false>
 __global__ void __launch_bounds__(1024)
 channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
                         float* __restrict__ y, float* __restrict__ mean_out,
@@ -94,19 +99,20 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
   const float rstd = stat[1][lane];
   if (live) {
     float* yb = y + (int64_t)b * C * P + p;
+    uint16_t* yb16 = reinterpret_cast<uint16_t*>(y) + (int64_t)b * C * P + p;
     if (MAXV > 0) {
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
         const int c = grp + G * i;
         if (c < C) {
           const float v = (vals[i] - mean) * rstd * w[c] + bias[c];
-          yb[(int64_t)c * P] = v;
+          if constexpr (Y16) yb16[(int64_t)c * P] = bf16_bits(v); else yb[(int64_t)c * P] = v;
         }
       }
     } else {
       for (int c = grp; c < C; c += G) {
         const float v = (s.row(b, c, P)[p] - mean) * rstd * w[c] + bias[c];
-        yb[(int64_t)c * P] = v;
+        if constexpr (Y16) yb16[(int64_t)c * P] = bf16_bits(v); else yb[(int64_t)c * P] = v;
       }
     }
   }
@@ -117,7 +123,7 @@ channel_norm_fwd_kernel(CatSrc s, const float* __restrict__ w, const float* __re
 // of all MAXV channels hoisted in front of the stores).  A wave holds two channel groups (lanes 0-31: channel
 // 2 wave + 32 i, lanes 32-63: the next one), so the row pair of value i has a wave-uniform base: every load and store
 // is `scalar base + one 32-bit lane offset`; w and bias are staged in LDS once and read at the point of use.
-template <int MAXV>
+template <int MAXV, bool Y16 = false>
 __global__ void __launch_bounds__(1024, 8)
 channel_norm_fwd32_kernel(CatSrc s, const float* __restrict__ w, const float* __restrict__ bias,
                           float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -184,16 +190,19 @@ channel_norm_fwd32_kernel(CatSrc s, const float* __restrict__ w, const float* __
   const float rstd = stat[1][lane];
   if (!live) return;
   typedef __attribute__((address_space(1))) float* gwptr;
-  const uint64_t ybase = (uint64_t)(y + (int64_t)b * C * P);
+  typedef __attribute__((address_space(1))) uint16_t* gwptr16;
+  constexpr int ES = Y16 ? 2 : 4;
+  const uint64_t ybase = (uint64_t)y + (uint64_t)b * C * P * ES;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int ce = 2 * wave + G * i;
     if (ce < C) {
       const int c = grp + G * i;
       const float v = (vals[i] - mean) * rstd * wl[c] + bl[c];
-      const uint64_t a = ybase + (uint64_t)ce * P * 4;
+      const uint64_t a = ybase + (uint64_t)ce * P * ES;
       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-      ((gwptr)(((uint64_t)hi << 32) | lo))[voff] = v;
+      if constexpr (Y16) ((gwptr16)(((uint64_t)hi << 32) | lo))[voff] = bf16_bits(v);
+      else ((gwptr)(((uint64_t)hi << 32) | lo))[voff] = v;
     }
   }
 }
@@ -634,9 +643,10 @@ extern "C" void paradis_debug_set_norm_bwd_reread(int on) { g_norm_bwd_reread = 
 #ifndef NORM_FWD32      // (A/B builds: 0 = the generic 32-pixel kernel)
 #define NORM_FWD32 1
 #endif
-extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
-                                        const float* b, float* y, float* mean, float* rstd, int B,
-                                        int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
+template <bool Y16>
+static int channel_norm_fwd_impl(const float* x1, const float* x2, const float* w,
+                                 const float* b, float* y, float* mean, float* rstd, int B,
+                                 int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
   if (int e = check_norm("channel_norm_fwd", B, C1, C2, P)) return e;
   if (B == 0) return 0;       // (an empty batch has no x2 pointer either)
   PD_REQUIRE(C2 == 0 || x2 != nullptr, "channel_norm_fwd: x2 missing");
@@ -648,23 +658,36 @@ extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const 
     const int tiles = (P + 31) / 32;
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 32 * 4)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<4, 32, Y16>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else if (NORM_FWD32 && (C1 & 1) == 0 && (C2 & 1) == 0 && (int64_t)2 * P < (1ll << 30))
-      hipLaunchKernelGGL((channel_norm_fwd32_kernel<36>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd32_kernel<36, Y16>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<36, 32, Y16>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
   } else {
     const int tiles = (P + NPX - 1) / NPX;
     const dim3 grid((unsigned)((int64_t)B * tiles));
     if (C <= 16 * 8)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<8, NPX, Y16>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else if (C <= 16 * 72)
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<72, NPX, Y16>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
     else
-      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
+      hipLaunchKernelGGL((channel_norm_fwd_kernel<0, NPX, Y16>), grid, block, 0, st, s, w, b, y, mean, rstd, P, tiles, eps);
   }
   PD_CHECK_LAUNCH("channel_norm_fwd");
   return 0;
+}
+
+extern "C" int paradis_channel_norm_fwd(const float* x1, const float* x2, const float* w,
+                                        const float* b, float* y, float* mean, float* rstd, int B,
+                                        int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
+  return channel_norm_fwd_impl<false>(x1, x2, w, b, y, mean, rstd, B, C1, C2, P, x1_bs, x2_bs, eps, stream);
+}
+
+// y written as bf16 [B][C1 + C2, P] (ABI 9; bf16-mixed mode: the consumer is a pointwise GEMM); mean / rstd stay fp32
+extern "C" int paradis_channel_norm_fwd16(const float* x1, const float* x2, const float* w,
+                                          const float* b, void* y, float* mean, float* rstd, int B,
+                                          int C1, int C2, int P, int64_t x1_bs, int64_t x2_bs, float eps, void* stream) {
+  return channel_norm_fwd_impl<true>(x1, x2, w, b, (float*)y, mean, rstd, B, C1, C2, P, x1_bs, x2_bs, eps, stream);
 }
 
 // pixels per workgroup of the apply kernel (one (sample, channel) row chunk); multiple of 4

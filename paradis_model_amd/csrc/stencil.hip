@@ -175,7 +175,11 @@ __device__ __forceinline__ void tile_stencil(const float* tile, const float* __r
 }
 
 // whole-plane path: PLANE_CHUNK planes per workgroup, the next plane's loads in flight during the stencil
-template <int K>
+// Y16 (round 6, bf16-mixed mode): y written as bf16 (round to nearest even) for a consumer that is the pointwise GEMM of
+// the same SepConv - the value that GEMM rounds its operand to (reference model/blocks.py:107-110 under autocast).
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+template <int K, bool Y16 = false>
 __global__ void __launch_bounds__(256, 5)   // (8 waves per SIMD = 64 registers spill the prefetched plane: 235 us instead of 99)
 dwconv_geo_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ w,
                              const float* __restrict__ bias, float* __restrict__ y, int C, int H, int64_t planes) {
@@ -198,16 +202,20 @@ dwconv_geo_fwd_planes_kernel(const float* __restrict__ x, const float* __restric
     float acc[RPT];
     tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
     const float bv = bias ? bias[c] : 0.f;
-    const ubase_t yp = uniform_base(y + plane * (int64_t)H * W);
-    const unsigned o0 = (unsigned)(r0l * W + xl) * 4u;
+    constexpr int ES = Y16 ? 2 : 4;
+    const ubase_t yp = uniform_base(reinterpret_cast<const char*>(y) + plane * (int64_t)H * W * ES);
+    const unsigned o0 = (unsigned)(r0l * W + xl) * (unsigned)ES;
 #pragma unroll
     for (int o = 0; o < RPT; ++o)
-      if (r0l + o < H) store_at<float>(yp + o * W * 4, o0, acc[o] + bv);   // (the row step is on the scalar base)
+      if (r0l + o < H) {      // (the row step is on the scalar base)
+        if constexpr (Y16) store_at<uint16_t>(yp + o * W * ES, o0, bf16_bits(acc[o] + bv));
+        else store_at<float>(yp + o * W * ES, o0, acc[o] + bv);
+      }
     __syncthreads();
   }
 }
 
-template <int K>
+template <int K, bool Y16 = false>
 __global__ void __launch_bounds__(256)
 dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                       const float* __restrict__ bias, float* __restrict__ y, int C, int H, int W,
@@ -225,11 +233,13 @@ dwconv_geo_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
   const int xx = tx0 + (threadIdx.x & 63), r0 = ty0 + (threadIdx.x >> 6) * RPT;
   if (xx < W) {
     float* yp = y + plane * (int64_t)H * W;
+    uint16_t* yp16 = reinterpret_cast<uint16_t*>(y) + plane * (int64_t)H * W;
 #pragma unroll
     for (int o = 0; o < RPT; ++o)
       if (r0 + o < H) {
         const float v = acc[o] + bv;
-        yp[(int64_t)(r0 + o) * W + xx] = v;
+        if constexpr (Y16) yp16[(int64_t)(r0 + o) * W + xx] = bf16_bits(v);
+        else yp[(int64_t)(r0 + o) * W + xx] = v;
       }
   }
 }
@@ -775,7 +785,7 @@ __device__ __forceinline__ int xcd_contiguous(int id, int nwg) {
 }
 
 // forward: a workgroup walks PLANE_CHUNK planes at one tile position
-template <int K>
+template <int K, bool Y16 = false>
 __global__ void __launch_bounds__(256, 5)
 dwconv_geo_fwd_tiles_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                             float* __restrict__ y, int C, int H, int W, int tiles_x, int tiles, int64_t planes) {
@@ -791,7 +801,8 @@ dwconv_geo_fwd_tiles_kernel(const float* __restrict__ x, const float* __restrict
   f32x4 q[2];
   float hv[2];
   sg.load(x + first * PS, q, hv);
-  const unsigned o0 = (unsigned)((tp.ty0 + r0l) * W + tp.tx0 + xl) * 4u;
+  constexpr int ES = Y16 ? 2 : 4;
+  const unsigned o0 = (unsigned)((tp.ty0 + r0l) * W + tp.tx0 + xl) * (unsigned)ES;
   const bool col_owned = tp.tx0 + xl >= tp.nx0;
   const int own0 = tp.ny0 - tp.ty0 - r0l;           // rows o >= own0 of this thread's strip are owned
   for (int i = 0; i < n; ++i) {
@@ -803,10 +814,13 @@ dwconv_geo_fwd_tiles_kernel(const float* __restrict__ x, const float* __restrict
     float acc[RPT];
     tile_stencil<K, false>(tile, w + (int64_t)c * K * K, acc);
     const float bv = bias ? bias[c] : 0.f;
-    const ubase_t yp = uniform_base(y + plane * PS);
+    const ubase_t yp = uniform_base(reinterpret_cast<const char*>(y) + plane * PS * ES);
 #pragma unroll
     for (int o = 0; o < RPT; ++o)
-      if (col_owned && o >= own0) store_at<float>(yp + (int64_t)o * W * 4, o0, acc[o] + bv);
+      if (col_owned && o >= own0) {
+        if constexpr (Y16) store_at<uint16_t>(yp + (int64_t)o * W * ES, o0, bf16_bits(acc[o] + bv));
+        else store_at<float>(yp + (int64_t)o * W * ES, o0, acc[o] + bv);
+      }
     __syncthreads();
   }
 }
@@ -1185,31 +1199,43 @@ static bool staged_tiles(const void* a, const void* b, int H, int W, int k) {
     default: { constexpr int KK = 11; CALL; } break; \
   }
 
-extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
-                                      int B, int C, int H, int W, int k, void* stream) {
+template <bool Y16>
+static int dwconv_geo_fwd_impl(const float* x, const float* w, const float* bias, float* y,
+                               int B, int C, int H, int W, int k, void* stream) {
   if (int e = check_dw("dwconv_geo_fwd", B, C, H, W, k)) return e;
   if (B == 0) return 0;
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH, tiles = tx * ty;
   const int64_t planes = (int64_t)B * C;
   if (DWCONV_PLANES && whole_plane_vec4(x, H, W, k)) {     // (k == 5 there)
-    hipLaunchKernelGGL(dwconv_geo_fwd_planes_kernel<5>, dim3((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK)),
+    hipLaunchKernelGGL((dwconv_geo_fwd_planes_kernel<5, Y16>), dim3((unsigned)((planes + PLANE_CHUNK - 1) / PLANE_CHUNK)),
                        dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, H, planes);
     PD_CHECK_LAUNCH("dwconv_geo_fwd");
     return 0;
   }
   if (staged_tiles(x, y, H, W, k)) {
     const int64_t nwg = (planes + PLANE_CHUNK - 1) / PLANE_CHUNK * tiles;
-    hipLaunchKernelGGL(dwconv_geo_fwd_tiles_kernel<5>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+    hipLaunchKernelGGL((dwconv_geo_fwd_tiles_kernel<5, Y16>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        y, C, H, W, tx, tiles, planes);
     PD_CHECK_LAUNCH("dwconv_geo_fwd");
     return 0;
   }
   const unsigned grid = (unsigned)(planes * tiles);
-  DISPATCH_K(k, hipLaunchKernelGGL(dwconv_geo_fwd_kernel<KK>, dim3(grid), dim3(256), 0,
+  DISPATCH_K(k, hipLaunchKernelGGL((dwconv_geo_fwd_kernel<KK, Y16>), dim3(grid), dim3(256), 0,
                                    (hipStream_t)stream, x, w, bias, y, C, H, W, tx, tiles,
                                    whole_plane_vec4(x, H, W, k)));
   PD_CHECK_LAUNCH("dwconv_geo_fwd");
   return 0;
+}
+
+extern "C" int paradis_dwconv_geo_fwd(const float* x, const float* w, const float* bias, float* y,
+                                      int B, int C, int H, int W, int k, void* stream) {
+  return dwconv_geo_fwd_impl<false>(x, w, bias, y, B, C, H, W, k, stream);
+}
+
+// y written as bf16 (ABI 9; bf16-mixed mode: the consumer is the SepConv's pointwise GEMM)
+extern "C" int paradis_dwconv_geo_fwd16(const float* x, const float* w, const float* bias, void* y,
+                                        int B, int C, int H, int W, int k, void* stream) {
+  return dwconv_geo_fwd_impl<true>(x, w, bias, (float*)y, B, C, H, W, k, stream);
 }
 
 static int dwconv_geo_dgrad_launch(const float* gy, const float* w, const float* addend, float* gx, int B, int C,

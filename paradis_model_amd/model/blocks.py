@@ -102,10 +102,11 @@ class SepConv(nn.Module):
         """``with_skip``: also hand back the input for a consumer around the block (``(out, x)``): its gradient is
         then added inside the stencil's data-gradient kernel (``ops.dwconv_geo_skip``)."""
         skip = None
+        # (the stencil's output has one consumer, the pointwise GEMM below: a bf16 tensor inside autocast(bfloat16))
         if with_skip:
-            x, skip = ops.dwconv_geo_skip(x, self.depthwise.weight, self.depthwise.bias)
+            x, skip = ops.dwconv_geo_skip(x, self.depthwise.weight, self.depthwise.bias, out_bf16=True)
         else:
-            x = ops.dwconv_geo(x, self.depthwise.weight, self.depthwise.bias)
+            x = ops.dwconv_geo(x, self.depthwise.weight, self.depthwise.bias, out_bf16=True)
         out = ops.pointwise(x, self.pointwise.weight, self.pointwise.bias, bias_map, residual, act,
                             bias_proj=bias_proj, gate=gate)
         return (out, skip) if with_skip else out
@@ -122,14 +123,16 @@ class ChannelNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(input_dim), requires_grad=True)
         self.bias = nn.Parameter(torch.zeros(input_dim), requires_grad=True)
 
-    def forward(self, x, x_extra=None, with_skip: bool = False):
+    def forward(self, x, x_extra=None, with_skip: bool = False, out_bf16: bool = False):
         """``x_extra``: optional second tensor treated as concatenated after ``x`` along channels
         (the reaction block's cat([hidden, hidden_static]) without materialising it).
         ``with_skip``: also return ``x`` for a residual branch; its gradient is then added inside
-        the backward kernel (no separate accumulation pass)."""
+        the backward kernel (no separate accumulation pass).
+        ``out_bf16``: the only consumer of the output is a pointwise layer - a request honoured inside
+        ``torch.autocast(bfloat16)`` only (``ops._want_bf16_out``): the output comes back as a bf16 tensor."""
         if with_skip:
-            return ops.channel_norm_skip(x, self.weight, self.bias, self.eps, x_extra)
-        return ops.channel_norm(x, self.weight, self.bias, self.eps, x_extra)
+            return ops.channel_norm_skip(x, self.weight, self.bias, self.eps, x_extra, out_bf16=out_bf16)
+        return ops.channel_norm(x, self.weight, self.bias, self.eps, x_extra, out_bf16=out_bf16)
 
 
 class GlobalBias(nn.Module):
@@ -269,13 +272,14 @@ class GMBlock(nn.Sequential):
         while i < n:
             m = mods[i]
             if isinstance(m, ChannelNorm):
+                to_gemm = i + 1 < n and isinstance(mods[i + 1], CLinear)     # sole consumer: a pointwise GEMM
                 if i == 0 and fuse_skip:
                     res_is_x = residual is x
-                    x, skip = m(x, x_extra, with_skip=True)
+                    x, skip = m(x, x_extra, with_skip=True, out_bf16=to_gemm)
                     if res_is_x:
                         residual = skip
                 else:
-                    x = m(x, x_extra)
+                    x = m(x, x_extra, out_bf16=to_gemm)
                 x_extra = None
                 i += 1
             elif isinstance(m, (CLinear, SepConv)):

@@ -167,6 +167,66 @@ def _is16(t) -> bool:
     return t is not None and t.dtype == torch.bfloat16
 
 
+# ---- bf16-stored activations between a NON-GEMM producer and its pointwise consumer (round 6) ----------------------------
+# ChannelNorm and the depthwise stencil can write their output as a bf16 tensor when its only consumer is a pointwise GEMM
+# in the bf16-mixed scheme (``out_bf16``).  Autograd hands a bf16 tensor's producer a bf16 cotangent; these producers'
+# backward kernels read fp32.  The consumer's data gradient IS bf16-valued (rounded where the reference's autocast backward
+# rounds it), so nothing is lost either way - but a 2-byte gradient would need bf16-reading variants of every producer
+# backward kernel.  Instead the consumer computes the gradient as bf16 VALUES IN FP32 WORDS (as in the fp32-stored layout),
+# leaves it in the producer's hand-off slot - the producing node hangs a token on the tensor it returns - and gives
+# autograd a zero-stride bf16 placeholder of the right shape.  The producer's backward takes the slot's tensor.  Every
+# failure mode is loud or correct: no token on the tensor (a foreign producer, a checkpoint's recomputed copy) -> the
+# consumer returns a REAL bf16 gradient and the producer widens it; a placeholder reaching a producer with an empty slot
+# raises.  Eager only (a traced graph has no side channel: ``out_bf16`` is not requested while compiling).
+class _Handoff:
+    __slots__ = ("grad32",)
+
+    def __init__(self):
+        self.grad32 = None
+
+
+_PLACEHOLDER16 = {}
+
+
+def _placeholder_grad16(like: Tensor) -> Tensor:
+    d = _PLACEHOLDER16.get(like.device)
+    if d is None:
+        d = _PLACEHOLDER16[like.device] = torch.zeros((), dtype=torch.bfloat16, device=like.device)
+    return d.expand(like.shape)
+
+
+def _is_placeholder16(g: Tensor) -> bool:
+    d = _PLACEHOLDER16.get(g.device)
+    return (d is not None and g.dtype == torch.bfloat16 and g.numel() > 1 and g.data_ptr() == d.data_ptr()
+            and all(st == 0 for st in g.stride()))
+
+
+def _attach_handoff(ctx, y: Tensor) -> None:
+    """producer side, forward: ``y`` is the bf16 tensor this node returns"""
+    if y.dtype == torch.bfloat16:
+        ctx.handoff = y._paradis_handoff = _Handoff()
+
+
+def _resolve_cotangent(ctx, gy):
+    """producer side, backward: the fp32 cotangent of this node's (possibly bf16-stored) output"""
+    tok = getattr(ctx, "handoff", None)
+    if tok is not None and tok.grad32 is not None:
+        g, tok.grad32 = tok.grad32, None
+        return g
+    if gy is not None and gy.dtype != torch.float32:
+        if _is_placeholder16(gy):
+            raise RuntimeError("paradis: the fp32 gradient of a bf16-stored activation was not handed over to its producer")
+        return gy.float()
+    return gy
+
+
+def _want_bf16_out(x: Tensor, out_bf16: bool) -> bool:
+    """a producer's ``out_bf16`` request is honoured where its consumer - a pointwise GEMM called next, inside the same
+    autocast region - will run the bf16-mixed scheme and take a bf16 operand (see ``pointwise``)"""
+    return (bool(out_bf16) and BF16_STORAGE and autocast_scheme(GEMM_SCHEME) == GEMM_BF16
+            and (x.shape[-2] * x.shape[-1]) % 16 == 0 and not torch.compiler.is_compiling())
+
+
 def _ws(nbytes: int, device) -> Optional[Tensor]:
     if nbytes <= 0:
         return None
@@ -479,23 +539,25 @@ def sl_advect(field, u, v, geom: AdvectGeometry, dt: float, mode: str = "bicubic
 # ---------------------------------------------------------------------------
 # a7 depthwise stencil on the virtual geocyclic halo (reference model/blocks.py:101-113)
 # ---------------------------------------------------------------------------
-@_define("dwconv_geo(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
-def _dwconv_geo(x, weight, bias):
+@_define("dwconv_geo(Tensor x, Tensor weight, Tensor? bias, bool out_bf16=False) -> Tensor")
+def _dwconv_geo(x, weight, bias, out_bf16=False):
+    """``out_bf16``: y as a bf16 tensor (bf16-mixed mode: the consumer is the SepConv's pointwise GEMM, which rounds its
+    operand to bf16 anyway - reference model/blocks.py:107-110 under autocast)."""
     _f32(x, weight, bias)
     x = x.contiguous()
     B, C, H, W = x.shape
     k = weight.shape[-1]
     assert weight.shape == (C, 1, k, k), "depthwise weight must be [C,1,k,k]"
     w = weight.contiguous()
-    y = torch.empty_like(x)
-    check(lib.paradis_dwconv_geo_fwd(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, stream_ptr()),
-          "dwconv_geo_fwd")
+    y = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    fn = lib.paradis_dwconv_geo_fwd16 if out_bf16 else lib.paradis_dwconv_geo_fwd
+    check(fn(dptr(x), dptr(w), dptr(bias), dptr(y), B, C, H, W, k, stream_ptr()), "dwconv_geo_fwd")
     return y
 
 
 @_fake("dwconv_geo")
-def _(x, weight, bias):
-    return x.new_empty(x.shape)
+def _(x, weight, bias, out_bf16=False):
+    return x.new_empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32)
 
 
 @_define("dwconv_geo_dgrad(Tensor gy, Tensor weight) -> Tensor")
@@ -596,22 +658,24 @@ def _dw_grads(ctx, gy, x, w, addend, raw=False):
 
 
 def _dw_setup(ctx, inputs, output):
-    x, w, bias = inputs
+    x, w, bias = inputs[:3]
     ctx.save_for_backward(x, w)
     ctx.has_bias = bias is not None
+    _attach_handoff(ctx, output)
 
 
 def _dw_backward(ctx, gy):
     x, w = ctx.saved_tensors
-    return _dw_grads(ctx, gy, x, w, None)
+    return (*_dw_grads(ctx, _resolve_cotangent(ctx, gy), x, w, None), None)
 
 
 _autograd("dwconv_geo", _dw_setup, _dw_backward)
 
 
-def dwconv_geo(x, weight, bias=None):
+def dwconv_geo(x, weight, bias=None, out_bf16: bool = False):
+    """``out_bf16``: a request (see ``_want_bf16_out``) - the stencil's output as a bf16 tensor for a pointwise consumer"""
     require_hip(x, weight, bias)
-    return _dwconv_geo(x, weight, bias)
+    return _dwconv_geo(x, weight, bias, _want_bf16_out(x, out_bf16))
 
 
 class _DwconvSkip(torch.autograd.Function):
@@ -621,27 +685,29 @@ class _DwconvSkip(torch.autograd.Function):
     over the tensor.  Eager only, like ``_ChannelNormSkip``."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        y = _eager_forward("dwconv_geo", _dwconv_geo, x, weight, bias)
+    def forward(ctx, x, weight, bias, out_bf16):
+        y = _eager_forward("dwconv_geo", _dwconv_geo, x, weight, bias, out_bf16)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)
+        _attach_handoff(ctx, y)
         return y, x
 
     @staticmethod
     def backward(ctx, gy, gskip):
         x, w = ctx.saved_tensors
         if gy is None:          # only the skip path was used
-            return gskip, None, None
-        return _dw_grads(ctx, gy, x, w, gskip, raw=_plain(gy))
+            return gskip, None, None, None
+        gy = _resolve_cotangent(ctx, gy)
+        return (*_dw_grads(ctx, gy, x, w, gskip, raw=_plain(gy)), None)
 
 
-def dwconv_geo_skip(x, weight, bias=None):
+def dwconv_geo_skip(x, weight, bias=None, out_bf16: bool = False):
     """``(dwconv_geo(x), x)`` for a stencil whose input has another consumer (see ``_DwconvSkip``)."""
     require_hip(x, weight, bias)
     if torch.compiler.is_compiling():
         return _dwconv_geo(x, weight, bias), x
-    return _DwconvSkip.apply(x, weight, bias)
+    return _DwconvSkip.apply(x, weight, bias, _want_bf16_out(x, out_bf16))
 
 
 # ---------------------------------------------------------------------------
@@ -760,8 +826,11 @@ def upsample_lonp(x, nlat: int, nlon: int):
 # ---------------------------------------------------------------------------
 # a8 ChannelNorm (reference model/blocks.py:118-134), optionally over a virtual concat
 # ---------------------------------------------------------------------------
-@_define("channel_norm(Tensor x1, Tensor? x2, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor, Tensor)")
-def _channel_norm(x1, x2, weight, bias, eps):
+@_define("channel_norm(Tensor x1, Tensor? x2, Tensor weight, Tensor bias, float eps, bool out_bf16=False) "
+         "-> (Tensor, Tensor, Tensor)")
+def _channel_norm(x1, x2, weight, bias, eps, out_bf16=False):
+    """``out_bf16``: y as a bf16 tensor (bf16-mixed mode, consumer = a pointwise GEMM: the reference casts the norm's fp32
+    output to bf16 at that conv2d, model/blocks.py:86 under train.py:56); mean / rstd stay fp32."""
     _f32(x1, x2, weight, bias)
     x1, bs1 = _plane_view(x1)
     B, C1, H, W = x1.shape
@@ -770,20 +839,21 @@ def _channel_norm(x1, x2, weight, bias, eps):
         x2, bs2 = _plane_view(x2)
         C2 = x2.shape[1]
     P = H * W
-    y = torch.empty(B, C1 + C2, H, W, dtype=x1.dtype, device=x1.device)
+    y = torch.empty(B, C1 + C2, H, W, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x1.device)
     mean = torch.empty(B, P, dtype=x1.dtype, device=x1.device)
     rstd = torch.empty_like(mean)
-    check(lib.paradis_channel_norm_fwd(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y), dptr(mean),
-                                       dptr(rstd), B, C1, C2, P, bs1, bs2, eps, stream_ptr()),
-          "channel_norm_fwd")
+    fn = lib.paradis_channel_norm_fwd16 if out_bf16 else lib.paradis_channel_norm_fwd
+    check(fn(dptr(x1), dptr(x2), dptr(weight), dptr(bias), dptr(y), dptr(mean),
+             dptr(rstd), B, C1, C2, P, bs1, bs2, eps, stream_ptr()), "channel_norm_fwd")
     return y, mean, rstd
 
 
 @_fake("channel_norm")
-def _(x1, x2, weight, bias, eps):
+def _(x1, x2, weight, bias, eps, out_bf16=False):
     B, C1, H, W = x1.shape
     C = C1 + (x2.shape[1] if x2 is not None else 0)
-    return x1.new_empty(B, C, H, W), x1.new_empty(B, H * W), x1.new_empty(B, H * W)
+    return (x1.new_empty(B, C, H, W, dtype=torch.bfloat16 if out_bf16 else torch.float32), x1.new_empty(B, H * W),
+            x1.new_empty(B, H * W))
 
 
 @_define("channel_norm_backward(Tensor gy, Tensor x1, Tensor? x2, Tensor weight, Tensor mean, Tensor rstd, "
@@ -823,19 +893,20 @@ def _(gy, x1, x2, weight, mean, rstd, add):
 
 
 def _norm_setup(ctx, inputs, output):
-    x1, x2, weight, bias, eps = inputs
+    x1, x2, weight, bias, eps = inputs[:5]
     y, mean, rstd = output
     ctx.save_for_backward(x1, x2, weight, mean, rstd)
     ctx.mark_non_differentiable(mean, rstd)
     ctx.set_materialize_grads(False)
+    _attach_handoff(ctx, y)
 
 
 def _norm_backward(ctx, gy, gmean=None, grstd=None):
     x1, x2, weight, mean, rstd = ctx.saved_tensors
     if gy is None:
-        return None, None, None, None, None
-    gx1, gx2, gw, gb = _channel_norm_backward(gy, x1, x2, weight, mean, rstd, None)
-    return gx1, (gx2 if x2 is not None else None), gw, gb, None
+        return None, None, None, None, None, None
+    gx1, gx2, gw, gb = _channel_norm_backward(_resolve_cotangent(ctx, gy), x1, x2, weight, mean, rstd, None)
+    return gx1, (gx2 if x2 is not None else None), gw, gb, None, None
 
 
 _autograd("channel_norm", _norm_setup, _norm_backward)
@@ -848,34 +919,37 @@ class _ChannelNormSkip(torch.autograd.Function):
     under ``torch.compile`` the plain op is used and the traced graph holds the addition."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, eps):
-        y, mean, rstd = _eager_forward("channel_norm", _channel_norm, x1, x2, weight, bias, eps)
+    def forward(ctx, x1, x2, weight, bias, eps, out_bf16):
+        y, mean, rstd = _eager_forward("channel_norm", _channel_norm, x1, x2, weight, bias, eps, out_bf16)
         ctx.save_for_backward(x1, x2, weight, mean, rstd)
         ctx.set_materialize_grads(False)
+        _attach_handoff(ctx, y)
         return y, x1
 
     @staticmethod
     def backward(ctx, gy, gskip):
         x1, x2, weight, mean, rstd = ctx.saved_tensors
         if gy is None:          # only the skip path was used
-            return gskip, None, None, None, None
+            return gskip, None, None, None, None, None
+        gy = _resolve_cotangent(ctx, gy)
         bwd = RAW["channel_norm_backward"] if _plain(gy) else _channel_norm_backward
         gx1, gx2, gw, gb = bwd(gy, x1, x2, weight, mean, rstd, gskip)
-        return gx1, (gx2 if x2 is not None else None), gw, gb, None
+        return gx1, (gx2 if x2 is not None else None), gw, gb, None, None
 
 
-def channel_norm(x, weight, bias, eps: float = 1e-5, x_extra=None):
-    """ChannelNorm over channels of ``x`` (and, virtually concatenated after them, ``x_extra``)."""
+def channel_norm(x, weight, bias, eps: float = 1e-5, x_extra=None, out_bf16: bool = False):
+    """ChannelNorm over channels of ``x`` (and, virtually concatenated after them, ``x_extra``).
+    ``out_bf16``: a request (see ``_want_bf16_out``) - the output as a bf16 tensor for a pointwise consumer."""
     require_hip(x, x_extra, weight, bias)
-    return _channel_norm(x, x_extra, weight, bias, float(eps))[0]
+    return _channel_norm(x, x_extra, weight, bias, float(eps), _want_bf16_out(x, out_bf16))[0]
 
 
-def channel_norm_skip(x, weight, bias, eps: float = 1e-5, x_extra=None):
+def channel_norm_skip(x, weight, bias, eps: float = 1e-5, x_extra=None, out_bf16: bool = False):
     """``(channel_norm(x), x)`` for a block with a residual branch around it (see ``_ChannelNormSkip``)."""
     require_hip(x, x_extra, weight, bias)
     if torch.compiler.is_compiling():
         return _channel_norm(x, x_extra, weight, bias, float(eps))[0], x
-    return _ChannelNormSkip.apply(x, x_extra, weight, bias, float(eps))
+    return _ChannelNormSkip.apply(x, x_extra, weight, bias, float(eps), _want_bf16_out(x, out_bf16))
 
 
 # ---------------------------------------------------------------------------
@@ -1568,8 +1642,15 @@ def _pw_backward(ctx, gy, gz=None, gamax=None, raw=False):
     if need[0]:
         # (a bf16-stored input gets its gradient as bf16: with the activation-gradient hand-off that IS the producing
         #  layer's d(pre-activation), rounded to bf16 where the reference's autocast backward rounds it)
-        gx = K["pw_gemm_dgrad"](dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme,
-                                getattr(ctx, "wt_image", None), x.dtype == torch.bfloat16)
+        tok = getattr(x, "_paradis_handoff", None) if (x.dtype == torch.bfloat16 and x_act == 0) else None
+        if tok is not None:
+            # x came from a ChannelNorm / stencil that wrote it as bf16: its backward kernels read fp32 - the gradient
+            # goes into the producer's hand-off slot as bf16 values in fp32 words, autograd gets a placeholder
+            tok.grad32 = K["pw_gemm_dgrad"](dz, weight, None, 0, dz_amax, scheme, getattr(ctx, "wt_image", None), False)
+            gx = _placeholder_grad16(x)
+        else:
+            gx = K["pw_gemm_dgrad"](dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme,
+                                    getattr(ctx, "wt_image", None), x.dtype == torch.bfloat16)
     want_b = has_bias and need[2]
     want_p = has_proj and (need[9] or need[10])
     want_m = (has_map and need[3]) or want_p

@@ -337,3 +337,72 @@ def test_bf16_storage_in_the_model_equals_fp32_storage_up_to_rounding_flips():
     errs = sorted(rms_rel(res[0][1][n], res[1][1][n]) for n in res[0][1] if float(res[1][1][n].abs().max()) > 0)
     print("bf16 storage vs fp32 storage: output %.2e, gradients median %.2e max %.2e" % (e, errs[len(errs) // 2], errs[-1]))
     assert e <= 2e-3 and errs[len(errs) // 2] <= 2e-3 and errs[-1] <= 2e-2
+
+
+def test_bf16_outputs_of_norm_and_stencil_are_the_rounded_fp32_outputs():
+    """ChannelNorm / depthwise stencil writing their output as bf16 for a pointwise consumer (``out_bf16``, honoured inside
+    ``torch.autocast(bfloat16)`` only): bit for bit the fp32 output rounded to nearest even - the value the consuming GEMM
+    rounds its operand to in this mode - on the whole-plane (32x64), staged-tile (40x72 with k = 5) and generic kernels,
+    with and without the virtual concat of the norm; outside autocast the request is ignored."""
+    from paradis_model_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (B, C, H, W, k) in ((2, 6, 32, 64, 5), (1, 5, 40, 72, 5), (2, 4, 12, 20, 3), (1, 3, 16, 32, 7)):
+        x = torch.randn(B, C, H, W, generator=g).cuda()
+        w = torch.randn(C, 1, k, k, generator=g).cuda()
+        ref = ops.dwconv_geo(x, w)
+        assert ops.dwconv_geo(x, w, out_bf16=True).dtype == torch.float32         # no autocast: ignored
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ops.dwconv_geo(x, w, out_bf16=True)
+        assert y.dtype == torch.bfloat16 and torch.equal(y, ref.to(torch.bfloat16)), (B, C, H, W, k)
+    for (B, C1, C2, H, W) in ((2, 64, 0, 16, 32), (1, 1024, 128, 32, 64), (2, 40, 8, 12, 20), (1, 130, 0, 9, 16)):
+        x = torch.randn(B, C1, H, W, generator=g).cuda()
+        xe = torch.randn(B, C2, H, W, generator=g).cuda() if C2 else None
+        w = torch.randn(C1 + C2, generator=g).cuda()
+        b = torch.randn(C1 + C2, generator=g).cuda()
+        ref = ops.channel_norm(x, w, b, 1e-5, xe)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ops.channel_norm(x, w, b, 1e-5, xe, out_bf16=True)
+        assert y.dtype == torch.bfloat16 and torch.equal(y, ref.to(torch.bfloat16)), (B, C1, C2, H, W)
+
+
+def test_gradient_handoff_and_its_fallbacks():
+    """norm -> pointwise with the norm's output stored as bf16: the consumer leaves the fp32-word gradient in the producer's
+    hand-off slot and autograd carries a zero-stride placeholder.  Same gradients (bit for bit: same kernels on the same
+    values) as with fp32 storage; under non-reentrant checkpointing the recomputed tensor carries no token and the REAL
+    bf16 gradient travels instead - same values again; a placeholder that reaches a producer with an empty slot raises."""
+    from torch.utils.checkpoint import checkpoint
+    from paradis_model_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, Co, H, W = 2, 48, 40, 16, 32
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    nw = torch.nn.Parameter(torch.randn(C, generator=g).cuda())
+    nb = torch.nn.Parameter(torch.randn(C, generator=g).cuda())
+    w = torch.nn.Parameter((torch.randn(Co, C, 1, 1, generator=g) / C ** 0.5).cuda())
+    ct = torch.randn(B, Co, H, W, generator=g).cuda()
+
+    def block(xi, stored):
+        y = ops.channel_norm(xi, nw, nb, 1e-5, out_bf16=stored)
+        return ops.pointwise(y, w)
+
+    def run(stored, ckpt):
+        for p in (nw, nb, w):
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = checkpoint(block, xi, stored, use_reentrant=False) if ckpt else block(xi, stored)
+        out.backward(ct)
+        return [t.detach().clone() for t in (out, xi.grad, nw.grad, nb.grad, w.grad)]
+
+    base = run(False, False)
+    for stored, ckpt in ((True, False), (True, True), (False, True)):
+        got = run(stored, ckpt)
+        # (forward: two GEMM kernels - register-staged vs LDS-DMA - accumulate in differently signed spaces: fp32 noise)
+        assert rms_rel(got[0], base[0]) <= 1e-6, (stored, ckpt)
+        for a, b_ in zip(got[1:], base[1:]):
+            assert rms_rel(a, b_) <= 1e-6, (stored, ckpt, rms_rel(a, b_))
+    # an orphaned placeholder is refused
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops.channel_norm(x.clone().requires_grad_(True), nw, nb, 1e-5, out_bf16=True)
+    assert y.dtype == torch.bfloat16
+    with pytest.raises(RuntimeError, match="not handed over"):
+        y.backward(ops._placeholder_grad16(y))
