@@ -1542,6 +1542,11 @@ pw_gemm_b16_kernel(GemmArgs g) {
   }
 }
 
+// (A 256 x 256 workgroup tile for this kernel - 2 x 4 waves of 128 x 64, 200-219 registers, one workgroup per CU, four
+//  32 KB stages - halves the activation bytes pulled from L2 and was built and measured in round 6: 309 against 218 us at
+//  896 x 896, the bf16-mixed step 83.8 against 77.6 ms.  At two waves per SIMD the store-bound epilogue doubles - a K = 32
+//  launch 161 against 78 us - and takes back more than the k-loop gains; the weight gradient, whose epilogue writes one
+//  fp32 tile per slab, does gain from that tile: pw_gemm_wgrad_square_kernel.  Removed; profiles/r06_amp_gemm_tiles.txt.)
 // (A soft rendezvous of a K-range slab's tiles - round 5: FETCH_SIZE 8.48 -> 4.06 GB per launch at 128 x 256, kernel 13 %
 //  slower - was measured and removed: DESIGN_HISTORY.md section 4.1d, profiles/r05_wgrad_rendezvous.txt.)
 template <int NP>
@@ -1969,6 +1974,159 @@ pw_gemm_wgrad_tall_kernel(GemmArgs g) {
   if (m0 + (wm >> 1) * 128 < g.M) gemm_epilogue(g, acc, bz, m0 + (wm >> 1) * 128, n0, wm & 1, wn, li, lh);
 }
 
+// ... and on a 256 x 256 tile (1.07 GB): 4 x 2 waves of 64 x 128, 128 accumulator registers per lane, ONE workgroup per CU
+// (two waves per SIMD: enough for a kernel that waits on L2 bytes, not on the matrix pipe); every thread stages one chunk of
+// each operand.  1024 x 1024, bf16 operands: 296 us (128 x 128) -> 250 (256 x 128) -> 221 (256 x 256).  PARADIS_WGRAD_SQUARE=0 /
+// PARADIS_WGRAD_TALL=0 select the smaller tiles (A/B runs).
+constexpr int SQ_P = 256 + 8, SQ_STAGE = 4 * SQ_P;   // chunks
+constexpr size_t sq_lds_bytes() { return (size_t)2 * SQ_STAGE * 16; }
+template <bool A16, bool B16>
+__global__ void __launch_bounds__(512, 2)
+pw_gemm_wgrad_square_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A: 2 x SQ_P | B: 2 x SQ_P]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr bool stB = true;
+
+  const int MT = (g.M + 255) / 256, NT = (g.N + 255) / 256;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = L % MT, nt = (L / MT) % NT, bz = L / (MT * NT);
+  const int m0 = mt * 256, n0 = nt * 256;
+  const int KT = g.K / SBK;
+  const int64_t total = (int64_t)g.inner * KT;
+  const int t_begin = (int)(total * bz / g.nbatch);
+  const int T = (int)(total * (bz + 1) / g.nbatch) - t_begin;
+
+  const int srow = tid >> 1, sh = tid & 1;
+  constexpr int EA = A16 ? 2 : 4, EB = B16 ? 2 : 4;
+  const char* Ag = reinterpret_cast<const char*>(g.A) + ((int64_t)min(m0 + srow, g.M - 1) * g.lda + sh * 8) * EA;
+  const char* Bg = reinterpret_cast<const char*>(g.B) + ((int64_t)min(n0 + srow, g.N - 1) * g.ldb + sh * 8) * EB;
+
+  int f_ib = t_begin / KT, f_kt = t_begin - f_ib * KT;
+  struct Regs { f32x4 a0, a1, b0, b1; };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Regs r0{zero4, zero4, zero4, zero4}, r1 = r0;
+  auto fetch = [&](Regs& r) __attribute__((always_inline)) {
+    const char* a = Ag + ((int64_t)f_ib * g.a_is + (int64_t)f_kt * SBK) * EA;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.a0) : "v"(a) : "memory");
+    if constexpr (!A16) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(r.a1) : "v"(a) : "memory");
+    if (stB) {
+      const char* b = Bg + ((int64_t)f_ib * g.b_is + (int64_t)f_kt * SBK) * EB;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.b0) : "v"(b) : "memory");
+      if constexpr (!B16) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(r.b1) : "v"(b) : "memory");
+    }
+    if (++f_kt == KT) { f_kt = 0; ++f_ib; }
+  };
+  constexpr int NLA = A16 ? 1 : 2, NLB = B16 ? 1 : 2;
+#define USE_RN(r, S) do { asm volatile("s_waitcnt vmcnt(" S ")" :: "v"(r.a0), "v"(r.a1), "v"(r.b0), "v"(r.b1) : "memory"); \
+                          __builtin_amdgcn_sched_barrier(0); } while (0)
+  // the registers of the older fetch are complete; the younger fetch (NLA or NLA + NLB loads of this wave) stays in flight
+  auto wait_keep_one = [&](Regs& r) __attribute__((always_inline)) {
+    if (stB) {
+      if constexpr (NLA + NLB == 4) USE_RN(r, "4"); else if constexpr (NLA + NLB == 3) USE_RN(r, "3"); else USE_RN(r, "2");
+    } else {
+      if constexpr (NLA == 2) USE_RN(r, "2"); else USE_RN(r, "1");
+    }
+  };
+  const bool do_rowsum = g.rowsum != nullptr && nt == 0;
+  float rs = 0.f;
+  const uint32_t slab_flip = (SPLIT_SIGNED_WGRAD && (bz & 1)) ? 0x80000000u : 0u;      // workgroup-uniform
+  const uint32_t slab_flip16 = slab_flip | (slab_flip >> 16);
+  auto split_store = [&](const Regs& r, int st, bool keep) __attribute__((always_inline)) {
+    u32x4* o = img + st * SQ_STAGE + sh * SQ_P + srow;
+    if constexpr (A16) {
+      const u32x4 c = __builtin_bit_cast(u32x4, r.a0);
+      if (do_rowsum) {
+        float add = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) add += __uint_as_float(c[i] << 16) + __uint_as_float(c[i] & 0xffff0000u);
+        rs += keep ? add : 0.f;
+      }
+      o[0] = (u32x4){c[0] ^ slab_flip16, c[1] ^ slab_flip16, c[2] ^ slab_flip16, c[3] ^ slab_flip16};
+    } else {
+      const float xa[8] = {r.a0.x, r.a0.y, r.a0.z, r.a0.w, r.a1.x, r.a1.y, r.a1.z, r.a1.w};
+      const float add = ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+      rs += keep ? add : 0.f;
+      float xs[8];
+      flip8(xs, xa, slab_flip);
+      o[0] = round8(xs);
+    }
+    if (stB) {
+      u32x4* ob = img + st * SQ_STAGE + 2 * SQ_P + sh * SQ_P + srow;      // (srow < 128 in these waves)
+      if constexpr (B16) {
+        ob[0] = __builtin_bit_cast(u32x4, r.b0);
+      } else {
+        const float xb[8] = {r.b0.x, r.b0.y, r.b0.z, r.b0.w, r.b1.x, r.b1.y, r.b1.z, r.b1.w};
+        ob[0] = round8(xb);
+      }
+    }
+  };
+
+  f32x16 acc[2][2], acc2[2][2];     // columns wn 128 + [0, 64) and + [64, 128)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+
+  if (T > 0) {
+    fetch(r0);
+    if (T > 1) { fetch(r1); wait_keep_one(r0); } else { USE_RN(r0, "0"); }
+    split_store(r0, 0, do_rowsum);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
+    const u32x4* As = img + cur * SQ_STAGE + lh * SQ_P + wm * 64 + li;
+    const u32x4* Bs = img + cur * SQ_STAGE + 2 * SQ_P + lh * SQ_P + wn * 128 + li;
+    SplitFrags<1> f, f2;
+    split_tile_read<1, 0, 0>(As, Bs, f);
+    f2.a[0][0] = f.a[0][0]; f2.a[0][1] = f.a[0][1];
+    f2.b[0][0] = Bs[64]; f2.b[0][1] = Bs[96];
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < T) { fetch(rload); wait_keep_one(rsplit); }
+    else USE_RN(rsplit, "0");
+    split_tile_mfma<1>(f, acc);
+    split_tile_mfma<1>(f2, acc2);
+    split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, 0, r0, r1);
+    if (t + 1 < T) step(t + 1, 1, r1, r0);
+  }
+#undef USE_RN
+  if (do_rowsum) {
+    rs += __shfl_xor(rs, 1, 64);
+    const int m = m0 + srow;
+    if (sh == 0 && m < g.M) g.rowsum[(int64_t)bz * g.M + m] = rs;
+  }
+  if (slab_flip) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = -acc[i][j][r]; acc2[i][j][r] = -acc2[i][j][r]; }
+  }
+  // the wave's 64 rows as rows of the 128-row tile at m0 + 128 (wm >> 1)
+  if (m0 + (wm >> 1) * 128 < g.M) {
+    const int mm = m0 + (wm >> 1) * 128, nn = n0 + wn * 128;           // 64-column halves as "wn" 0 / 1 of a 128-column tile
+    if (nn < g.N) {
+      gemm_epilogue(g, acc, bz, mm, nn, wm & 1, 0, li, lh);
+      gemm_epilogue(g, acc2, bz, mm, nn, wm & 1, 1, li, lh);
+    }
+  }
+}
+
 // out[i] = slabs[0][i] + slabs[1][i] + ... in that order; vec: n % 4 == 0 and 16-byte aligned pointers (four
 // elements per thread, four slabs' loads in flight)
 __global__ void __launch_bounds__(256)
@@ -2040,6 +2198,17 @@ int wgrad_dma_wgs() { return g_wgrad_dma_stages == 2 ? 4 : 3; }
 bool wgrad_tall_ok(int M) {
   static const bool on = [] { const char* e = getenv("PARADIS_WGRAD_TALL"); return !(e && e[0] == '0'); }();
   return on && M >= 256 && ((M + 255) / 256) * 256 * 7 <= M * 8;
+}
+bool wgrad_square_on() {
+  static const bool on = [] { const char* e = getenv("PARADIS_WGRAD_SQUARE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+int wgrad_splits_square(int B, int M, int K, int N) {
+  const int tiles = ((M + 255) / 256) * ((K + 255) / 256);
+  const int64_t total_kt = (int64_t)B * ((N + SBK - 1) / SBK);
+  int s = (int)std::max<int64_t>(1, std::min<int64_t>(256 / tiles, total_kt));
+  if (s > 1) s &= ~1;
+  return s;
 }
 int wgrad_splits_tall(int B, int M, int K, int N) {
   const int tiles = ((M + 255) / 256) * ((K + BN - 1) / BN);
@@ -2491,7 +2660,8 @@ extern "C" int paradis_pw_gemm_dgrad16(const void* WTsplit, const void* dY, cons
 extern "C" size_t paradis_pw_gemm_wgrad_ws_bytes(int B, int M, int K, int N) {
   const int b = std::max(B, 1);
   const int S = std::max({wgrad_splits(b, M, K, N, DBK, wgrad_dma_wgs()), wgrad_splits(b, M, K, N, g_bk, g_wg_per_cu),
-                          wgrad_splits(b, M, K, N, SBK, 3), wgrad_splits_tall(b, M, K, N)});
+                          wgrad_splits(b, M, K, N, SBK, 3), wgrad_splits_tall(b, M, K, N),
+                          wgrad_splits_square(b, M, K, N)});
   return (size_t)S * M * ((size_t)K + 1) * sizeof(float) + 256;   // slabs + row-sum partials
 }
 
@@ -2531,7 +2701,8 @@ static int pw_gemm_wgrad_impl(const float* dY, const float* X, float* dW, float*
   const bool use_split = io16 != 0 || (scheme != PARADIS_GEMM_EXACT && wgrad_vec_layout(N, dy_bs, x_bs, dY, X));
   const bool dma = use_split || wgrad_dma_ok(N, dy_bs, x_bs, dY, X);   // "dma" = kernels with fused row sums
   const bool tall = use_split && scheme == PARADIS_GEMM_BF16 && wgrad_tall_ok(M);
-  const int S = tall ? wgrad_splits_tall(B, M, K, N)
+  const bool square = tall && wgrad_square_on() && ((K + 255) / 256) * 256 * 7 <= K * 8;
+  const int S = square ? wgrad_splits_square(B, M, K, N) : tall ? wgrad_splits_tall(B, M, K, N)
               : use_split ? wgrad_splits(B, M, K, N, SBK, 3)
                           : dma ? wgrad_splits(B, M, K, N, DBK, wgrad_dma_wgs())
                                 : wgrad_splits(B, M, K, N, g_bk, g_wg_per_cu);
@@ -2549,7 +2720,15 @@ static int pw_gemm_wgrad_impl(const float* dY, const float* X, float* dW, float*
   g.stagger = g_stagger;
   g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = (tall ? (M + 255) / 256 : (M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-  if (tall) {
+  if (square) {
+    g.io16 = io16;
+    const dim3 gr(((M + 255) / 256) * ((K + 255) / 256) * S), bl(512);
+    const size_t ld = sq_lds_bytes();
+    if ((io16 & IO_A16) && (io16 & IO_B16)) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, true>), gr, bl, ld, st, g);
+    else if (io16 & IO_A16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, false>), gr, bl, ld, st, g);
+    else if (io16 & IO_B16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, true>), gr, bl, ld, st, g);
+    else hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, false>), gr, bl, ld, st, g);
+  } else if (tall) {
     g.io16 = io16;
     const dim3 gr(grid), bl(512);
     const size_t ld = tall_lds_bytes();
