@@ -1974,6 +1974,10 @@ pw_gemm_wgrad_tall_kernel(GemmArgs g) {
   if (m0 + (wm >> 1) * 128 < g.M) gemm_epilogue(g, acc, bz, m0 + (wm >> 1) * 128, n0, wm & 1, wn, li, lh);
 }
 
+// (The bf16x3 - fp32-width - weight gradient on this 256 x 128 tile, three planes per operand image and 24 MFMAs per wave
+//  and k-tile in the 128 registers that two 8-wave workgroups per CU leave, was tried in round 6: the step went from 150 to
+//  308 ms - the twelve operand fragments next to 64 accumulators spill - and it failed the accuracy test; removed.  The
+//  six-product kernels are bound by the matrix pipe's power budget, not by L2 bytes: DESIGN.md section 4.1.)
 // ... and on a 256 x 256 tile (1.07 GB): 4 x 2 waves of 64 x 128, 128 accumulator registers per lane, ONE workgroup per CU
 // (two waves per SIMD: enough for a kernel that waits on L2 bytes, not on the matrix pipe); every thread stages one chunk of
 // each operand.  1024 x 1024, bf16 operands: 296 us (128 x 128) -> 250 (256 x 128) -> 221 (256 x 256).  PARADIS_WGRAD_SQUARE=0 /
