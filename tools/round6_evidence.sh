@@ -40,3 +40,11 @@ for t, c, k in sorted(rows, reverse=True):
 print("TOTAL %.2f ms in %.0f launches; ATen / runtime copy kernels: %.3f ms in %.1f launches" % (tot, totn, aten, atenn))
 PY
 tail -3 gpurun_out/profiles_out/r06_steady_step_launches.txt
+# SQ counters of the advection kernels on the three grids (velocity sigma ~ what the default model produces at random init)
+for cfg in "32x64 32 768 1.0" "128x256 8 768 0.2" "721x1440 1 768 0.3"; do
+  tag=$(echo $cfg | cut -d' ' -f1)
+  rm -rf gpurun_out/apmc_1 gpurun_out/apmc_2 gpurun_out/apmc_3
+  bash tools/advect_pmc.sh $cfg
+  python3 tools/pmc_table.py gpurun_out/apmc_1 gpurun_out/apmc_2 gpurun_out/apmc_3 sl_advect > gpurun_out/profiles_out/r06_advect_sq_$tag.txt 2>&1
+done
+tail -30 gpurun_out/profiles_out/r06_advect_sq_721x1440.txt
