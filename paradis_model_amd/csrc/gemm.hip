@@ -1300,7 +1300,7 @@ pw_gemm_split_wide_kernel(GemmArgs g) {
 //  STAGED activation tiles, so that a 16 x 256 fp32 tile is fetched from L2 and split into its bf16 planes once per 256 output
 //  rows: 40 instead of 56 KB through L2 per 256 x 256 x 16 and half the split arithmetic per MFMA; the copies take turns
 //  fetching / splitting; 96 KB of LDS, one 1024-thread workgroup per CU; bit-identical results - was built in round 6
-//  (commit adad739 + 1, `pw_gemm_split_quad_kernel`) and measured on the training step: 156.2 / 157.0 against 154.8 / 155.0 ms,
+//  (`pw_gemm_split_quad_kernel`; the structure is all that is recorded) and measured on the training step: 156.2 / 157.0 against 154.8 / 155.0 ms,
 //  same box.  Fewer L2 bytes and fewer VALU operations per MFMA buy nothing: what bounds these kernels is the matrix pipe
 //  under the chip's power budget (busy x clock), as the yardstick of DESIGN.md 4.1 says.  Removed; profiles/r06_gemm_quad.txt.)
 // wgrad: dW[M,N'] = sum over (sample, p) A[m][p] B[n][p], both operands p-contiguous fp32, both split

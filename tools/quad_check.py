@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""PARADIS_GEMM_QUAD=1 (256 x 256 bf16x3 tile, activation tile staged once for two m-tiles) against the 128 x 256 kernel:
-bitwise equality of forward / dgrad outputs over the layer shapes (run twice, once per setting, compare saved results)."""
+"""Bitwise comparison of the bf16x3 pointwise GEMM (forward, dX, dW) over the layer shapes between two library builds or
+settings: run once per setting (`PARADIS_HIP_LIB=... python tools/quad_check.py out.pt [reference.pt]`).  Round 6 used it
+for the 256 x 256 'quad' tile (profiles/r06_gemm_quad.txt)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
