@@ -1553,7 +1553,12 @@ pw_gemm_b16_kernel(GemmArgs g) {
 //  32 KB stages - halves the activation bytes pulled from L2 and was built and measured in round 6: 309 against 218 us at
 //  896 x 896, the bf16-mixed step 83.8 against 77.6 ms.  At two waves per SIMD the store-bound epilogue doubles - a K = 32
 //  launch 161 against 78 us - and takes back more than the k-loop gains; the weight gradient, whose epilogue writes one
-//  fp32 tile per slab, does gain from that tile: pw_gemm_wgrad_square_kernel.  Removed; profiles/r06_amp_gemm_tiles.txt.)
+//  fp32 tile per slab, does gain from that tile: pw_gemm_wgrad_square_kernel.  Removed; profiles/r06_amp_gemm_tiles.txt.
+//  The same 256 x 256 tile with SIXTEEN waves - 1024 threads, two copies of the arrangement above sharing the activation tile
+//  in LDS, every wave keeping its 64 x 64 accumulators and epilogue, 0.47 instead of 0.94 GB of activations per launch - was
+//  parity-green and changed nothing: 183 / 210 against 180 / 222 us at 896^2 / 1024^2, the step 78.7 against 77.8 ms.  With
+//  8 MFMAs per wave between two barriers the kernel waits on its per-tile chain (DMA landing, barrier, fragment reads), not on
+//  L2 bytes - which is why the weight gradient, whose taller tiles also DOUBLE the MFMAs per barrier, gained and this did not.)
 // (A soft rendezvous of a K-range slab's tiles - round 5: FETCH_SIZE 8.48 -> 4.06 GB per launch at 128 x 256, kernel 13 %
 //  slower - was measured and removed: DESIGN_HISTORY.md section 4.1d, profiles/r05_wgrad_rendezvous.txt.)
 template <int NP>
