@@ -1549,6 +1549,118 @@ pw_gemm_b16_kernel(GemmArgs g) {
   }
 }
 
+// 256 x 256 x 64 steps with sixteen waves (round 6): 1024 threads = two copies (msub 0 / 1 = m-tiles 2 mt2, 2 mt2 + 1) of the
+// 8-wave arrangement above sharing the activation tile in LDS, and k-steps of 64: SIXTEEN MFMAs per wave between two
+// barriers instead of eight - the 128 x 256 x 32 kernel waits on its per-step chain (DMA landing, barrier, fragment reads;
+// matrix pipe 19 % busy at 2.4 GHz), not on bytes.  Every wave keeps its 64 x 64 accumulators and its epilogue; sixteen waves
+// per CU as with two 512-thread workgroups.  Two stages of 64 KB (32 KB of weight tiles - two k32 image tiles per copy - and
+// 32 KB of activations); a thread issues four LDS-DMAs per step.  An odd number of k32 image tiles: the last step runs
+// two of its four k16 slices.
+constexpr int B16Q_KT = 64;
+constexpr int B16Q_STAGE = 2 * (2 * B16_ACH) + 2 * B16_BCH;          // chunks per stage: [copy 0: 2 k32 weight tiles | copy 1 | 64 rows of activations]
+constexpr size_t b16q_lds_bytes() { return (size_t)2 * B16Q_STAGE * 16; }
+template <bool C16, bool ZM16>
+__global__ void __launch_bounds__(1024, 4)
+pw_gemm_b16_quad_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* img = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int msub = wave >> 3, w8 = wave & 7, sub = w8 >> 2, lw = w8 & 3;
+  const int wm = lw >> 1, wn = lw & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, MT2 = (MT + 1) / 2, NT = (g.N + BN - 1) / BN, NT2 = (NT + 1) / 2;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt2 = L % MT2, nt2 = (L / MT2) % NT2, bz = L / (MT2 * NT2);
+  const bool live = 2 * nt2 + sub < NT && 2 * mt2 + msub < MT;       // wave-uniform
+  const int nt = min(2 * nt2 + sub, NT - 1), mt = min(2 * mt2 + msub, MT - 1);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T32 = (g.K + B16_KT - 1) / B16_KT, T = (T32 + 1) / 2;     // k32 image tiles, k64 steps
+
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T32 * B16_ACH + (tid & 511);
+  const uint16_t* Bb = reinterpret_cast<const uint16_t*>(g.B) + (int64_t)bz * g.b_bs;
+  // this lane's two source chunks of the activation tile: LDS chunk c = (2 wave + j) 64 + lane -> row c >> 5 (0..63), slot c & 31
+  int brow[2], bcol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = (2 * wave + j) * 64 + lane, r = c >> 5, slot = c & 31;
+    brow[j] = r;
+    bcol[j] = min(nt2 * 2 * BN + 8 * (slot ^ ((r & 3) << 2)), g.N - 8);
+  }
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    u32x4* st = img + (t & 1) * B16Q_STAGE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {        // the two k32 image tiles of the step (an odd T32: the last one twice, second use skipped)
+      const int t32 = min(2 * t + h, T32 - 1);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t32 * B16_ACH),
+                                       (lds_ptr_t)(st + (2 * msub + h) * B16_ACH + w8 * 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = min(t * B16Q_KT + brow[j], g.K - 1);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bb + (int64_t)k * g.ldb + bcol[j]),
+                                       (lds_ptr_t)(st + 4 * B16_ACH + (2 * wave + j) * 64), 16, 0, 0);
+    }
+  };
+  const int gq = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  uint32_t boff[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int nbi = sub * 4 + wn * 2 + tn;
+    boff[tn] = (uint32_t)((8 * lh + q4) * 512 + (4 * (nbi ^ q4) + 2 * (gq & 1) + (p4 >> 1)) * 16 + 8 * (p4 & 1));
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0);
+  for (int t = 0; t < T; ++t) {
+    // step t has landed (the only DMAs in flight) and every wave is past step t - 1: refill that stage at once
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < T) issue(t + 1);
+    const u32x4* st = img + (t & 1) * B16Q_STAGE;
+    const u32x4* As = st + 2 * msub * B16_ACH + lh * SCH + wm * 64 + li;
+    const char* Bs = reinterpret_cast<const char*>(st + 4 * B16_ACH);
+    const int nsl = (2 * t + 1 < T32) ? 4 : 2;       // workgroup-uniform
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl < nsl) {
+        const u32x4 a0 = As[sl * 2 * SCH], a1 = As[sl * 2 * SCH + 32];     // (slice sl of the two k32 image tiles: 2 SCH chunks apart)
+        u32x4 b[2];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const char* pb = Bs + boff[tn] + sl * 16 * 512;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(pb));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(pb + 4 * 512));
+          const uint64_t l64 = __builtin_bit_cast(uint64_t, lo), h64 = __builtin_bit_cast(uint64_t, hi);
+          b[tn] = (u32x4){(uint32_t)l64, (uint32_t)(l64 >> 32), (uint32_t)h64, (uint32_t)(h64 >> 32)};
+        }
+        SPLIT_MFMA(a0, b[0], acc[0][0]); SPLIT_MFMA(a0, b[1], acc[0][1]);
+        SPLIT_MFMA(a1, b[0], acc[1][0]); SPLIT_MFMA(a1, b[1], acc[1][1]);
+      }
+    }
+  }
+  if (live) {
+    if (SPLIT_SIGNED) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[1][tn][r] = -acc[1][tn][r];
+    }
+    gemm_epilogue<true, C16, ZM16>(g, acc, bz, m0, n0, wm, wn, li, lh);
+  }
+}
+
 // (A 256 x 256 workgroup tile for this kernel - 2 x 4 waves of 128 x 64, 200-219 registers, one workgroup per CU, four
 //  32 KB stages - halves the activation bytes pulled from L2 and was built and measured in round 6: 309 against 218 us at
 //  896 x 896, the bf16-mixed step 83.8 against 77.6 ms.  At two waves per SIMD the store-bound epilogue doubles - a K = 32
@@ -1558,7 +1670,8 @@ pw_gemm_b16_kernel(GemmArgs g) {
 //  in LDS, every wave keeping its 64 x 64 accumulators and epilogue, 0.47 instead of 0.94 GB of activations per launch - was
 //  parity-green and changed nothing: 183 / 210 against 180 / 222 us at 896^2 / 1024^2, the step 78.7 against 77.8 ms.  With
 //  8 MFMAs per wave between two barriers the kernel waits on its per-tile chain (DMA landing, barrier, fragment reads), not on
-//  L2 bytes - which is why the weight gradient, whose taller tiles also DOUBLE the MFMAs per barrier, gained and this did not.)
+//  L2 bytes - which is why the weight gradient, whose taller tiles also DOUBLE the MFMAs per barrier, gained and this did not.
+//  With k-steps of 64 on top - sixteen MFMAs per barrier - it does pay: pw_gemm_b16_quad_kernel above.)
 // (A soft rendezvous of a K-range slab's tiles - round 5: FETCH_SIZE 8.48 -> 4.06 GB per launch at 128 x 256, kernel 13 %
 //  slower - was measured and removed: DESIGN_HISTORY.md section 4.1d, profiles/r05_wgrad_rendezvous.txt.)
 template <int NP>
@@ -2362,6 +2475,28 @@ int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
             paradis_set_error("pw_gemm(b16): cannot reserve LDS");
             return 2;
           }
+      }
+      const int MT = (d.M + BM - 1) / BM;
+      static const bool quad_on = [] { const char* e = getenv("PARADIS_GEMM_B16_QUAD"); return !(e && e[0] == '0'); }();   // (=0: A/B)
+      if (quad_on && MT >= 2 && ((MT + 1) / 2) * 2 * 7 <= MT * 8) {       // (an odd MT repeats its last m-tile: at most 1/8)
+        static PerDeviceOnce once_q;
+        if (once_q.first()) {
+          const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<false, false>),
+                               reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<true, false>),
+                               reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<false, true>),
+                               reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<true, true>)};
+          for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16q_lds_bytes()) != hipSuccess) {
+              paradis_set_error("pw_gemm(b16 quad): cannot reserve LDS");
+              return 2;
+            }
+        }
+        const dim3 gq(((MT + 1) / 2) * ((NT + 1) / 2) * d.nbatch), bq(1024);
+        if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<true, true>), gq, bq, b16q_lds_bytes(), st, d);
+        else if (c16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<true, false>), gq, bq, b16q_lds_bytes(), st, d);
+        else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<false, true>), gq, bq, b16q_lds_bytes(), st, d);
+        else hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<false, false>), gq, bq, b16q_lds_bytes(), st, d);
+        return 0;
       }
       const dim3 gr(grid), bl(512);
       if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, true>), gr, bl, b16_lds_bytes(), st, d);
