@@ -254,7 +254,10 @@ def test_narrow_inputs_under_autocast_in_grad_mode():
 
 
 @pytest.mark.parametrize("B,Ci,Ch,Co,H,W", [(2, 186, 64, 40, 16, 32), (1, 1024, 896, 1024, 32, 64), (3, 130, 258, 97, 9, 16),
-                                            (2, 96, 160, 64, 12, 20)])
+                                            (2, 96, 160, 64, 12, 20),
+                                            # the 256 x 256 x 64 kernel with an ODD number of k32 image tiles (its last step
+                                            # runs half its slices): forward K = 96, data gradient K = 160
+                                            (2, 64, 96, 256, 16, 32), (1, 64, 256, 160, 16, 32)])
 def test_bf16_stored_tensors_carry_the_same_values(B, Ci, Ch, Co, H, W):
     """Round 6: in the bf16-mixed scheme the activations between two chained pointwise layers are STORED as bf16 (what
     the reference's autocast conv2d returns: model/blocks.py:86,110 under train.py:56) instead of as bf16 values in fp32
