@@ -34,7 +34,7 @@ for t, dlt in ev:
 span = iv[-1][1] - iv[0][0]
 names = {}
 for s, e, n in iv:
-    key = re.sub(r"^void ", "", n)
+    key = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
     key = re.sub(r"[<(].*", "", key)[:60]
     a = names.setdefault(key, [0, 0])
     a[0] += 1
