@@ -2108,12 +2108,12 @@ pw_gemm_wgrad_tall_kernel(GemmArgs g) {
 // each operand.  1024 x 1024, bf16 operands: 296 us (128 x 128) -> 250 (256 x 128) -> 221 (256 x 256).  PARADIS_WGRAD_SQUARE=0 /
 // PARADIS_WGRAD_TALL=0 select the smaller tiles (A/B runs).
 constexpr int SQ_P = 256 + 8, SQ_STAGE = 4 * SQ_P;   // chunks
-constexpr size_t sq_lds_bytes() { return (size_t)2 * SQ_STAGE * 16; }
+constexpr size_t sq_lds_bytes() { return (size_t)4 * SQ_STAGE * 16; }
 template <bool A16, bool B16>
 __global__ void __launch_bounds__(512, 2)
 pw_gemm_wgrad_square_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [2 stages][A: 2 x SQ_P | B: 2 x SQ_P]
+  u32x4* img = reinterpret_cast<u32x4*>(lds);        // [4 stages][A: 2 x SQ_P | B: 2 x SQ_P]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -2206,31 +2206,67 @@ pw_gemm_wgrad_square_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
-  if (T > 0) {
-    fetch(r0);
-    if (T > 1) { fetch(r1); wait_keep_one(r0); } else { USE_RN(r0, "0"); }
-    split_store(r0, 0, do_rowsum);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-  auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
-    const u32x4* As = img + cur * SQ_STAGE + lh * SQ_P + wm * 64 + li;
-    const u32x4* Bs = img + cur * SQ_STAGE + 2 * SQ_P + lh * SQ_P + wn * 128 + li;
-    SplitFrags<1> f, f2;
-    split_tile_read<1, 0, 0>(As, Bs, f);
-    f2.a[0][0] = f.a[0][0]; f2.a[0][1] = f.a[0][1];
-    f2.b[0][0] = Bs[64]; f2.b[0][1] = Bs[96];
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < T) { fetch(rload); wait_keep_one(rsplit); }
-    else USE_RN(rsplit, "0");
-    split_tile_mfma<1>(f, acc);
-    split_tile_mfma<1>(f2, acc2);
-    split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+  if constexpr (A16 && B16) {
+    // Two k-tiles per barrier (sixteen MFMAs per wave between two barriers instead of eight): a ring of FOUR stages, tile t in
+    // stage t & 3.  Entering a pair (t, t + 1) both tiles are staged and the loads of t + 2 / t + 3 sit in r0 / r1; inside the
+    // pair tile t + 2 is stored behind the MFMAs of t and tile t + 3 behind those of t + 1 (their stages were last read a pair
+    // ago: every wave is past that pair's barrier), each followed by the fetch of the tile four ahead.
+    auto stage_tile = [&](int t, Regs& r, bool younger_in_flight) __attribute__((always_inline)) {
+      if (younger_in_flight) wait_keep_one(r); else USE_RN(r, "0");
+      split_store(r, t & 3, do_rowsum);
+    };
+    if (T > 0) { fetch(r0); }
+    if (T > 1) { fetch(r1); }
+    if (T > 0) { stage_tile(0, r0, T > 1); if (T > 2) fetch(r0); }
+    if (T > 1) { stage_tile(1, r1, T > 2); if (T > 3) fetch(r1); }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  for (int t = 0; t < T; t += 2) {
-    step(t, 0, r0, r1);
-    if (t + 1 < T) step(t + 1, 1, r1, r0);
+    auto half = [&](int t, Regs& r) __attribute__((always_inline)) {      // tile t is staged; r holds the loads of tile t + 2
+      const u32x4* As = img + (t & 3) * SQ_STAGE + lh * SQ_P + wm * 64 + li;
+      const u32x4* Bs = img + (t & 3) * SQ_STAGE + 2 * SQ_P + lh * SQ_P + wn * 128 + li;
+      SplitFrags<1> f, f2;
+      split_tile_read<1, 0, 0>(As, Bs, f);
+      f2.a[0][0] = f.a[0][0]; f2.a[0][1] = f.a[0][1];
+      f2.b[0][0] = Bs[64]; f2.b[0][1] = Bs[96];
+      __builtin_amdgcn_sched_barrier(0);
+      split_tile_mfma<1>(f, acc);
+      split_tile_mfma<1>(f2, acc2);
+      if (t + 2 < T) {
+        stage_tile(t + 2, r, t + 3 < T);       // (the fetch of tile t + 3, issued after this one's, may stay in flight)
+        if (t + 4 < T) fetch(r);
+      }
+    };
+    for (int t = 0; t < T; t += 2) {
+      half(t, r0);
+      if (t + 1 < T) half(t + 1, r1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    if (T > 0) {
+      fetch(r0);
+      if (T > 1) { fetch(r1); wait_keep_one(r0); } else { USE_RN(r0, "0"); }
+      split_store(r0, 0, do_rowsum);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
+      const u32x4* As = img + cur * SQ_STAGE + lh * SQ_P + wm * 64 + li;
+      const u32x4* Bs = img + cur * SQ_STAGE + 2 * SQ_P + lh * SQ_P + wn * 128 + li;
+      SplitFrags<1> f, f2;
+      split_tile_read<1, 0, 0>(As, Bs, f);
+      f2.a[0][0] = f.a[0][0]; f2.a[0][1] = f.a[0][1];
+      f2.b[0][0] = Bs[64]; f2.b[0][1] = Bs[96];
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < T) { fetch(rload); wait_keep_one(rsplit); }
+      else USE_RN(rsplit, "0");
+      split_tile_mfma<1>(f, acc);
+      split_tile_mfma<1>(f2, acc2);
+      split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int t = 0; t < T; t += 2) {
+      step(t, 0, r0, r1);
+      if (t + 1 < T) step(t + 1, 1, r1, r0);
+    }
   }
 #undef USE_RN
   if (do_rowsum) {
@@ -2875,6 +2911,18 @@ static int pw_gemm_wgrad_impl(const float* dY, const float* X, float* dW, float*
     g.io16 = io16;
     const dim3 gr(((M + 255) / 256) * ((K + 255) / 256) * S), bl(512);
     const size_t ld = sq_lds_bytes();
+    static PerDeviceOnce once_sq;
+    if (once_sq.first()) {
+      const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<false, false>),
+                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<true, false>),
+                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<false, true>),
+                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<true, true>)};
+      for (const void* k : ks)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ld) != hipSuccess) {
+          paradis_set_error("pw_gemm_wgrad(square): cannot reserve LDS");
+          return 2;
+        }
+    }
     if ((io16 & IO_A16) && (io16 & IO_B16)) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, true>), gr, bl, ld, st, g);
     else if (io16 & IO_A16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, false>), gr, bl, ld, st, g);
     else if (io16 & IO_B16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, true>), gr, bl, ld, st, g);
