@@ -409,3 +409,33 @@ def test_gradient_handoff_and_its_fallbacks():
     assert y.dtype == torch.bfloat16
     with pytest.raises(RuntimeError, match="not handed over"):
         y.backward(ops._placeholder_grad16(y))
+
+
+@pytest.mark.parametrize("B,Co,Ci,H,W", [(1, 256, 256, 32, 64), (1, 256, 256, 64, 64), (4, 256, 256, 64, 128), (1, 512, 512, 32, 64),
+                                         (2, 1024, 1024, 32, 64), (1, 896, 1024, 32, 64), (2, 768, 1024, 32, 64), (3, 512, 768, 16, 32),
+                                         (1, 384, 1536, 32, 64), (2, 97, 896, 16, 32), (1, 256, 256, 4, 8), (5, 1024, 384, 8, 16)])
+def test_bf16_mixed_weight_gradient_tiles_and_operand_types(B, Co, Ci, H, W):
+    """The bf16-mixed weight gradient over its three tiles (128 x 128, 256 x 128, 256 x 256 - the last with two k-tiles per
+    barrier for bf16 / bf16 operands) and the four operand-storage combinations, from one to ~90 k-tiles per slab: every
+    entry against an fp64 evaluation of the bf16-rounded operands, the four combinations bit-identical to one another
+    (same values in the same order through the same MFMAs), the bias gradient (row sums of dY) alongside."""
+    from paradis_model_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Co)
+    dz = torch.randn(B, Co, H, W, generator=g).cuda()
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    dzb, xb = dz.to(torch.bfloat16), x.to(torch.bfloat16)
+    ref = torch.einsum("bohw,bchw->oc", dzb.double(), xb.double())
+    rb = dz.double().sum(dim=(0, 2, 3))
+    outs = []
+    for a, b in ((dzb.float(), xb.float()), (dzb, xb.float()), (dzb.float(), xb), (dzb, xb)):
+        gw, gb = ops._pw_gemm_wgrad(a, b, True, None, None, ops.GEMM_BF16)
+        assert bool(torch.isfinite(gw).all())
+        e = float((gw.double() - ref).abs().max() / ref.abs().max())
+        assert e <= 2e-6, (a.dtype, b.dtype, e)
+        outs.append(gw)
+        if a.dtype == torch.float32 and a is not dz:
+            continue
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    gw, gb = ops._pw_gemm_wgrad(dz, xb, True, None, None, ops.GEMM_BF16)          # fp32 dY: the row sums are those of the fp32 values
+    assert float((gb.double() - rb).abs().max() / rb.abs().max().clamp_min(1e-30)) <= 1e-5
