@@ -607,9 +607,7 @@ extern "C" int paradis_gated_blend_bwd(const float* gout, const float* h, const 
   return gated_blend_bwd_impl(gout, h, adv, alpha, gh, gadv, galpha, B, C, P, workspace, stream, 0);
 }
 
-// The same gradients when the advected tensor was never materialised (paradis_pw_gemm_fwd_gated): `out` is the
-// blended output, adv - h = (out - h) / sigmoid, so galpha = (1 - sigmoid) sum gout (out - h) - no division.
-// the same on a bf16-STORED dz (bf16-mixed mode, round 6): eight columns per thread from one 16-byte load per sample
+// bias / bias-map gradients on a bf16-STORED dz (bf16-mixed mode, round 6): eight columns per thread from one 16-byte load per sample
 // (P % 8 == 0, 16-byte aligned rows); fp32 sums in batch order, fp32 outputs
 __global__ void __launch_bounds__(256)
 bias_grads_b16_kernel(const uint16_t* __restrict__ dz, float* __restrict__ gmap, float* __restrict__ gbias,
@@ -651,6 +649,8 @@ bias_grads_b16_kernel(const uint16_t* __restrict__ dz, float* __restrict__ gmap,
   if (threadIdx.x == 0) atomicAdd(&gbias[c], red[0] + red[1] + red[2] + red[3]);
 }
 
+// The same gradients when the advected tensor was never materialised (paradis_pw_gemm_fwd_gated): `out` is the
+// blended output, adv - h = (out - h) / sigmoid, so galpha = (1 - sigmoid) sum gout (out - h) - no division.
 extern "C" int paradis_gated_blend_bwd_out(const float* gout, const float* h, const float* out,
                                            const float* alpha, float* gh, float* gadv, float* galpha, int B,
                                            int C, int P, void* workspace, void* stream) {
