@@ -1429,6 +1429,128 @@ pw_gemm_bf16_k32_kernel(GemmArgs g) {
   }
 }
 
+// The same kernel in 256 x 256 x 64 steps on sixteen waves (round 6; the structure of pw_gemm_b16_quad_kernel below, for an
+// fp32-STORED activation operand): 1024 threads = two copies (msub 0 / 1 = m-tiles 2 mt2, 2 mt2 + 1) of the 8-wave arrangement
+// sharing the ROUNDED activation tiles in LDS.  Per step each thread fetches the sixteen fp32 values it fetched per k32 tile
+// above - copy msub stages the k-rows [32 msub, 32 msub + 32) of the 64 - so the rounding work and the activation bytes from
+// L2 per MFMA halve, and a wave runs SIXTEEN MFMAs between two barriers.  Weight tiles: two k32 image tiles per copy and
+// step by LDS-DMA.  Two stages of 64 KB.  An odd number of k32 image tiles: the last step runs two of its four slices.
+constexpr int Q32_BCH = 4 * 2 * SCH;                      // chunks of one sub's activation image per stage: [4 slices][2 k-halves][128 columns]
+constexpr int Q32_STAGE = 2 * (2 * simg(2)) + 2 * Q32_BCH;  // [copy 0: 2 k32 weight tiles | copy 1 | sub 0 | sub 1]
+constexpr size_t q32_lds_bytes() { return (size_t)2 * Q32_STAGE * 16; }
+template <bool C16, bool ZM16>
+__global__ void __launch_bounds__(1024, 4)
+pw_gemm_bf16_quad32_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ACH = simg(2);                      // 512 chunks: one k32 weight-image tile
+  u32x4* img = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int msub = wave >> 3, w8 = wave & 7, sub = w8 >> 2, lw = w8 & 3, ltid = tid & 255;
+  const int wm = lw >> 1, wn = lw & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int MT = (g.M + BM - 1) / BM, MT2 = (MT + 1) / 2, NT = (g.N + BN - 1) / BN, NT2 = (NT + 1) / 2;
+  int L;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt2 = L % MT2, nt2 = (L / MT2) % NT2, bz = L / (MT2 * NT2);
+  const bool live = 2 * nt2 + sub < NT && 2 * mt2 + msub < MT;       // wave-uniform
+  const int nt = min(2 * nt2 + sub, NT - 1), mt = min(2 * mt2 + msub, MT - 1);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T32 = (g.K + 31) / 32, T = (T32 + 1) / 2;
+
+  const u32x4* Ag = reinterpret_cast<const u32x4*>(g.A) + (int64_t)bz * g.a_bs + (int64_t)mt * T32 * ACH + (tid & 511);
+  const int bh = __builtin_amdgcn_readfirstlane(ltid >> 7);      // k-half staged by this wave
+  const float* Bb;
+  {
+    const uint64_t a = reinterpret_cast<uint64_t>(g.B + (int64_t)bz * g.b_bs);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    Bb = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  }
+  const int bn = min(n0 + (ltid & 127), g.N - 1);
+  const uint32_t flip = split_flip_mask(ltid & 127);
+  float xb[2][8] = {};
+  auto issueA = [&](int t) __attribute__((always_inline)) {
+    u32x4* st = img + (t & 1) * Q32_STAGE + 2 * msub * ACH;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t32 = min(2 * t + h, T32 - 1);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ag + (int64_t)t32 * ACH), (lds_ptr_t)(st + h * ACH + w8 * 64), 16, 0, 0);
+    }
+  };
+  const uint32_t boff = (uint32_t)bn * 4u;
+  auto fetchB = [&](int t, float (&x)[2][8]) __attribute__((always_inline)) {      // this copy's 32 k-rows of step t
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int k0 = t * 64 + msub * 32 + sl * SBK + bh * 8;
+      const float* p = Bb + (int64_t)min(k0, g.K - 1) * g.ldb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        asm volatile("global_load_dword %0, %1, %2" : "=&v"(x[sl][j]) : "v"(boff), "s"(p) : "memory");
+        p += (k0 + j + 1 < g.K) ? g.ldb : 0;
+      }
+    }
+  };
+#define USE_XQ16(x) do { asm volatile("s_waitcnt vmcnt(0)" :: "v"(x[0][0]), "v"(x[0][1]), "v"(x[0][2]), "v"(x[0][3]), \
+                                      "v"(x[0][4]), "v"(x[0][5]), "v"(x[0][6]), "v"(x[0][7]), "v"(x[1][0]), "v"(x[1][1]),     \
+                                      "v"(x[1][2]), "v"(x[1][3]), "v"(x[1][4]), "v"(x[1][5]), "v"(x[1][6]), "v"(x[1][7])      \
+                                      : "memory");                                                                           \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
+  // this thread's chunk in its sub's image of stage 0: slices 2 msub, 2 msub + 1
+  u32x4* const Bst = img + 4 * ACH + sub * Q32_BCH + (2 * msub) * 2 * SCH + bh * SCH + (ltid & 127);
+  auto round_store = [&](const float (&x)[2][8], u32x4* o) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      float xs[8];
+      flip8(xs, x[sl], flip);
+      o[sl * 2 * SCH] = round8(xs);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issueA(0);
+  fetchB(0, xb);
+  USE_XQ16(xb);
+  round_store(xb, Bst);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    const u32x4* As = img + cur * Q32_STAGE + 2 * msub * ACH + lh * SCH + wm * 64 + li;
+    const u32x4* Bs = img + cur * Q32_STAGE + 4 * ACH + sub * Q32_BCH + lh * SCH + wn * 64 + li;
+    const bool more = t + 1 < T;                      // workgroup-uniform
+    if (more) { issueA(t + 1); fetchB(t + 1, xb); }
+    const int nsl = (2 * t + 1 < T32) ? 4 : 2;       // workgroup-uniform
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl < nsl) {
+        const u32x4 a0 = As[sl * 2 * SCH], a1 = As[sl * 2 * SCH + 32], b0 = Bs[sl * 2 * SCH], b1 = Bs[sl * 2 * SCH + 32];
+        SPLIT_MFMA(a0, b0, acc[0][0]); SPLIT_MFMA(a0, b1, acc[0][1]);
+        SPLIT_MFMA(a1, b0, acc[1][0]); SPLIT_MFMA(a1, b1, acc[1][1]);
+      }
+    }
+    if (more) {
+      USE_XQ16(xb);                                   // (this step's DMAs are older than the loads: landed too)
+      round_store(xb, Bst + (cur ^ 1) * Q32_STAGE);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#undef USE_XQ16
+  if (live) {
+    split_unflip(acc, wn);
+    gemm_epilogue<true, C16, ZM16>(g, acc, bz, m0, n0, wm, wn, li, lh);
+  }
+}
+
 // PARADIS_GEMM_BF16 forward / dgrad with the activation operand STORED as bf16 (round 6; GemmArgs::io16 & IO_B16).
 // B is [K rows][N columns] of bf16, n-contiguous (a [C, H W] plane stack as it sits in HBM).  Nothing of it passes through
 // the vector ALU: a 32 x 256 tile (16 KB) goes HBM -> LDS by LDS-DMA, sixteen bytes per lane, and the MFMA's B fragment -
@@ -2540,6 +2662,30 @@ int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
       else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<false, true>), gr, bl, b16_lds_bytes(), st, d);
       else hipLaunchKernelGGL((pw_gemm_b16_kernel<false, false>), gr, bl, b16_lds_bytes(), st, d);
       return 0;
+    }
+    {
+      const int MT = (d.M + BM - 1) / BM;
+      static const bool q32_on = [] { const char* e = getenv("PARADIS_GEMM_K32_QUAD"); return !(e && e[0] == '0'); }();   // (=0: A/B)
+      if (q32_on && MT >= 2 && ((MT + 1) / 2) * 2 * 7 <= MT * 8) {
+        static PerDeviceOnce once_q32;
+        if (once_q32.first()) {
+          const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<false, false>),
+                               reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<true, false>),
+                               reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<false, true>),
+                               reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<true, true>)};
+          for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q32_lds_bytes()) != hipSuccess) {
+              paradis_set_error("pw_gemm(k32 quad): cannot reserve LDS");
+              return 2;
+            }
+        }
+        const dim3 gq(((MT + 1) / 2) * ((NT + 1) / 2) * d.nbatch), bq(1024);
+        if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<true, true>), gq, bq, q32_lds_bytes(), st, d);
+        else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<true, false>), gq, bq, q32_lds_bytes(), st, d);
+        else if (zm16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<false, true>), gq, bq, q32_lds_bytes(), st, d);
+        else hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<false, false>), gq, bq, q32_lds_bytes(), st, d);
+        return 0;
+      }
     }
     if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, true>), dim3(grid), dim3(512), lds, st, d);
     else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, false>), dim3(grid), dim3(512), lds, st, d);
