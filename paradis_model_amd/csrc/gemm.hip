@@ -20,22 +20,16 @@
 #include <cstdlib>
 #include "common.h"
 
-namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128;
-constexpr int ld_of(bool kc) { return kc ? BM + 1 : BM + 4; }  // floats per k-row of the LDS image
-constexpr int stage_floats(int bk) { return bk * (BM + 4); }   // per operand per stage (upper bound)
-constexpr size_t lds_bytes(int bk) { return (size_t)4 * stage_floats(bk) * sizeof(float); }
-constexpr int nv_of(int bk) { return BM * bk / (256 * 4); }    // float4 loads per thread per operand
-
-// Tunables (debug setters below; defaults chosen from tools/gemm_bench.py measurements)
-int g_bk = 16;            // k-tile depth: 16 or 32
-int g_wg_per_cu = 4;      // resident workgroups per CU enforced through the dynamic-LDS request
-int g_stagger = 0;        // see GemmArgs::stagger
-int g_dma_stages = 3;     // LDS-DMA ring depth for row-contiguous operands (0 = never use the DMA kernel)
-int g_wgrad_dma_stages = 2;  // LDS-DMA ring depth of the weight-gradient kernel (0 = register-staged)
+// Three translation units from this one source (the Makefile compiles it three times; -DGEMM_PART unset = all in one):
+//   GEMM_PART == 1: the fp32-width schemes (exact f32 MFMA, bf16x3, f16x2) and every host entry point of the C ABI;
+//   GEMM_PART == 2: the forward / data-gradient kernels of the bf16-mixed scheme (PARADIS_GEMM_BF16), pd_amp_launch_fwd;
+//   GEMM_PART == 3: its weight-gradient kernels, pd_amp_launch_wgrad.
+// All kernels are templates or sit behind the guards, so each unit instantiates only what it launches: a clean build
+// takes the time of the slowest third on three cores instead of five minutes on one (the bf16-mixed kernels come in
+// four I/O-type instantiations each, and each inlines the whole epilogue).
+#ifndef GEMM_PART
+#define GEMM_PART 0
+#endif
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -66,6 +60,31 @@ struct GemmArgs {
   //  conv2d rounds it - the pre-activation and the activated value (fwd), the activation-gradient product (dgrad) -
   //  before the fp32 residual / blend; a compile-time property of pw_gemm_bf16_k32_kernel's epilogue.  Stored as fp32.)
 };
+
+// launchers of the bf16-mixed kernels (defined in units 2 and 3)
+int pd_amp_launch_fwd(const GemmArgs& d, hipStream_t st);
+// kind: 0 = 128 x 128 tile, fp32 operands; 1 = 128 x 128 with a bf16 operand; 2 = 256 x 128; 3 = 256 x 256 (grid: the caller's)
+int pd_amp_launch_wgrad(const GemmArgs& g, int io16, int kind, int grid, hipStream_t st);
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int ld_of(bool kc) { return kc ? BM + 1 : BM + 4; }  // floats per k-row of the LDS image
+constexpr int stage_floats(int bk) { return bk * (BM + 4); }   // per operand per stage (upper bound)
+constexpr size_t lds_bytes(int bk) { return (size_t)4 * stage_floats(bk) * sizeof(float); }
+constexpr int nv_of(int bk) { return BM * bk / (256 * 4); }    // float4 loads per thread per operand
+
+// Tunables (debug setters below; defaults chosen from tools/gemm_bench.py measurements)
+#if GEMM_PART < 2
+int g_bk = 16;            // k-tile depth: 16 or 32
+int g_wg_per_cu = 4;      // resident workgroups per CU enforced through the dynamic-LDS request
+int g_stagger = 0;        // see GemmArgs::stagger
+int g_dma_stages = 3;     // LDS-DMA ring depth for row-contiguous operands (0 = never use the DMA kernel)
+int g_wgrad_dma_stages = 2;  // LDS-DMA ring depth of the weight-gradient kernel (0 = register-staged)
+#endif
+
 
 // ---- staging: 128 x 16 operand slab -> registers -> LDS image [k][m] -------------------------
 // KC: element (row=m|n, k) at base[row*ld + k]   (k contiguous)
@@ -159,7 +178,7 @@ __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; 
 // (An epilogue / k-loop stagger - the second workgroup of every CU of the first round starting late by 64-256 x 512 cycles,
 //  so that one workgroup's store-bound epilogue runs under the other's MFMA-bound k-loop - was measured on the bf16-mixed
 //  and the bf16x3 kernels and lost 0-10 % at every setting: profiles/r06_stagger_sweep.txt.  Not kept.)
-constexpr int IO_B16 = 1, IO_C16 = 2, IO_ZM16 = 4, IO_A16 = 8;     // GemmArgs::io16 (IO_A16: wgrad's dY operand)
+[[maybe_unused]] constexpr int IO_B16 = 1, IO_C16 = 2, IO_ZM16 = 4, IO_A16 = 8;     // GemmArgs::io16 (IO_A16: wgrad's dY operand)
 // bf16 storage: element i of a bf16 array as a float / a bf16-VALUED float (already rounded) into a bf16 array
 __device__ __forceinline__ float ld_bf16(const void* p, int64_t i) {
   return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16);
@@ -787,6 +806,7 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], float s, u32x4& 
 // max |x| over B blocks of `inner` contiguous floats (block stride bs) -> PARADIS_AMAX_PARTIALS words, one
 // per workgroup (bits of a non-negative float order like unsigned integers; a NaN is larger than Inf and
 // so survives).  The consumers take the maximum of the words: no atomics, no zero-fill, deterministic.
+#if GEMM_PART < 2
 __global__ void __launch_bounds__(256)
 amax_partials_kernel(const float* __restrict__ x, int B, int64_t inner, int64_t bs, int vec, uint32_t* __restrict__ out) {
   uint32_t m = 0;
@@ -810,6 +830,7 @@ amax_partials_kernel(const float* __restrict__ x, int B, int64_t inner, int64_t 
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
+#endif
 
 // Image of A[m,k] = W[m*rs + k*cs] (rs/cs select W or W^T), zero padded to [MT*128, KT*16]:
 // out[((mt*KT + kt)*3 + s)*256 + half*128 + row] ; one thread per (mt, kt, half, row).
@@ -848,15 +869,18 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 
 // both images of one row-major W[M,K] in ONE launch (a training step needs W for the forward GEMM and W^T for the
 // data gradient: 78 launches of a few microseconds per step instead of 155): blockIdx.y = 0 -> W, 1 -> W^T
+#if GEMM_PART < 2
 __global__ void __launch_bounds__(256)
 split_weights_pair_kernel(const float* __restrict__ W, int M, int K, int KT, int KTt, int64_t units, int64_t units_t,
                           u32x4* __restrict__ out, u32x4* __restrict__ out_t) {
   if (blockIdx.y == 0) split_weights_body<3>(W, K, 1, M, K, KT, units, out);
   else split_weights_body<3>(W, 1, K, K, M, KTt, units_t, out_t);
 }
+#endif
 
 // f16x2 image: out[((mt*KT + kt)*2 + s)*256 + half*128 + row]; `tail` = the words behind the image:
 // [0] = bits of max |W| (written here, read by the GEMMs), [4 ..) = the amax partials of W (input)
+#if GEMM_PART < 2
 __global__ void __launch_bounds__(256)
 split_weights_f16_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M, int K, int KT, int64_t units,
                          u32x4* __restrict__ out, uint32_t* __restrict__ tail) {
@@ -881,6 +905,7 @@ split_weights_f16_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, in
     o[0] = h; o[2 * SCH] = l;
   }
 }
+#endif
 
 #define SPLIT_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 // The six partial products of one 32x32 block, smallest first.  (An order in which consecutive MFMAs
@@ -2416,6 +2441,7 @@ pw_gemm_wgrad_square_kernel(GemmArgs g) {
 
 // out[i] = slabs[0][i] + slabs[1][i] + ... in that order; vec: n % 4 == 0 and 16-byte aligned pointers (four
 // elements per thread, four slabs' loads in flight)
+#if GEMM_PART < 2
 __global__ void __launch_bounds__(256)
 slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int S, int vec,
                    const float* __restrict__ slabs2, float* __restrict__ out2, int n2, int blocks1) {
@@ -2458,7 +2484,9 @@ slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int
     out[i] = s;
   }
 }
+#endif
 
+#if GEMM_PART < 2
 int slots() { return 256 * g_wg_per_cu; }
 
 // both operands p-contiguous with whole, 16-B aligned 16-float chunks (LDS-DMA and split kernels)
@@ -2614,85 +2642,7 @@ int launch_split_wide(const GemmArgs& d, int NT, hipStream_t st) {
 }
 int launch_split(const GemmArgs& d, int scheme, hipStream_t st) {
   const int NT = (d.N + BN - 1) / BN;
-  if (scheme == PARADIS_GEMM_BF16) {
-    // (round 5: the k16 kernels with one plane ran the bf16-mixed step at 91.6 ms; a 256 x 128 tile - two M-tiles
-    //  sharing one fp32 activation tile, 16 instead of 20 KB through L2 per tile pair - at 95.9 ms: with four MFMAs per
-    //  wave and barrier the kernel is bound by its per-tile latency chain, not by bytes.  Hence 32-deep tiles.)
-    const size_t lds = (size_t)(2 * 2 + 2) * simg(BK32_SL) * 16;
-    const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;
-    const bool c16 = (d.io16 & IO_C16) != 0, zm16 = (d.io16 & IO_ZM16) != 0 && d.zmul != nullptr;
-    if (d.io16 & IO_B16) {     // activations stored as bf16: LDS-DMA + transposed reads (layout checked by the caller)
-      static PerDeviceOnce once;
-      if (once.first()) {
-        const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_b16_kernel<false, false>),
-                             reinterpret_cast<const void*>(&pw_gemm_b16_kernel<true, false>),
-                             reinterpret_cast<const void*>(&pw_gemm_b16_kernel<false, true>),
-                             reinterpret_cast<const void*>(&pw_gemm_b16_kernel<true, true>)};
-        for (const void* k : ks)
-          if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds_bytes()) != hipSuccess) {
-            paradis_set_error("pw_gemm(b16): cannot reserve LDS");
-            return 2;
-          }
-      }
-      const int MT = (d.M + BM - 1) / BM;
-      static const bool quad_on = [] { const char* e = getenv("PARADIS_GEMM_B16_QUAD"); return !(e && e[0] == '0'); }();   // (=0: A/B)
-      if (quad_on && MT >= 2 && ((MT + 1) / 2) * 2 * 7 <= MT * 8) {       // (an odd MT repeats its last m-tile: at most 1/8)
-        static PerDeviceOnce once_q;
-        if (once_q.first()) {
-          const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<false, false>),
-                               reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<true, false>),
-                               reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<false, true>),
-                               reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<true, true>)};
-          for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16q_lds_bytes()) != hipSuccess) {
-              paradis_set_error("pw_gemm(b16 quad): cannot reserve LDS");
-              return 2;
-            }
-        }
-        const dim3 gq(((MT + 1) / 2) * ((NT + 1) / 2) * d.nbatch), bq(1024);
-        if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<true, true>), gq, bq, b16q_lds_bytes(), st, d);
-        else if (c16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<true, false>), gq, bq, b16q_lds_bytes(), st, d);
-        else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<false, true>), gq, bq, b16q_lds_bytes(), st, d);
-        else hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<false, false>), gq, bq, b16q_lds_bytes(), st, d);
-        return 0;
-      }
-      const dim3 gr(grid), bl(512);
-      if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, true>), gr, bl, b16_lds_bytes(), st, d);
-      else if (c16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, false>), gr, bl, b16_lds_bytes(), st, d);
-      else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<false, true>), gr, bl, b16_lds_bytes(), st, d);
-      else hipLaunchKernelGGL((pw_gemm_b16_kernel<false, false>), gr, bl, b16_lds_bytes(), st, d);
-      return 0;
-    }
-    {
-      const int MT = (d.M + BM - 1) / BM;
-      static const bool q32_on = [] { const char* e = getenv("PARADIS_GEMM_K32_QUAD"); return !(e && e[0] == '0'); }();   // (=0: A/B)
-      if (q32_on && MT >= 2 && ((MT + 1) / 2) * 2 * 7 <= MT * 8) {
-        static PerDeviceOnce once_q32;
-        if (once_q32.first()) {
-          const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<false, false>),
-                               reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<true, false>),
-                               reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<false, true>),
-                               reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<true, true>)};
-          for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q32_lds_bytes()) != hipSuccess) {
-              paradis_set_error("pw_gemm(k32 quad): cannot reserve LDS");
-              return 2;
-            }
-        }
-        const dim3 gq(((MT + 1) / 2) * ((NT + 1) / 2) * d.nbatch), bq(1024);
-        if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<true, true>), gq, bq, q32_lds_bytes(), st, d);
-        else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<true, false>), gq, bq, q32_lds_bytes(), st, d);
-        else if (zm16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<false, true>), gq, bq, q32_lds_bytes(), st, d);
-        else hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<false, false>), gq, bq, q32_lds_bytes(), st, d);
-        return 0;
-      }
-    }
-    if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, true>), dim3(grid), dim3(512), lds, st, d);
-    else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, false>), dim3(grid), dim3(512), lds, st, d);
-    else if (zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<false, true>), dim3(grid), dim3(512), lds, st, d);
-    else hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<false, false>), dim3(grid), dim3(512), lds, st, d);
-    return 0;
-  }
+  if (scheme == PARADIS_GEMM_BF16) return pd_amp_launch_fwd(d, st);      // (the other translation unit)
   if (scheme != PARADIS_GEMM_F16X2) {
 #if SPLIT_WIDE_BF16X3
     if (NT >= 2) return launch_split_wide<3>(d, NT, st);
@@ -2710,8 +2660,139 @@ int check_gemm(const char* name, int B, int M, int K, int N) {
   return 0;
 }
 
+#endif   // GEMM_PART < 2
 }  // namespace
 
+// ---- launchers of the bf16-mixed kernels (called from the first translation unit) ---------------------------------------
+#if GEMM_PART == 0 || GEMM_PART == 2
+int pd_amp_launch_fwd(const GemmArgs& d, hipStream_t st) {
+  const int NT = (d.N + BN - 1) / BN;
+  // (round 5: the k16 kernels with one plane ran the bf16-mixed step at 91.6 ms; a 256 x 128 tile - two M-tiles
+  //  sharing one fp32 activation tile, 16 instead of 20 KB through L2 per tile pair - at 95.9 ms: with four MFMAs per
+  //  wave and barrier the kernel is bound by its per-tile latency chain, not by bytes.  Hence 32-deep tiles.)
+  const size_t lds = (size_t)(2 * 2 + 2) * simg(BK32_SL) * 16;
+  const int grid = ((d.M + BM - 1) / BM) * ((NT + 1) / 2) * d.nbatch;
+  const bool c16 = (d.io16 & IO_C16) != 0, zm16 = (d.io16 & IO_ZM16) != 0 && d.zmul != nullptr;
+  if (d.io16 & IO_B16) {     // activations stored as bf16: LDS-DMA + transposed reads (layout checked by the caller)
+    static PerDeviceOnce once;
+    if (once.first()) {
+      const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_b16_kernel<false, false>),
+                           reinterpret_cast<const void*>(&pw_gemm_b16_kernel<true, false>),
+                           reinterpret_cast<const void*>(&pw_gemm_b16_kernel<false, true>),
+                           reinterpret_cast<const void*>(&pw_gemm_b16_kernel<true, true>)};
+      for (const void* k : ks)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds_bytes()) != hipSuccess) {
+          paradis_set_error("pw_gemm(b16): cannot reserve LDS");
+          return 2;
+        }
+    }
+    const int MT = (d.M + BM - 1) / BM;
+    static const bool quad_on = [] { const char* e = getenv("PARADIS_GEMM_B16_QUAD"); return !(e && e[0] == '0'); }();   // (=0: A/B)
+    if (quad_on && MT >= 2 && ((MT + 1) / 2) * 2 * 7 <= MT * 8) {       // (an odd MT repeats its last m-tile: at most 1/8)
+      static PerDeviceOnce once_q;
+      if (once_q.first()) {
+        const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<false, false>),
+                             reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<true, false>),
+                             reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<false, true>),
+                             reinterpret_cast<const void*>(&pw_gemm_b16_quad_kernel<true, true>)};
+        for (const void* k : ks)
+          if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16q_lds_bytes()) != hipSuccess) {
+            paradis_set_error("pw_gemm(b16 quad): cannot reserve LDS");
+            return 2;
+          }
+      }
+      const dim3 gq(((MT + 1) / 2) * ((NT + 1) / 2) * d.nbatch), bq(1024);
+      if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<true, true>), gq, bq, b16q_lds_bytes(), st, d);
+      else if (c16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<true, false>), gq, bq, b16q_lds_bytes(), st, d);
+      else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<false, true>), gq, bq, b16q_lds_bytes(), st, d);
+      else hipLaunchKernelGGL((pw_gemm_b16_quad_kernel<false, false>), gq, bq, b16q_lds_bytes(), st, d);
+      return 0;
+    }
+    const dim3 gr(grid), bl(512);
+    if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, true>), gr, bl, b16_lds_bytes(), st, d);
+    else if (c16) hipLaunchKernelGGL((pw_gemm_b16_kernel<true, false>), gr, bl, b16_lds_bytes(), st, d);
+    else if (zm16) hipLaunchKernelGGL((pw_gemm_b16_kernel<false, true>), gr, bl, b16_lds_bytes(), st, d);
+    else hipLaunchKernelGGL((pw_gemm_b16_kernel<false, false>), gr, bl, b16_lds_bytes(), st, d);
+    return 0;
+  }
+  {
+    const int MT = (d.M + BM - 1) / BM;
+    static const bool q32_on = [] { const char* e = getenv("PARADIS_GEMM_K32_QUAD"); return !(e && e[0] == '0'); }();   // (=0: A/B)
+    if (q32_on && MT >= 2 && ((MT + 1) / 2) * 2 * 7 <= MT * 8) {
+      static PerDeviceOnce once_q32;
+      if (once_q32.first()) {
+        const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<false, false>),
+                             reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<true, false>),
+                             reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<false, true>),
+                             reinterpret_cast<const void*>(&pw_gemm_bf16_quad32_kernel<true, true>)};
+        for (const void* k : ks)
+          if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q32_lds_bytes()) != hipSuccess) {
+            paradis_set_error("pw_gemm(k32 quad): cannot reserve LDS");
+            return 2;
+          }
+      }
+      const dim3 gq(((MT + 1) / 2) * ((NT + 1) / 2) * d.nbatch), bq(1024);
+      if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<true, true>), gq, bq, q32_lds_bytes(), st, d);
+      else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<true, false>), gq, bq, q32_lds_bytes(), st, d);
+      else if (zm16) hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<false, true>), gq, bq, q32_lds_bytes(), st, d);
+      else hipLaunchKernelGGL((pw_gemm_bf16_quad32_kernel<false, false>), gq, bq, q32_lds_bytes(), st, d);
+      return 0;
+    }
+  }
+  if (c16 && zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, true>), dim3(grid), dim3(512), lds, st, d);
+  else if (c16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<true, false>), dim3(grid), dim3(512), lds, st, d);
+  else if (zm16) hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<false, true>), dim3(grid), dim3(512), lds, st, d);
+  else hipLaunchKernelGGL((pw_gemm_bf16_k32_kernel<false, false>), dim3(grid), dim3(512), lds, st, d);
+  return 0;
+}
+#endif
+
+#if GEMM_PART == 0 || GEMM_PART == 3
+int pd_amp_launch_wgrad(const GemmArgs& g0, int io16, int kind, int grid, hipStream_t st) {
+  GemmArgs g = g0;
+  g.io16 = io16;
+  constexpr size_t lds128 = (size_t)2 * 2 * simgp(1) * 16;
+  if (kind == 3) {
+    const dim3 gr(grid), bl(512);
+    const size_t ld = sq_lds_bytes();
+    static PerDeviceOnce once_sq;
+    if (once_sq.first()) {
+      const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<false, false>),
+                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<true, false>),
+                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<false, true>),
+                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<true, true>)};
+      for (const void* k : ks)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ld) != hipSuccess) {
+          paradis_set_error("pw_gemm_wgrad(square): cannot reserve LDS");
+          return 2;
+        }
+    }
+    if ((io16 & IO_A16) && (io16 & IO_B16)) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, true>), gr, bl, ld, st, g);
+    else if (io16 & IO_A16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, false>), gr, bl, ld, st, g);
+    else if (io16 & IO_B16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, true>), gr, bl, ld, st, g);
+    else hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, false>), gr, bl, ld, st, g);
+  } else if (kind == 2) {
+    const dim3 gr(grid), bl(512);
+    const size_t ld = tall_lds_bytes();
+    if ((io16 & IO_A16) && (io16 & IO_B16)) hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<true, true>), gr, bl, ld, st, g);
+    else if (io16 & IO_A16) hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<true, false>), gr, bl, ld, st, g);
+    else if (io16 & IO_B16) hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<false, true>), gr, bl, ld, st, g);
+    else hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<false, false>), gr, bl, ld, st, g);
+  } else if (kind == 1) {
+    if ((io16 & IO_A16) && (io16 & IO_B16))
+      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<true, true>), dim3(grid), dim3(256), lds128, st, g);
+    else if (io16 & IO_A16)
+      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<true, false>), dim3(grid), dim3(256), lds128, st, g);
+    else
+      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<false, true>), dim3(grid), dim3(256), lds128, st, g);
+  } else {
+    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<1>, dim3(grid), dim3(256), lds128, st, g);
+  }
+  return 0;
+}
+#endif
+
+#if GEMM_PART < 2
 #ifdef PARADIS_DEV_KNOBS
 // diagnostic knobs of the development build only (`make dev`, tools/gemm_bench.py); the shipped
 // library exports none of them.  bk in {16,32}, wg_per_cu in 1..4
@@ -3053,47 +3134,14 @@ static int pw_gemm_wgrad_impl(const float* dY, const float* X, float* dW, float*
   g.stagger = g_stagger;
   g.rowsum = (gbias && dma) ? rowsum_ws : nullptr;
   const int grid = (tall ? (M + 255) / 256 : (M + BM - 1) / BM) * ((K + BN - 1) / BN) * S;
-  if (square) {
-    g.io16 = io16;
-    const dim3 gr(((M + 255) / 256) * ((K + 255) / 256) * S), bl(512);
-    const size_t ld = sq_lds_bytes();
-    static PerDeviceOnce once_sq;
-    if (once_sq.first()) {
-      const void* ks[4] = {reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<false, false>),
-                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<true, false>),
-                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<false, true>),
-                           reinterpret_cast<const void*>(&pw_gemm_wgrad_square_kernel<true, true>)};
-      for (const void* k : ks)
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ld) != hipSuccess) {
-          paradis_set_error("pw_gemm_wgrad(square): cannot reserve LDS");
-          return 2;
-        }
-    }
-    if ((io16 & IO_A16) && (io16 & IO_B16)) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, true>), gr, bl, ld, st, g);
-    else if (io16 & IO_A16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<true, false>), gr, bl, ld, st, g);
-    else if (io16 & IO_B16) hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, true>), gr, bl, ld, st, g);
-    else hipLaunchKernelGGL((pw_gemm_wgrad_square_kernel<false, false>), gr, bl, ld, st, g);
-  } else if (tall) {
-    g.io16 = io16;
-    const dim3 gr(grid), bl(512);
-    const size_t ld = tall_lds_bytes();
-    if ((io16 & IO_A16) && (io16 & IO_B16)) hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<true, true>), gr, bl, ld, st, g);
-    else if (io16 & IO_A16) hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<true, false>), gr, bl, ld, st, g);
-    else if (io16 & IO_B16) hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<false, true>), gr, bl, ld, st, g);
-    else hipLaunchKernelGGL((pw_gemm_wgrad_tall_kernel<false, false>), gr, bl, ld, st, g);
+  if (square || tall) {
+    const int g2 = square ? ((M + 255) / 256) * ((K + 255) / 256) * S : grid;
+    if (int e = pd_amp_launch_wgrad(g, io16, square ? 3 : 2, g2, st)) return e;
   } else if (use_split && scheme == PARADIS_GEMM_F16X2) {
     g.a_amax = dy_amax; g.b_amax = x_amax;
     hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<2>, dim3(grid), dim3(256), split_lds_wgrad(2), st, g);
-  } else if (use_split && scheme == PARADIS_GEMM_BF16 && io16) {
-    g.io16 = io16;
-    if ((io16 & IO_A16) && (io16 & IO_B16))
-      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<true, true>), dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
-    else if (io16 & IO_A16)
-      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<true, false>), dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
-    else
-      hipLaunchKernelGGL((pw_gemm_wgrad_b16_kernel<false, true>), dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
   } else if (use_split && scheme == PARADIS_GEMM_BF16) {
-    hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<1>, dim3(grid), dim3(256), split_lds_wgrad(1), st, g);
+    if (int e = pd_amp_launch_wgrad(g, io16, io16 ? 1 : 0, grid, st)) return e;
   } else if (use_split) {
     hipLaunchKernelGGL(pw_gemm_wgrad_split_kernel<3>, dim3(grid), dim3(256), split_lds_wgrad(3), st, g);
   } else if (dma) {
@@ -3131,3 +3179,4 @@ extern "C" int paradis_pw_gemm_wgrad16(const void* dY, const void* X, float* dW,
   return pw_gemm_wgrad_impl((const float*)dY, (const float*)X, dW, gbias, B, M, K, N, dy_bs, x_bs, PARADIS_GEMM_BF16,
                             nullptr, nullptr, workspace, stream, io16);
 }
+#endif   // GEMM_PART < 2

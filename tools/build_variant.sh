@@ -11,6 +11,7 @@ EXTRA="-fno-slp-vectorize"
 [ $BASE = advect ] && EXTRA="$EXTRA -ffp-contract=off"
 [ $BASE = feed ] && EXTRA="$EXTRA -ffp-contract=off"
 OBJS=$(ls $R/build/obj/*.o | grep -v "/$BASE.o")
+[ $BASE = gemm ] && OBJS=$(echo "$OBJS" | grep -v "/gemm_amp_")     # (gemm.hip without -DGEMM_PART holds both halves)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -munsafe-fp-atomics $EXTRA $FLAGS \
     -c $R/paradis_model_amd/csrc/$BASE.hip -o $OUT/${BASE}_$NAME.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$NAME.so $OBJS $OUT/${BASE}_$NAME.o
