@@ -69,6 +69,10 @@ SIGNATURES = {
     "paradis_bias_grads16": (I, [P, P, P, I, I, I, L, P]),
     "paradis_channel_norm_fwd16": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
     "paradis_dwconv_geo_fwd16": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "paradis_channel_norm_bwd16_ok": (I, [I, I, I]),
+    "paradis_channel_norm_bwd16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P]),
+    "paradis_dwconv_geo_bwd16_ok": (I, [I, I, I]),
+    "paradis_dwconv_geo_bwd16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_channel_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, L, L, F, P]),
     "paradis_channel_norm_bwd_ws_bytes": (S, [I, I, I]),
     "paradis_channel_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, P, L, P, P]),

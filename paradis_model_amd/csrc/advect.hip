@@ -2015,6 +2015,43 @@ sl_advect_fwd_strip_fixup(const float* __restrict__ field, const float* __restri
     O[q[i]] = gather_global<MODE>(F, qx[i], qy[i], H, W, p, m0, m1);
 }
 
+// Diagnostic (round 6, verdict r5 item 5; PARADIS_ADVECT_DIRECT=1): the forward gather with NO LDS window - every tap a
+// global load served by L2.  All workgroups of a plane run on ONE XCD (blockIdx % 8 = XCD; a 721 x 1440 plane is 4.15 MB,
+// that XCD's L2 holds the band of rows in flight), a wave takes 64 points of one latitude row (scalar sa / ca as in the
+// strips), a workgroup DROWS consecutive rows so that its waves share tap rows through the CU's L1.  Same departure
+// point and tap arithmetic as the strips' deferred points (gather_global).  A/B: profiles/r06_advect_direct.txt.
+template <int MODE, int DROWS>
+__global__ void __launch_bounds__(64 * DROWS)
+sl_advect_fwd_direct(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
+                     float* __restrict__ out, const float* __restrict__ sin_lat, const float* __restrict__ cos_lat,
+                     const float* __restrict__ lat_cells, const float* __restrict__ lon, const float* __restrict__ fmeans,
+                     int K, AdvGeom g, int64_t f_bs, int64_t uv_bs, int64_t o_bs, int planes, int rgroups, int cblocks) {
+  const int H = g.H, W = g.W, p = g.p, P = H * W;
+  const int per_plane = rgroups * cblocks;
+  const unsigned j = blockIdx.x >> 3;
+  const int plane = (int)(j / per_plane) * 8 + (int)(blockIdx.x & 7);
+  if (plane >= planes) return;
+  const int t = (int)(j % per_plane), rg = t / cblocks, cb = t - rg * cblocks;
+  const unsigned lane = threadIdx.x & 63;
+  const int y = rg * DROWS + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (y >= H) return;
+  const int b = plane / K, k = plane - b * K;
+  const float* F = field + (int64_t)b * f_bs + (int64_t)k * P;
+  const float* U = u + (int64_t)b * uv_bs + (int64_t)k * P;
+  const float* V = v + (int64_t)b * uv_bs + (int64_t)k * P;
+  float* O = out + (int64_t)b * o_bs + (int64_t)k * P;
+  const int x = cb * 64 + (int)lane;
+  const bool active = x < W;
+  const unsigned xc = (unsigned)min(x, W - 1);
+  const float cu = srow(U + y * W)[xc], cv = srow(V + y * W)[xc];
+  const float lonc = lon_cells(srow(lon)[xc], g);
+  const float sa = sin_lat[y * W], ca = cos_lat[y * W];
+  float ix, iy;
+  departure_row(cu, cv, sa, ca, lonc, lat_cells[y * W], g, ix, iy, nullptr);
+  const float r = gather_global<MODE>(F, ix, iy, H, W, p, fmeans[2 * plane], fmeans[2 * plane + 1]);
+  if (active) srow(O + y * W)[xc] = r;
+}
+
 // field gradient and coordinate gradients of a point whose tap block leaves the window: global atomics on the field
 // gradient (float, or the integer plane of the deterministic mode), taps from global memory, one tap row at a time
 template <int MODE, bool DET>
@@ -2825,7 +2862,18 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
         reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
       return 2;
   }
-  if (separable(flags, lat_cells) && strip_ok(W, flags)) {
+  static const int direct = [] { const char* e = getenv("PARADIS_ADVECT_DIRECT"); return e ? atoi(e) : 0; }();   // (A/B: 4 or 8 rows per workgroup)
+  if (direct > 0 && separable(flags, lat_cells)) {
+    const int drows = direct >= 8 ? 8 : 4, rgroups = (H + drows - 1) / drows, cblocks = (W + 63) / 64;
+    const int64_t nwg = (int64_t)((planes + 7) / 8) * 8 * rgroups * cblocks;
+    PD_REQUIRE(nwg < (1ll << 31), "sl_advect_fwd(direct): too many workgroups");
+#define LAUNCH_DIRECT(M, D)                                                                                            \
+    hipLaunchKernelGGL((sl_advect_fwd_direct<M, D>), dim3((unsigned)nwg), dim3(64 * D), 0, st, field, u, v, out, sin_lat,  \
+                       cos_lat, lat_cells, lon, (const float*)fmeans, K, g, f_bs, uv_bs, o_bs, planes, rgroups, cblocks)
+    if (mode == PARADIS_INTERP_BICUBIC) { if (drows == 8) LAUNCH_DIRECT(PARADIS_INTERP_BICUBIC, 8); else LAUNCH_DIRECT(PARADIS_INTERP_BICUBIC, 4); }
+    else { if (drows == 8) LAUNCH_DIRECT(PARADIS_INTERP_BILINEAR, 8); else LAUNCH_DIRECT(PARADIS_INTERP_BILINEAR, 4); }
+#undef LAUNCH_DIRECT
+  } else if (separable(flags, lat_cells) && strip_ok(W, flags)) {
     // strip schedule: ring of R padded rows, longitude halo hx (flags: PARADIS_ADVECT_HALO)
     const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_fwd(W), false);
     const int strips = (W + STRIP_W - 1) / STRIP_W;

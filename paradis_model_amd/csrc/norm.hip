@@ -29,6 +29,7 @@ struct CatSrc {
 // the value that GEMM would round its operand to anyway (the reference casts the norm's output to bf16 at the conv2d,
 // model/blocks.py:86 under train.py:56), in half the bytes.
 __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float bf16_widen(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 
 template <int MAXV, int NPXF, bool Y16 = false>
 __global__ void __launch_bounds__(1024)
@@ -479,7 +480,10 @@ channel_norm_bwd_reread_kernel(const float* __restrict__ gy, CatSrc s, const flo
 //   apply : gx = rstd (gy w - m1 - xhat m2) (+ addend), one workgroup per (sample, channel) row, 16-byte accesses,
 //           and - the row being one channel - the parameter-gradient sums of that row fall out of the same pass.
 // Same HBM bytes as the reread kernel (gy and x twice), all of them at streaming efficiency; deterministic.
+// GY16 (round 6, bf16-mixed mode): the cotangent is a bf16 tensor - the data gradient of the pointwise GEMM that consumed a
+// bf16-stored y, bf16-valued in the reference's autocast backward as well (the gradient of conv2d's bf16 input).
 constexpr int NSTAT_PX = 64, NSTAT_G = 4, NSTAT_U = 8;
+template <bool GY16>
 __global__ void __launch_bounds__(NSTAT_PX * NSTAT_G)
 channel_norm_bwd_stats_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -492,13 +496,14 @@ channel_norm_bwd_stats_kernel(const float* __restrict__ gy, CatSrc s, const floa
   const int p = min(p0 + lane, P - 1);          // clamped loads, predicated store
   const float mean = mean_in[(int64_t)b * P + p], rstd = rstd_in[(int64_t)b * P + p];
   const float* gyb = gy + (int64_t)b * C * P + p;
+  [[maybe_unused]] const uint16_t* gyb16 = reinterpret_cast<const uint16_t*>(gy) + (int64_t)b * C * P + p;
   float s1 = 0.f, s2 = 0.f;
   for (int c0 = grp; c0 < C; c0 += NSTAT_G * NSTAT_U) {
     float gv[NSTAT_U], xv[NSTAT_U], wv[NSTAT_U];
 #pragma unroll
     for (int j = 0; j < NSTAT_U; ++j) {
       const int c = min(c0 + NSTAT_G * j, C - 1);            // wave-uniform
-      gv[j] = gyb[(int64_t)c * P];
+      if constexpr (GY16) gv[j] = bf16_widen(gyb16[(int64_t)c * P]); else gv[j] = gyb[(int64_t)c * P];
       xv[j] = s.row(b, c, P)[p];
       wv[j] = c0 + NSTAT_G * j < C ? w[c] : 0.f;
     }
@@ -521,7 +526,7 @@ channel_norm_bwd_stats_kernel(const float* __restrict__ gy, CatSrc s, const floa
 
 // one workgroup per (b, c, chunk of `span` pixels); partial[(b * chunks + chunk)][2][C] = this chunk's sums of
 // gy xhat and of gy for channel c (reduced by channel_norm_bwd_fused_finish / finish2 in a fixed order)
-template <bool VEC>
+template <bool VEC, bool GY16 = false>
 __global__ void __launch_bounds__(256)
 channel_norm_bwd_apply_kernel(const float* __restrict__ gy, CatSrc s, const float* __restrict__ w,
                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -535,6 +540,7 @@ channel_norm_bwd_apply_kernel(const float* __restrict__ gy, CatSrc s, const floa
   const int c = row % C, b = row / C;
   const int q0 = chunk * span, q1 = min(q0 + span, P);
   const float* g = gy + ((int64_t)b * C + c) * P;
+  [[maybe_unused]] const uint16_t* g16 = reinterpret_cast<const uint16_t*>(gy) + ((int64_t)b * C + c) * P;
   const float* x = s.row(b, c, P);
   const bool first = c < s.C1;
   float* out = first ? gx1 + (int64_t)b * gbs1 + (int64_t)c * P
@@ -548,7 +554,14 @@ channel_norm_bwd_apply_kernel(const float* __restrict__ gy, CatSrc s, const floa
   float a = 0.f, d = 0.f;
   if (VEC) {
     for (int q = q0 + 4 * (int)threadIdx.x; q < q1; q += 4 * 256) {
-      const float4 gv = *reinterpret_cast<const float4*>(g + q), xv = *reinterpret_cast<const float4*>(x + q);
+      float4 gv;
+      if constexpr (GY16) {
+        const uint2 r = *reinterpret_cast<const uint2*>(g16 + q);
+        gv = make_float4(bf16_widen(r.x & 0xffffu), bf16_widen(r.x >> 16), bf16_widen(r.y & 0xffffu), bf16_widen(r.y >> 16));
+      } else {
+        gv = *reinterpret_cast<const float4*>(g + q);
+      }
+      const float4 xv = *reinterpret_cast<const float4*>(x + q);
       const float4 mu = *reinterpret_cast<const float4*>(mean + q), rs = *reinterpret_cast<const float4*>(rstd + q);
       const float4 a1 = *reinterpret_cast<const float4*>(m1 + q), a2 = *reinterpret_cast<const float4*>(m2 + q);
       float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -568,7 +581,7 @@ channel_norm_bwd_apply_kernel(const float* __restrict__ gy, CatSrc s, const floa
     }
   } else {
     for (int q = q0 + (int)threadIdx.x; q < q1; q += 256) {
-      const float gv = g[q], xh = (x[q] - mean[q]) * rstd[q];
+      const float gv = GY16 ? bf16_widen(g16[q]) : g[q], xh = (x[q] - mean[q]) * rstd[q];
       a += gv * xh;
       d += gv;
       if (out) out[q] = rstd[q] * (gv * wc - m1[q] - xh * m2[q]) + (ad ? ad[q] : 0.f);
@@ -695,6 +708,9 @@ constexpr int APPLY_SPAN = 8192;
 #ifndef NORM_BWD_STREAMING    // (A/B builds: 0 = the fused reread kernel of round 2)
 #define NORM_BWD_STREAMING 1
 #endif
+#ifndef NORM_BWD_CHUNK_MB
+#define NORM_BWD_CHUNK_MB 0
+#endif
 
 extern "C" size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P) {
   const size_t b = (size_t)std::max(B, 1);
@@ -706,12 +722,19 @@ extern "C" size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P) {
   return std::max({three_kernel, fused, streaming}) + 256;
 }
 
-extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2,
-                                        const float* w, const float* mean, const float* rstd,
-                                        float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
-                                        int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
-                                        int64_t gx2_bs, const float* addend1, int64_t add1_bs,
-                                        void* workspace, void* stream) {
+// shapes whose backward runs as the two streaming kernels (the only ones with a bf16-cotangent instantiation)
+static bool norm_bwd_streaming(int B, int C, int P) {
+  const int apply_chunks = (P + APPLY_SPAN - 1) / APPLY_SPAN;
+  return NORM_BWD_STREAMING && (int64_t)B * C * apply_chunks < (1ll << 31) && (int64_t)B * ((P + 63) / 64) < (1ll << 31);
+}
+
+template <bool GY16>
+static int channel_norm_bwd_impl(const float* gy, const float* x1, const float* x2,
+                                 const float* w, const float* mean, const float* rstd,
+                                 float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
+                                 int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
+                                 int64_t gx2_bs, const float* addend1, int64_t add1_bs,
+                                 void* workspace, void* stream) {
   if (int e = check_norm("channel_norm_bwd", B, C1, C2, P)) return e;
   PD_REQUIRE(workspace != nullptr, "channel_norm_bwd: workspace required");
   const int C = C1 + C2;
@@ -727,26 +750,46 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
   CatSrc s{x1, x2, C1, C2, x1_bs, x2_bs};
   int nblk = 0;
   const int apply_chunks = (P + APPLY_SPAN - 1) / APPLY_SPAN;
-  if (NORM_BWD_STREAMING && (int64_t)B * C * apply_chunks < (1ll << 31) && (int64_t)B * ((P + 63) / 64) < (1ll << 31)) {
+  if (norm_bwd_streaming(B, C, P)) {
     float* m1 = (float*)workspace;
     float* m2 = m1 + (size_t)B * P;
     float* partial = m2 + (size_t)B * P;
     const int tiles = (P + NSTAT_PX - 1) / NSTAT_PX;
-    hipLaunchKernelGGL(channel_norm_bwd_stats_kernel, dim3((unsigned)((int64_t)B * tiles)), dim3(NSTAT_PX * NSTAT_G), 0,
-                       st, gy, s, w, mean, rstd, m1, m2, P, tiles);
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = P % 4 == 0 && x1_bs % 4 == 0 && (C2 == 0 || (x2_bs % 4 == 0 && a16(x2))) && gx1_bs % 4 == 0 &&
                      (gx2 == nullptr || (gx2_bs % 4 == 0 && a16(gx2))) && (addend1 == nullptr || (add1_bs % 4 == 0 && a16(addend1))) &&
                      a16(gy) && a16(x1) && a16(gx1) && a16(mean) && a16(rstd) && a16(workspace) && ((size_t)B * P) % 4 == 0;
-    const unsigned grid = (unsigned)((int64_t)B * C * apply_chunks);
-    if (vec)
-      hipLaunchKernelGGL(channel_norm_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, st, gy, s, w, mean, rstd,
-                         (const float*)m1, (const float*)m2, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P,
-                         APPLY_SPAN, apply_chunks);
-    else
-      hipLaunchKernelGGL(channel_norm_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, gy, s, w, mean, rstd,
-                         (const float*)m1, (const float*)m2, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P,
-                         APPLY_SPAN, apply_chunks);
+    // The two passes run over `bc` samples at a time, stats then apply, so that the apply pass finds the gy / x it
+    // re-reads in the 256 MB memory-side cache instead of in HBM (every index in both kernels is per sample: a chunk
+    // is the same launch on offset pointers, and the sums keep their order).  PARADIS_NORM_BWD_CHUNK_MB = read set of
+    // one chunk in MB (0 = one chunk).
+    static const int chunk_mb = [] { const char* e = getenv("PARADIS_NORM_BWD_CHUNK_MB"); return e ? atoi(e) : NORM_BWD_CHUNK_MB; }();
+    const int64_t per_sample = (int64_t)2 * C * P * sizeof(float);
+    int bc = B;
+    if (chunk_mb > 0 && vec) bc = (int)std::min<int64_t>(B, std::max<int64_t>(1, ((int64_t)chunk_mb << 20) / per_sample));
+    for (int b0 = 0; b0 < B; b0 += bc) {
+      const int nb = std::min(bc, B - b0);
+      CatSrc sc{x1 + (int64_t)b0 * x1_bs, x2 ? x2 + (int64_t)b0 * x2_bs : nullptr, C1, C2, x1_bs, x2_bs};
+      const float* gyc = GY16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(gy) + (int64_t)b0 * C * P)
+                              : gy + (int64_t)b0 * C * P;
+      const float *mc = mean + (int64_t)b0 * P, *rc = rstd + (int64_t)b0 * P;
+      float *m1c = m1 + (int64_t)b0 * P, *m2c = m2 + (int64_t)b0 * P;
+      hipLaunchKernelGGL(channel_norm_bwd_stats_kernel<GY16>, dim3((unsigned)((int64_t)nb * tiles)), dim3(NSTAT_PX * NSTAT_G), 0,
+                         st, gyc, sc, w, mc, rc, m1c, m2c, P, tiles);
+      const unsigned grid = (unsigned)((int64_t)nb * C * apply_chunks);
+      float* gx1c = gx1 + (int64_t)b0 * gx1_bs;
+      float* gx2c = gx2 ? gx2 + (int64_t)b0 * gx2_bs : nullptr;
+      const float* adc = addend1 ? addend1 + (int64_t)b0 * add1_bs : nullptr;
+      float* pc = partial + (size_t)b0 * apply_chunks * 2 * C;
+      if (vec)
+        hipLaunchKernelGGL((channel_norm_bwd_apply_kernel<true, GY16>), dim3(grid), dim3(256), 0, st, gyc, sc, w, mc, rc,
+                           (const float*)m1c, (const float*)m2c, gx1c, gx2c, gx1_bs, gx2_bs, adc, add1_bs, pc, P,
+                           APPLY_SPAN, apply_chunks);
+      else
+        hipLaunchKernelGGL((channel_norm_bwd_apply_kernel<false, GY16>), dim3(grid), dim3(256), 0, st, gyc, sc, w, mc, rc,
+                           (const float*)m1c, (const float*)m2c, gx1c, gx2c, gx1_bs, gx2_bs, adc, add1_bs, pc, P,
+                           APPLY_SPAN, apply_chunks);
+    }
     nblk = B * apply_chunks;
     const int rows = 64, chunks = (nblk + rows - 1) / rows;
     float* chunk = partial + (size_t)nblk * 2 * C;
@@ -757,6 +800,10 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
     PD_CHECK_LAUNCH("channel_norm_bwd(streaming)");
     return 0;
   }
+  if constexpr (GY16) {
+    paradis_set_error("channel_norm_bwd16: shape outside the streaming kernels (paradis_channel_norm_bwd16_ok)");
+    return 1;
+  } else {
   if (C <= 32 * 36 && (int64_t)B * ((P + 31) / 32) < (1ll << 31)) {
     // g_norm_bwd_reread: 1 = stream-twice kernel (default; in the training step 231.6 vs 235.2 ms),
     // 0 = gy in registers + xhat in LDS, one workgroup per CU (half the HBM traffic, phases serialised).
@@ -808,4 +855,28 @@ extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const 
                      chunks);
   PD_CHECK_LAUNCH("channel_norm_bwd");
   return 0;
+  }
+}
+
+extern "C" int paradis_channel_norm_bwd(const float* gy, const float* x1, const float* x2,
+                                        const float* w, const float* mean, const float* rstd,
+                                        float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
+                                        int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
+                                        int64_t gx2_bs, const float* addend1, int64_t add1_bs,
+                                        void* workspace, void* stream) {
+  return channel_norm_bwd_impl<false>(gy, x1, x2, w, mean, rstd, gx1, gx2, gw, gb, B, C1, C2, P, x1_bs, x2_bs, gx1_bs, gx2_bs,
+                                      addend1, add1_bs, workspace, stream);
+}
+
+// gy as a bf16 tensor [B][C1 + C2, P] (ABI 9; bf16-mixed mode); everything else as paradis_channel_norm_bwd.  Only where
+// paradis_channel_norm_bwd16_ok says so (the caller widens gy otherwise).
+extern "C" int paradis_channel_norm_bwd16_ok(int B, int C, int P) { return norm_bwd_streaming(std::max(B, 1), C, P) ? 1 : 0; }
+extern "C" int paradis_channel_norm_bwd16(const void* gy, const float* x1, const float* x2,
+                                          const float* w, const float* mean, const float* rstd,
+                                          float* gx1, float* gx2, float* gw, float* gb, int B, int C1,
+                                          int C2, int P, int64_t x1_bs, int64_t x2_bs, int64_t gx1_bs,
+                                          int64_t gx2_bs, const float* addend1, int64_t add1_bs,
+                                          void* workspace, void* stream) {
+  return channel_norm_bwd_impl<true>((const float*)gy, x1, x2, w, mean, rstd, gx1, gx2, gw, gb, B, C1, C2, P, x1_bs, x2_bs,
+                                     gx1_bs, gx2_bs, addend1, add1_bs, workspace, stream);
 }

@@ -65,6 +65,7 @@ __device__ __forceinline__ void stage_any(float* tile, const float* __restrict__
 // `global_load/store v, v_off, s[base:base+1]` - no 64-bit address arithmetic, no 64-bit addresses kept in registers
 // (with typed indexing the compiler only finds this form for 4-byte elements)
 typedef __attribute__((address_space(1))) char* ubase_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 struct cannot be read through an address-space pointer on the host pass)
 __device__ __forceinline__ ubase_t uniform_base(const void* p) {
   const uint64_t a = (uint64_t)p;
@@ -120,6 +121,17 @@ struct PlaneStager {
     const ubase_t b = uniform_base(F);
 #pragma unroll
     for (int j = 0; j < 2; ++j) { q[j] = load_at<f32x4>(b, vsrc[j]); hv[j] = load_at<float>(b, hsrc[j]); }
+  }
+  // the same plane stored as bf16 (round 6: the cotangent of a bf16-stored output): half the byte offsets, widened on arrival
+  __device__ __forceinline__ void load16(const uint16_t* __restrict__ F, f32x4 (&q)[2], float (&hv)[2]) const {
+    const ubase_t b = uniform_base(F);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32x2 r = load_at<u32x2>(b, vsrc[j] >> 1);
+      q[j] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                   __uint_as_float(r.y & 0xffff0000u)};
+      hv[j] = __uint_as_float((uint32_t)load_at<uint16_t>(b, hsrc[j] >> 1) << 16);
+    }
   }
   __device__ __forceinline__ void store(float* tile, const f32x4 (&q)[2], const float (&hv)[2]) const {
 #pragma unroll
@@ -569,7 +581,9 @@ dwconv_geo_wgrad_planes_kernel(const float* __restrict__ gy, const float* __rest
 // TWO tiles per plane: gy with its geocyclic extension (what the data gradient convolves) and x with its halo; the
 // cotangent values the weight gradient multiplies are the centre of the gy tile.  Same arithmetic in the same order as
 // dwconv_geo_dgrad_planes_kernel and dwconv_geo_wgrad_planes_kernel: bit-identical results.
-template <int K, bool ADD>
+// GY16 (round 6, bf16-mixed mode): gy is a bf16 tensor - the data gradient of the SepConv's pointwise GEMM, which consumed
+// the stencil's bf16-stored output (bf16-valued in the reference's autocast backward too).
+template <int K, bool ADD, bool GY16 = false>
 __global__ void __launch_bounds__(256, 4)
 dwconv_geo_bwd_planes_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ w,
                              const float* __restrict__ addend, float* __restrict__ gx, float* __restrict__ partial,
@@ -591,7 +605,8 @@ dwconv_geo_bwd_planes_kernel(const float* __restrict__ gy, const float* __restri
   const unsigned o0 = (unsigned)(r0 * W + xl) * 4u;
   auto fetch = [&](int item) __attribute__((always_inline)) {
     const int64_t off = ((int64_t)item * C + c) * (int64_t)H * W;
-    sg.load(gy + off, qg, hg);
+    if constexpr (GY16) sg.load16(reinterpret_cast<const uint16_t*>(gy) + off, qg, hg);
+    else sg.load(gy + off, qg, hg);
     sg.load(x + off, qx, hx);
   };
   // (rows of the tiles beyond the padded plane are never staged: define them once - see the weight-gradient kernel)
@@ -1323,6 +1338,25 @@ extern "C" int paradis_dwconv_geo_wgrad(const float* gy, const float* x, float* 
   return 0;
 }
 
+template <bool GY16>
+static int dwconv_geo_bwd_planes_launch(const float* gy, const float* x, const float* w, const float* addend, float* gx,
+                                        float* gw, float* gbias, int B, int C, int H, int k, void* workspace, void* stream) {
+  const int chunks = wgrad_chunks(B, C, 1);
+  float* partial = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (addend)
+    hipLaunchKernelGGL((dwconv_geo_bwd_planes_kernel<5, true, GY16>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend,
+                       gx, partial, B, C, H, chunks);
+  else
+    hipLaunchKernelGGL((dwconv_geo_bwd_planes_kernel<5, false, GY16>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend,
+                       gx, partial, B, C, H, chunks);
+  const int n = C * (k * k + 1);
+  hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias, C, k * k,
+                     chunks);
+  PD_CHECK_LAUNCH("dwconv_geo_bwd");
+  return 0;
+}
+
 // Both gradients of the stencil from one call: gx = dgrad(gy) (+ addend), gw / gbias.  On the whole-plane path
 // (k = 5, W = 64, H <= 32, aligned tensors: the reference grids at 5.625 degrees) and on the staged-tiles path (k = 5,
 // larger grids with W % 4 == 0) ONE kernel reads gy once; elsewhere the two kernels of paradis_dwconv_geo_dgrad / _wgrad
@@ -1362,20 +1396,26 @@ extern "C" int paradis_dwconv_geo_bwd(const float* gy, const float* x, const flo
     if (int e = dwconv_geo_dgrad_launch(gy, w, addend, gx, B, C, H, W, k, stream)) return e;
     return paradis_dwconv_geo_wgrad(gy, x, gw, gbias, B, C, H, W, k, workspace, stream);
   }
-  const int chunks = wgrad_chunks(B, C, 1);
-  float* partial = (float*)workspace;
-  hipStream_t st = (hipStream_t)stream;
-  if (addend)
-    hipLaunchKernelGGL((dwconv_geo_bwd_planes_kernel<5, true>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend,
-                       gx, partial, B, C, H, chunks);
-  else
-    hipLaunchKernelGGL((dwconv_geo_bwd_planes_kernel<5, false>), dim3(C * chunks), dim3(256), 0, st, gy, x, w, addend,
-                       gx, partial, B, C, H, chunks);
-  const int n = C * (k * k + 1);
-  hipLaunchKernelGGL(dwconv_wgrad_finish, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, gbias, C, k * k,
-                     chunks);
-  PD_CHECK_LAUNCH("dwconv_geo_bwd");
-  return 0;
+  return dwconv_geo_bwd_planes_launch<false>(gy, x, w, addend, gx, gw, gbias, B, C, H, k, workspace, stream);
+}
+
+// gy as a bf16 tensor (ABI 9; bf16-mixed mode), everything else as paradis_dwconv_geo_bwd.  Whole-plane grids only
+// (paradis_dwconv_geo_bwd16_ok: k = 5, W = 64, H <= 32 - the 5.625-degree grid); the caller widens gy elsewhere.
+extern "C" int paradis_dwconv_geo_bwd16_ok(int H, int W, int k) {
+  return (DWCONV_BWD_FUSED && DWCONV_PLANES && k == 5 && W == TW && H <= TH && ((int64_t)H * W) % 4 == 0) ? 1 : 0;
+}
+extern "C" int paradis_dwconv_geo_bwd16(const void* gy, const float* x, const float* w, const float* addend, float* gx,
+                                        float* gw, float* gbias, int B, int C, int H, int W, int k, void* workspace,
+                                        void* stream) {
+  if (int e = check_dw("dwconv_geo_bwd16", B, C, H, W, k)) return e;
+  PD_REQUIRE(workspace != nullptr, "dwconv_geo_bwd16: workspace required");
+  PD_REQUIRE(addend == nullptr || addend != gx, "dwconv_geo_bwd16: addend must not alias gx");
+  PD_REQUIRE(paradis_dwconv_geo_bwd16_ok(H, W, k), "dwconv_geo_bwd16: whole-plane grids only (%dx%d, k = %d)", H, W, k);
+  PD_REQUIRE(((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
+             ((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(addend)) & 3) == 0,
+             "dwconv_geo_bwd16: misaligned tensor");
+  if (B == 0) return paradis_dwconv_geo_bwd(nullptr, x, w, addend, gx, gw, gbias, B, C, H, W, k, workspace, stream);
+  return dwconv_geo_bwd_planes_launch<true>((const float*)gy, x, w, addend, gx, gw, gbias, B, C, H, k, workspace, stream);
 }
 
 static int check_pool(const char* name, int64_t planes, int H, int W, int s) {

@@ -169,55 +169,16 @@ def _is16(t) -> bool:
 
 # ---- bf16-stored activations between a NON-GEMM producer and its pointwise consumer (round 6) ----------------------------
 # ChannelNorm and the depthwise stencil can write their output as a bf16 tensor when its only consumer is a pointwise GEMM
-# in the bf16-mixed scheme (``out_bf16``).  Autograd hands a bf16 tensor's producer a bf16 cotangent; these producers'
-# backward kernels read fp32.  The consumer's data gradient IS bf16-valued (rounded where the reference's autocast backward
-# rounds it), so nothing is lost either way - but a 2-byte gradient would need bf16-reading variants of every producer
-# backward kernel.  Instead the consumer computes the gradient as bf16 VALUES IN FP32 WORDS (as in the fp32-stored layout),
-# leaves it in the producer's hand-off slot - the producing node hangs a token on the tensor it returns - and gives
-# autograd a zero-stride bf16 placeholder of the right shape.  The producer's backward takes the slot's tensor.  Every
-# failure mode is loud or correct: no token on the tensor (a foreign producer, a checkpoint's recomputed copy) -> the
-# consumer returns a REAL bf16 gradient and the producer widens it; a placeholder reaching a producer with an empty slot
-# raises.  Eager only (a traced graph has no side channel: ``out_bf16`` is not requested while compiling).
-class _Handoff:
-    __slots__ = ("grad32",)
-
-    def __init__(self):
-        self.grad32 = None
-
-
-_PLACEHOLDER16 = {}
-
-
-def _placeholder_grad16(like: Tensor) -> Tensor:
-    d = _PLACEHOLDER16.get(like.device)
-    if d is None:
-        d = _PLACEHOLDER16[like.device] = torch.zeros((), dtype=torch.bfloat16, device=like.device)
-    return d.expand(like.shape)
-
-
-def _is_placeholder16(g: Tensor) -> bool:
-    d = _PLACEHOLDER16.get(g.device)
-    return (d is not None and g.dtype == torch.bfloat16 and g.numel() > 1 and g.data_ptr() == d.data_ptr()
-            and all(st == 0 for st in g.stride()))
-
-
-def _attach_handoff(ctx, y: Tensor) -> None:
-    """producer side, forward: ``y`` is the bf16 tensor this node returns"""
-    if y.dtype == torch.bfloat16:
-        ctx.handoff = y._paradis_handoff = _Handoff()
-
-
-def _resolve_cotangent(ctx, gy):
-    """producer side, backward: the fp32 cotangent of this node's (possibly bf16-stored) output"""
-    tok = getattr(ctx, "handoff", None)
-    if tok is not None and tok.grad32 is not None:
-        g, tok.grad32 = tok.grad32, None
-        return g
-    if gy is not None and gy.dtype != torch.float32:
-        if _is_placeholder16(gy):
-            raise RuntimeError("paradis: the fp32 gradient of a bf16-stored activation was not handed over to its producer")
-        return gy.float()
-    return gy
+# in the bf16-mixed scheme (``out_bf16``).  Autograd hands a bf16 tensor's producer a bf16 cotangent - the consumer's data
+# gradient, bf16-valued in the reference's autocast backward as well (the gradient of conv2d's bf16 input).  The producers'
+# backward kernels read it as it is stored where they have a bf16 instantiation (the streaming ChannelNorm backward, the
+# whole-plane stencil backward: ``paradis_*_bwd16``); on every other path the op widens it first.  No side channel: the
+# cotangent is an ordinary tensor, so checkpointing, hooks and foreign producers / consumers need no special case.
+def _cotangent(gy, takes_bf16: bool):
+    """the cotangent of a (possibly bf16-stored) output as the backward kernels of this node take it"""
+    if gy is None or gy.dtype == torch.float32 or (takes_bf16 and gy.dtype == torch.bfloat16):
+        return gy
+    return gy.float()
 
 
 def _want_bf16_out(x: Tensor, out_bf16: bool) -> bool:
@@ -616,27 +577,30 @@ def _(gy, x, k, has_bias):
 def _dwconv_geo_bwd(gy, x, weight, addend, has_bias):
     """(gx (+ addend), gw, gb) of the stencil in one call: with k = 5 on the reference grids one kernel that reads gy
     once (paradis_dwconv_geo_bwd); bit-identical to ``dwconv_geo_dgrad`` (``_add``) + ``dwconv_geo_wgrad``."""
-    _f32(gy, x, weight, addend)
+    _f32(x, weight, addend)
+    _f32_or_bf16(gy)
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    if _is16(gy) and not lib.paradis_dwconv_geo_bwd16_ok(H, W, k):
+        gy = gy.float()             # (a bf16 cotangent is read as stored on the whole-plane grids only)
     gy, x, w = gy.contiguous(), x.contiguous(), weight.contiguous()
     if addend is not None:
         addend = addend.contiguous()
         assert addend.shape == gy.shape
-    B, C, H, W = x.shape
-    k = w.shape[-1]
-    gx = torch.empty_like(gy)
+    gx = torch.empty(gy.shape, dtype=x.dtype, device=x.device)
     gw = torch.empty(C, 1, k, k, dtype=x.dtype, device=x.device)
     gb = torch.empty(C if has_bias else 0, dtype=x.dtype, device=x.device)
     ws = _ws(lib.paradis_dwconv_geo_wgrad_ws_bytes(B, C, H, W, k), x.device)
-    check(lib.paradis_dwconv_geo_bwd(dptr(gy), dptr(x), dptr(w), dptr(addend), dptr(gx), dptr(gw),
-                                     dptr(gb) if has_bias else None, B, C, H, W, k, dptr(ws), stream_ptr()),
-          "dwconv_geo_bwd")
+    fn = lib.paradis_dwconv_geo_bwd16 if _is16(gy) else lib.paradis_dwconv_geo_bwd
+    check(fn(dptr(gy), dptr(x), dptr(w), dptr(addend), dptr(gx), dptr(gw),
+             dptr(gb) if has_bias else None, B, C, H, W, k, dptr(ws), stream_ptr()), "dwconv_geo_bwd")
     return gx, gw, gb
 
 
 @_fake("dwconv_geo_bwd")
 def _(gy, x, weight, addend, has_bias):
     C, k = x.shape[1], weight.shape[-1]
-    return gy.new_empty(gy.shape), x.new_empty(C, 1, k, k), x.new_empty(C if has_bias else 0)
+    return x.new_empty(gy.shape), x.new_empty(C, 1, k, k), x.new_empty(C if has_bias else 0)
 
 
 def _dw_grads(ctx, gy, x, w, addend, raw=False):
@@ -646,6 +610,7 @@ def _dw_grads(ctx, gy, x, w, addend, raw=False):
     need_x = ctx.needs_input_grad[0]
     need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
     gx = gw = gb = None
+    gy = _cotangent(gy, need_x and need_w)       # (the fused kernel has the bf16-cotangent instantiation)
     if need_x and need_w:
         gx, gw, gb = K["dwconv_geo_bwd"](gy, x, w, addend, ctx.has_bias)
     elif need_x:
@@ -661,12 +626,11 @@ def _dw_setup(ctx, inputs, output):
     x, w, bias = inputs[:3]
     ctx.save_for_backward(x, w)
     ctx.has_bias = bias is not None
-    _attach_handoff(ctx, output)
 
 
 def _dw_backward(ctx, gy):
     x, w = ctx.saved_tensors
-    return (*_dw_grads(ctx, _resolve_cotangent(ctx, gy), x, w, None), None)
+    return (*_dw_grads(ctx, gy, x, w, None), None)
 
 
 _autograd("dwconv_geo", _dw_setup, _dw_backward)
@@ -690,7 +654,6 @@ class _DwconvSkip(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)
-        _attach_handoff(ctx, y)
         return y, x
 
     @staticmethod
@@ -698,7 +661,6 @@ class _DwconvSkip(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if gy is None:          # only the skip path was used
             return gskip, None, None, None
-        gy = _resolve_cotangent(ctx, gy)
         return (*_dw_grads(ctx, gy, x, w, gskip, raw=_plain(gy)), None)
 
 
@@ -861,7 +823,8 @@ def _(x1, x2, weight, bias, eps, out_bf16=False):
 def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
     """``add``: a gradient that reaches x1 along another path (the residual branch around the block);
     it is added inside the kernel instead of by a separate accumulation pass."""
-    _f32(gy, x1, x2, add)
+    _f32(x1, x2, add)
+    _f32_or_bf16(gy)
     x1, bs1 = _plane_view(x1)
     B, C1, H, W = x1.shape
     C2, bs2 = 0, 0
@@ -873,15 +836,18 @@ def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
     add_bs = 0
     if add is not None:
         add, add_bs = _plane_view(add)
-    gx1 = torch.empty(B, C1, H, W, dtype=gy.dtype, device=gy.device)
-    gx2 = torch.empty(B, C2, H, W, dtype=gy.dtype, device=gy.device)
-    gw = torch.empty(C, dtype=gy.dtype, device=gy.device)
+    if _is16(gy) and not lib.paradis_channel_norm_bwd16_ok(B, C, P):
+        gy = gy.float().contiguous()        # (a bf16 cotangent is read as stored by the streaming kernels only)
+    gx1 = torch.empty(B, C1, H, W, dtype=x1.dtype, device=gy.device)
+    gx2 = torch.empty(B, C2, H, W, dtype=x1.dtype, device=gy.device)
+    gw = torch.empty(C, dtype=x1.dtype, device=gy.device)
     gb = torch.empty_like(gw)
     ws = _ws(lib.paradis_channel_norm_bwd_ws_bytes(B, C, P), gy.device)
-    check(lib.paradis_channel_norm_bwd(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight), dptr(mean),
-                                       dptr(rstd), dptr(gx1), dptr(gx2) if C2 else None, dptr(gw), dptr(gb), B,
-                                       C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add), add_bs, dptr(ws),
-                                       stream_ptr()), "channel_norm_bwd")
+    fn = lib.paradis_channel_norm_bwd16 if _is16(gy) else lib.paradis_channel_norm_bwd
+    check(fn(dptr(gy), dptr(x1), dptr(x2) if C2 else None, dptr(weight), dptr(mean),
+             dptr(rstd), dptr(gx1), dptr(gx2) if C2 else None, dptr(gw), dptr(gb), B,
+             C1, C2, P, bs1, bs2, C1 * P, C2 * P, dptr(add), add_bs, dptr(ws),
+             stream_ptr()), "channel_norm_bwd")
     return gx1, gx2, gw, gb
 
 
@@ -889,7 +855,7 @@ def _channel_norm_backward(gy, x1, x2, weight, mean, rstd, add):
 def _(gy, x1, x2, weight, mean, rstd, add):
     B, C1, H, W = x1.shape
     C2 = x2.shape[1] if x2 is not None else 0
-    return (gy.new_empty(B, C1, H, W), gy.new_empty(B, C2, H, W), gy.new_empty(C1 + C2), gy.new_empty(C1 + C2))
+    return (x1.new_empty(B, C1, H, W), x1.new_empty(B, C2, H, W), x1.new_empty(C1 + C2), x1.new_empty(C1 + C2))
 
 
 def _norm_setup(ctx, inputs, output):
@@ -898,14 +864,13 @@ def _norm_setup(ctx, inputs, output):
     ctx.save_for_backward(x1, x2, weight, mean, rstd)
     ctx.mark_non_differentiable(mean, rstd)
     ctx.set_materialize_grads(False)
-    _attach_handoff(ctx, y)
 
 
 def _norm_backward(ctx, gy, gmean=None, grstd=None):
     x1, x2, weight, mean, rstd = ctx.saved_tensors
     if gy is None:
         return None, None, None, None, None, None
-    gx1, gx2, gw, gb = _channel_norm_backward(_resolve_cotangent(ctx, gy), x1, x2, weight, mean, rstd, None)
+    gx1, gx2, gw, gb = _channel_norm_backward(_cotangent(gy, True), x1, x2, weight, mean, rstd, None)
     return gx1, (gx2 if x2 is not None else None), gw, gb, None, None
 
 
@@ -923,7 +888,6 @@ class _ChannelNormSkip(torch.autograd.Function):
         y, mean, rstd = _eager_forward("channel_norm", _channel_norm, x1, x2, weight, bias, eps, out_bf16)
         ctx.save_for_backward(x1, x2, weight, mean, rstd)
         ctx.set_materialize_grads(False)
-        _attach_handoff(ctx, y)
         return y, x1
 
     @staticmethod
@@ -931,7 +895,7 @@ class _ChannelNormSkip(torch.autograd.Function):
         x1, x2, weight, mean, rstd = ctx.saved_tensors
         if gy is None:          # only the skip path was used
             return gskip, None, None, None, None, None
-        gy = _resolve_cotangent(ctx, gy)
+        gy = _cotangent(gy, True)
         bwd = RAW["channel_norm_backward"] if _plain(gy) else _channel_norm_backward
         gx1, gx2, gw, gb = bwd(gy, x1, x2, weight, mean, rstd, gskip)
         return gx1, (gx2 if x2 is not None else None), gw, gb, None, None
@@ -1642,15 +1606,8 @@ def _pw_backward(ctx, gy, gz=None, gamax=None, raw=False):
     if need[0]:
         # (a bf16-stored input gets its gradient as bf16: with the activation-gradient hand-off that IS the producing
         #  layer's d(pre-activation), rounded to bf16 where the reference's autocast backward rounds it)
-        tok = getattr(x, "_paradis_handoff", None) if (x.dtype == torch.bfloat16 and x_act == 0) else None
-        if tok is not None:
-            # x came from a ChannelNorm / stencil that wrote it as bf16: its backward kernels read fp32 - the gradient
-            # goes into the producer's hand-off slot as bf16 values in fp32 words, autograd gets a placeholder
-            tok.grad32 = K["pw_gemm_dgrad"](dz, weight, None, 0, dz_amax, scheme, getattr(ctx, "wt_image", None), False)
-            gx = _placeholder_grad16(x)
-        else:
-            gx = K["pw_gemm_dgrad"](dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme,
-                                    getattr(ctx, "wt_image", None), x.dtype == torch.bfloat16)
+        gx = K["pw_gemm_dgrad"](dz, weight, x_pre if x_act != 0 else None, x_act, dz_amax, scheme,
+                                getattr(ctx, "wt_image", None), x.dtype == torch.bfloat16)
     want_b = has_bias and need[2]
     want_p = has_proj and (need[9] or need[10])
     want_m = (has_map and need[3]) or want_p

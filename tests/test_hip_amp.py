@@ -368,47 +368,95 @@ def test_bf16_outputs_of_norm_and_stencil_are_the_rounded_fp32_outputs():
         assert y.dtype == torch.bfloat16 and torch.equal(y, ref.to(torch.bfloat16)), (B, C1, C2, H, W)
 
 
-def test_gradient_handoff_and_its_fallbacks():
-    """norm -> pointwise with the norm's output stored as bf16: the consumer leaves the fp32-word gradient in the producer's
-    hand-off slot and autograd carries a zero-stride placeholder.  Same gradients (bit for bit: same kernels on the same
-    values) as with fp32 storage; under non-reentrant checkpointing the recomputed tensor carries no token and the REAL
-    bf16 gradient travels instead - same values again; a placeholder that reaches a producer with an empty slot raises."""
+def test_bf16_cotangent_of_a_bf16_stored_output():
+    """norm -> pointwise and stencil -> pointwise with the producer's output stored as bf16: the consumer's data gradient is
+    a bf16 tensor (bf16-valued in the reference's autocast backward as well) and the producer's backward kernels read it as
+    stored.  Same gradients as with fp32 storage up to that rounding (the fp32-storage path rounds the same value to bf16
+    inside fp32 words: the parameter and input gradients agree to fp32 noise), also under non-reentrant checkpointing, and
+    with an fp32 cotangent handed to the bf16 output by a foreign consumer (widened, not refused)."""
     from torch.utils.checkpoint import checkpoint
     from paradis_model_amd import ops
     g = torch.Generator().manual_seed(9)
-    B, C, Co, H, W = 2, 48, 40, 16, 32
+    B, C, Co, H, W = 2, 48, 40, 32, 64
     x = torch.randn(B, C, H, W, generator=g).cuda()
     nw = torch.nn.Parameter(torch.randn(C, generator=g).cuda())
     nb = torch.nn.Parameter(torch.randn(C, generator=g).cuda())
+    dw = torch.nn.Parameter((torch.randn(C, 1, 5, 5, generator=g) / 5).cuda())
     w = torch.nn.Parameter((torch.randn(Co, C, 1, 1, generator=g) / C ** 0.5).cuda())
     ct = torch.randn(B, Co, H, W, generator=g).cuda()
 
-    def block(xi, stored):
-        y = ops.channel_norm(xi, nw, nb, 1e-5, out_bf16=stored)
-        return ops.pointwise(y, w)
+    def norm_block(xi, stored):
+        return ops.pointwise(ops.channel_norm(xi, nw, nb, 1e-5, out_bf16=stored), w)
 
-    def run(stored, ckpt):
-        for p in (nw, nb, w):
-            p.grad = None
+    def stencil_block(xi, stored):
+        return ops.pointwise(ops.dwconv_geo(xi, dw, out_bf16=stored), w)
+
+    for block, params in ((norm_block, (nw, nb, w)), (stencil_block, (dw, w))):
+        def run(stored, ckpt):
+            for p in params:
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = checkpoint(block, xi, stored, use_reentrant=False) if ckpt else block(xi, stored)
+            out.backward(ct)
+            return [t.detach().clone() for t in (out, xi.grad, *[p.grad for p in params])]
+
+        base = run(False, False)
+        for stored, ckpt in ((True, False), (True, True), (False, True)):
+            got = run(stored, ckpt)
+            # (forward: two GEMM kernels - register-staged vs LDS-DMA - accumulate in differently signed spaces: fp32 noise)
+            for a, b_ in zip(got, base):
+                assert rms_rel(a, b_) <= 1e-6, (block.__name__, stored, ckpt, rms_rel(a, b_))
+    # a foreign consumer's cotangent for the bf16 output: any dtype is taken
+    for dt in (torch.float32, torch.bfloat16):
         xi = x.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = checkpoint(block, xi, stored, use_reentrant=False) if ckpt else block(xi, stored)
-        out.backward(ct)
-        return [t.detach().clone() for t in (out, xi.grad, nw.grad, nb.grad, w.grad)]
+            y = ops.channel_norm(xi, nw, nb, 1e-5, out_bf16=True)
+        assert y.dtype == torch.bfloat16
+        gy = torch.randn(y.shape, generator=g).cuda().to(torch.bfloat16)
+        (gx,) = torch.autograd.grad(y.float() if dt == torch.float32 else y, xi, gy.to(dt))
+        xr = x.clone().requires_grad_(True)
+        (gr,) = torch.autograd.grad(ops.channel_norm(xr, nw, nb, 1e-5), xr, gy.float())
+        assert torch.equal(gx, gr), dt
 
-    base = run(False, False)
-    for stored, ckpt in ((True, False), (True, True), (False, True)):
-        got = run(stored, ckpt)
-        # (forward: two GEMM kernels - register-staged vs LDS-DMA - accumulate in differently signed spaces: fp32 noise)
-        assert rms_rel(got[0], base[0]) <= 1e-6, (stored, ckpt)
-        for a, b_ in zip(got[1:], base[1:]):
-            assert rms_rel(a, b_) <= 1e-6, (stored, ckpt, rms_rel(a, b_))
-    # an orphaned placeholder is refused
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y = ops.channel_norm(x.clone().requires_grad_(True), nw, nb, 1e-5, out_bf16=True)
-    assert y.dtype == torch.bfloat16
-    with pytest.raises(RuntimeError, match="not handed over"):
-        y.backward(ops._placeholder_grad16(y))
+
+@pytest.mark.parametrize("B,C1,C2,H,W,add", [(2, 64, 0, 32, 64, True), (1, 1024, 128, 32, 64, True), (3, 40, 8, 12, 20, False),
+                                             (1, 130, 0, 9, 16, True), (2, 33, 0, 7, 9, False)])
+def test_channel_norm_backward_reads_a_bf16_cotangent_as_stored(B, C1, C2, H, W, add):
+    """paradis_channel_norm_bwd16 (streaming kernels, vector and scalar rows): bit for bit the fp32 entry point on the
+    widened cotangent - every gradient, with and without the fused residual addend and the virtual concat."""
+    from paradis_model_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x1 = torch.randn(B, C1, H, W, generator=g).cuda()
+    x2 = torch.randn(B, C2, H, W, generator=g).cuda() if C2 else None
+    w = torch.randn(C1 + C2, generator=g).cuda()
+    b = torch.randn(C1 + C2, generator=g).cuda()
+    _, mean, rstd = ops._channel_norm(x1, x2, w, b, 1e-5)
+    gy16 = torch.randn(B, C1 + C2, H, W, generator=g).cuda().to(torch.bfloat16)
+    addend = torch.randn(B, C1, H, W, generator=g).cuda() if add else None
+    got = ops._channel_norm_backward(gy16, x1, x2, w, mean, rstd, addend)
+    ref = ops._channel_norm_backward(gy16.float(), x1, x2, w, mean, rstd, addend)
+    for a, r in zip(got, ref):
+        assert a.dtype == torch.float32 and torch.equal(a, r)
+
+
+@pytest.mark.parametrize("B,C,H,W,k,add", [(2, 6, 32, 64, 5, False), (3, 5, 32, 64, 5, True), (9, 3, 24, 64, 5, True),
+                                           (1, 5, 40, 72, 5, True), (2, 4, 12, 20, 3, False)])
+def test_stencil_backward_reads_a_bf16_cotangent_as_stored(B, C, H, W, k, add):
+    """paradis_dwconv_geo_bwd16 on the whole-plane grids (several planes per workgroup: B = 9), and the op's widening
+    fallback elsewhere: bit for bit the fp32 entry point on the widened cotangent."""
+    from paradis_model_amd import ops
+    from paradis_model_amd._lib import lib
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = torch.randn(C, 1, k, k, generator=g).cuda()
+    gy16 = torch.randn(B, C, H, W, generator=g).cuda().to(torch.bfloat16)
+    addend = torch.randn(B, C, H, W, generator=g).cuda() if add else None
+    assert bool(lib.paradis_dwconv_geo_bwd16_ok(H, W, k)) == (k == 5 and W == 64 and H <= 32)
+    got = ops._dwconv_geo_bwd(gy16, x, w, addend, True)
+    ref = ops._dwconv_geo_bwd(gy16.float(), x, w, addend, True)
+    for a, r in zip(got, ref):
+        assert a.dtype == torch.float32 and torch.equal(a, r)
 
 
 @pytest.mark.parametrize("B,Co,Ci,H,W", [(1, 256, 256, 32, 64), (1, 256, 256, 64, 64), (4, 256, 256, 64, 128), (1, 512, 512, 32, 64),
