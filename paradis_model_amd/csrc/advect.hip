@@ -2015,11 +2015,13 @@ sl_advect_fwd_strip_fixup(const float* __restrict__ field, const float* __restri
     O[q[i]] = gather_global<MODE>(F, qx[i], qy[i], H, W, p, m0, m1);
 }
 
-// Diagnostic (round 6, verdict r5 item 5; PARADIS_ADVECT_DIRECT=1): the forward gather with NO LDS window - every tap a
+#ifdef PARADIS_DEV_KNOBS
+// Diagnostic (round 6, verdict r5 item 5; development library only, PARADIS_ADVECT_DIRECT=4|8): the forward gather with NO LDS window - every tap a
 // global load served by L2.  All workgroups of a plane run on ONE XCD (blockIdx % 8 = XCD; a 721 x 1440 plane is 4.15 MB,
 // that XCD's L2 holds the band of rows in flight), a wave takes 64 points of one latitude row (scalar sa / ca as in the
 // strips), a workgroup DROWS consecutive rows so that its waves share tap rows through the CU's L1.  Same departure
-// point and tap arithmetic as the strips' deferred points (gather_global).  A/B: profiles/r06_advect_direct.txt.
+// point and tap arithmetic as the strips' deferred points (gather_global).  A/B (profiles/r06_advect_direct.txt, tools/advect_direct_ab.py):
+// 2-3x slower than the strips with bicubic taps, 1.5x with bilinear, outputs identical.
 template <int MODE, int DROWS>
 __global__ void __launch_bounds__(64 * DROWS)
 sl_advect_fwd_direct(const float* __restrict__ field, const float* __restrict__ u, const float* __restrict__ v,
@@ -2051,6 +2053,7 @@ sl_advect_fwd_direct(const float* __restrict__ field, const float* __restrict__ 
   const float r = gather_global<MODE>(F, ix, iy, H, W, p, fmeans[2 * plane], fmeans[2 * plane + 1]);
   if (active) srow(O + y * W)[xc] = r;
 }
+#endif
 
 // field gradient and coordinate gradients of a point whose tap block leaves the window: global atomics on the field
 // gradient (float, or the integer plane of the deterministic mode), taps from global memory, one tap row at a time
@@ -2862,6 +2865,7 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
         reserve_lds(&sl_advect_fwd_kernel<PARADIS_INTERP_BILINEAR, false, TILED_THREADS_FWD>, "sl_advect_fwd: cannot reserve LDS"))
       return 2;
   }
+#ifdef PARADIS_DEV_KNOBS
   static const int direct = [] { const char* e = getenv("PARADIS_ADVECT_DIRECT"); return e ? atoi(e) : 0; }();   // (A/B: 4 or 8 rows per workgroup)
   if (direct > 0 && separable(flags, lat_cells)) {
     const int drows = direct >= 8 ? 8 : 4, rgroups = (H + drows - 1) / drows, cblocks = (W + 63) / 64;
@@ -2873,7 +2877,9 @@ extern "C" int paradis_sl_advect_fwd(const float* field, const float* u, const f
     if (mode == PARADIS_INTERP_BICUBIC) { if (drows == 8) LAUNCH_DIRECT(PARADIS_INTERP_BICUBIC, 8); else LAUNCH_DIRECT(PARADIS_INTERP_BICUBIC, 4); }
     else { if (drows == 8) LAUNCH_DIRECT(PARADIS_INTERP_BILINEAR, 8); else LAUNCH_DIRECT(PARADIS_INTERP_BILINEAR, 4); }
 #undef LAUNCH_DIRECT
-  } else if (separable(flags, lat_cells) && strip_ok(W, flags)) {
+  } else
+#endif
+  if (separable(flags, lat_cells) && strip_ok(W, flags)) {
     // strip schedule: ring of R padded rows, longitude halo hx (flags: PARADIS_ADVECT_HALO)
     const int ring = strip_ring_rows(H), hx = halo_of(flags, strip_halo_fwd(W), false);
     const int strips = (W + STRIP_W - 1) / STRIP_W;

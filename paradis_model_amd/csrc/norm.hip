@@ -708,9 +708,6 @@ constexpr int APPLY_SPAN = 8192;
 #ifndef NORM_BWD_STREAMING    // (A/B builds: 0 = the fused reread kernel of round 2)
 #define NORM_BWD_STREAMING 1
 #endif
-#ifndef NORM_BWD_CHUNK_MB
-#define NORM_BWD_CHUNK_MB 0
-#endif
 
 extern "C" size_t paradis_channel_norm_bwd_ws_bytes(int B, int C, int P) {
   const size_t b = (size_t)std::max(B, 1);
@@ -759,37 +756,21 @@ static int channel_norm_bwd_impl(const float* gy, const float* x1, const float* 
     const bool vec = P % 4 == 0 && x1_bs % 4 == 0 && (C2 == 0 || (x2_bs % 4 == 0 && a16(x2))) && gx1_bs % 4 == 0 &&
                      (gx2 == nullptr || (gx2_bs % 4 == 0 && a16(gx2))) && (addend1 == nullptr || (add1_bs % 4 == 0 && a16(addend1))) &&
                      a16(gy) && a16(x1) && a16(gx1) && a16(mean) && a16(rstd) && a16(workspace) && ((size_t)B * P) % 4 == 0;
-    // The two passes run over `bc` samples at a time, stats then apply, so that the apply pass finds the gy / x it
-    // re-reads in the 256 MB memory-side cache instead of in HBM (every index in both kernels is per sample: a chunk
-    // is the same launch on offset pointers, and the sums keep their order).  PARADIS_NORM_BWD_CHUNK_MB = read set of
-    // one chunk in MB (0 = one chunk).
-    static const int chunk_mb = [] { const char* e = getenv("PARADIS_NORM_BWD_CHUNK_MB"); return e ? atoi(e) : NORM_BWD_CHUNK_MB; }();
-    const int64_t per_sample = (int64_t)2 * C * P * sizeof(float);
-    int bc = B;
-    if (chunk_mb > 0 && vec) bc = (int)std::min<int64_t>(B, std::max<int64_t>(1, ((int64_t)chunk_mb << 20) / per_sample));
-    for (int b0 = 0; b0 < B; b0 += bc) {
-      const int nb = std::min(bc, B - b0);
-      CatSrc sc{x1 + (int64_t)b0 * x1_bs, x2 ? x2 + (int64_t)b0 * x2_bs : nullptr, C1, C2, x1_bs, x2_bs};
-      const float* gyc = GY16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(gy) + (int64_t)b0 * C * P)
-                              : gy + (int64_t)b0 * C * P;
-      const float *mc = mean + (int64_t)b0 * P, *rc = rstd + (int64_t)b0 * P;
-      float *m1c = m1 + (int64_t)b0 * P, *m2c = m2 + (int64_t)b0 * P;
-      hipLaunchKernelGGL(channel_norm_bwd_stats_kernel<GY16>, dim3((unsigned)((int64_t)nb * tiles)), dim3(NSTAT_PX * NSTAT_G), 0,
-                         st, gyc, sc, w, mc, rc, m1c, m2c, P, tiles);
-      const unsigned grid = (unsigned)((int64_t)nb * C * apply_chunks);
-      float* gx1c = gx1 + (int64_t)b0 * gx1_bs;
-      float* gx2c = gx2 ? gx2 + (int64_t)b0 * gx2_bs : nullptr;
-      const float* adc = addend1 ? addend1 + (int64_t)b0 * add1_bs : nullptr;
-      float* pc = partial + (size_t)b0 * apply_chunks * 2 * C;
-      if (vec)
-        hipLaunchKernelGGL((channel_norm_bwd_apply_kernel<true, GY16>), dim3(grid), dim3(256), 0, st, gyc, sc, w, mc, rc,
-                           (const float*)m1c, (const float*)m2c, gx1c, gx2c, gx1_bs, gx2_bs, adc, add1_bs, pc, P,
-                           APPLY_SPAN, apply_chunks);
-      else
-        hipLaunchKernelGGL((channel_norm_bwd_apply_kernel<false, GY16>), dim3(grid), dim3(256), 0, st, gyc, sc, w, mc, rc,
-                           (const float*)m1c, (const float*)m2c, gx1c, gx2c, gx1_bs, gx2_bs, adc, add1_bs, pc, P,
-                           APPLY_SPAN, apply_chunks);
-    }
+    // (Round 6: the two passes over chunks of the batch, stats then apply, so that the apply pass would find the gy / x it
+    //  re-reads in the 256 MB memory-side cache - every index is per sample, a chunk is the same launch on offset pointers.
+    //  Measured, removed: 318 us per call in one chunk, 371 / 424 / 600 / 1338 us with read sets of 160 / 96 / 48 / 24 MB per
+    //  chunk at 32 x 64, B = 32, C = 1024; the training step 152.7 -> 156.5 / 163.8 ms.  profiles/r06_norm_bwd_chunked.txt)
+    hipLaunchKernelGGL(channel_norm_bwd_stats_kernel<GY16>, dim3((unsigned)((int64_t)B * tiles)), dim3(NSTAT_PX * NSTAT_G), 0,
+                       st, gy, s, w, mean, rstd, m1, m2, P, tiles);
+    const unsigned grid = (unsigned)((int64_t)B * C * apply_chunks);
+    if (vec)
+      hipLaunchKernelGGL((channel_norm_bwd_apply_kernel<true, GY16>), dim3(grid), dim3(256), 0, st, gy, s, w, mean, rstd,
+                         (const float*)m1, (const float*)m2, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P,
+                         APPLY_SPAN, apply_chunks);
+    else
+      hipLaunchKernelGGL((channel_norm_bwd_apply_kernel<false, GY16>), dim3(grid), dim3(256), 0, st, gy, s, w, mean, rstd,
+                         (const float*)m1, (const float*)m2, gx1, gx2, gx1_bs, gx2_bs, addend1, add1_bs, partial, P,
+                         APPLY_SPAN, apply_chunks);
     nblk = B * apply_chunks;
     const int rows = 64, chunks = (nblk + rows - 1) / rows;
     float* chunk = partial + (size_t)nblk * 2 * C;

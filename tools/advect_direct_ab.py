@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic (verdict r5 item 5): the forward gather of the large grids through the LDS ring (strips, shipped) against
-the no-window variant that takes every tap from L2 with a plane per XCD (PARADIS_ADVECT_DIRECT=4|8 rows per workgroup;
-the knob is read once per process, so one process per arm).
-    python tools/advect_direct_ab.py <ref.pt>     first arm writes the outputs to ref.pt, later arms compare with them"""
+the no-window variant that takes every tap from L2 with a plane per XCD (development library only - `make -C
+paradis_model_amd/csrc dev` - PARADIS_ADVECT_DIRECT=4|8 rows per workgroup; the knob is read once per process, so one
+process per arm).  Result: profiles/r06_advect_direct.txt.
+    PARADIS_HIP_LIB=paradis_model_amd/libparadis_hip_dev.so PARADIS_ADVECT_DIRECT=<0|4|8> python tools/advect_direct_ab.py <ref.pt>
+    (the first arm writes its outputs to ref.pt, later arms compare with them)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
