@@ -175,6 +175,23 @@ __device__ __forceinline__ void gemm_add_projection(const GemmArgs& g, f32x16 (&
 __device__ __forceinline__ float gate_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
 // value of x rounded to bf16 (round to nearest even; a NaN stays a NaN: v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+// Activations of the bf16-mixed epilogue (R16): the value is rounded to bf16 - 8 significant bits - in the next instruction, so
+// the hardware's 1-ulp exp2 / reciprocal stand in for expf and the IEEE division of act_apply / act_grad (common.h): about 9
+// instead of about 29 vector instructions per element in an epilogue that was bound by exactly those (sixteen waves x 64 elements
+// per lane and tensor).  SiLU only; GELU keeps the library functions.  The fp32-width schemes never call these.
+__device__ __forceinline__ float sigmoid_r16(float z) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * z));
+}
+__device__ __forceinline__ float act_apply_r16(float z, int act) {
+  return act == PARADIS_ACT_SILU ? z * sigmoid_r16(z) : act_apply(z, act);
+}
+__device__ __forceinline__ float act_grad_r16(float z, int act) {
+  if (act == PARADIS_ACT_SILU) {
+    const float s = sigmoid_r16(z);
+    return s * (1.0f + z * (1.0f - s));
+  }
+  return act_grad(z, act);
+}
 // (An epilogue / k-loop stagger - the second workgroup of every CU of the first round starting late by 64-256 x 512 cycles,
 //  so that one workgroup's store-bound epilogue runs under the other's MFMA-bound k-loop - was measured on the bf16-mixed
 //  and the bf16x3 kernels and lost 0-10 % at every setting: profiles/r06_stagger_sweep.txt.  Not kept.)
@@ -207,6 +224,141 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
   (void)sizeof(char[C16 + ZM16 + 1]);
   const int64_t cb16 = (int64_t)bz * g.c_bs, zmb16 = (int64_t)bz * g.zmul_bs, zob16 = (int64_t)bz * g.zout_bs;
   if (g.pw) gemm_add_projection(g, acc, m0, n0, wm, wn, li, lh);
+  if constexpr (C16 || ZM16) {
+    // bf16-stored tensors of an interior tile move as PACKED PAIRS: a lane holds pixel li of the wave's two 32-column MFMA
+    // tiles (columns li and 32 + li of one row) - as 2-byte accesses a row of a tile is a 64-byte segment per instruction.
+    // Adjacent lanes swap one value each (even lane: its tile-1 value for the odd lane's tile-0 value), after which the even
+    // lane holds columns (li, li + 1) of tile 0 and the odd lane columns (31 + li, 32 + li): one dword per lane, 128 contiguous
+    // bytes per row and instruction, half the instructions.  Loads of a bf16 zmul run the same exchange backwards.
+    if (m0 + BM <= g.M && n0 + BN <= g.N && ((g.ldc | g.c_bs | g.zout_bs | g.zmul_bs) & 1) == 0) {
+      const bool odd = (li & 1) != 0;
+      const uint32_t sel = odd ? 0x07060302u : 0x03020706u;       // v_perm_b32(keep, recv): {lo, hi} halves of the dword
+      const int pcol = odd ? 31 + li : li;                         // first column of this lane's pair (even)
+      auto swap1 = [](float v) __attribute__((always_inline)) {   // the neighbour's value (lanes 2u <-> 2u + 1)
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+      };
+      auto pack = [&](float a0, float a1) __attribute__((always_inline)) {      // a0 / a1: this lane's tile-0 / tile-1 value (bf16-valued)
+        const float keep = odd ? a1 : a0, recv = swap1(odd ? a0 : a1);
+        return __builtin_amdgcn_perm(__float_as_uint(keep), __float_as_uint(recv), sel);
+      };
+      auto unpack = [&](uint32_t w, float& t0, float& t1) __attribute__((always_inline)) {
+        const float wlo = __uint_as_float(w << 16), whi = __uint_as_float(w & 0xffff0000u);
+        const float recv = swap1(odd ? wlo : whi);
+        t0 = odd ? recv : wlo;
+        t1 = odd ? whi : recv;
+      };
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int mrow = m0 + wm * 64 + tm * 32 + 4 * lh;
+        const int64_t base = (int64_t)mrow * g.ldc + n0 + wn * 64 + li;          // tile 0; tile 1: + 32
+        const int64_t pbase = (int64_t)mrow * g.ldc + n0 + wn * 64 + pcol;       // this lane's pair
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {   // 4 accumulator registers of each tile at a time
+          float v[2][4], t[2][4];
+          // register r = 4h + q  ->  row offset q + 8h
+#define ROWOFF(q) ((int64_t)((q) + 8 * h) * g.ldc)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[tn][q] = acc[tm][tn][4 * h + q];
+          if (g.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[0][q] = g.bias[mrow + q + 8 * h];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[0][q] += t[0][q]; v[1][q] += t[0][q]; }
+          }
+          if (g.map) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) t[tn][q] = g.map[base + 32 * tn + ROWOFF(q)];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[tn][q] += t[tn][q];
+          }
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[tn][q] = round_bf16(v[tn][q]);
+          if (zoutb) {
+            if constexpr (C16) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                reinterpret_cast<uint32_t*>(g.zout)[(zob16 + pbase + ROWOFF(q)) >> 1] = pack(v[0][q], v[1][q]);
+            } else {
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zoutb[base + 32 * tn + ROWOFF(q)] = v[tn][q];
+            }
+          }
+          if (zmulb) {
+            if constexpr (ZM16) {
+              uint32_t w[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) w[q] = reinterpret_cast<const uint32_t*>(g.zmul)[(zmb16 + pbase + ROWOFF(q)) >> 1];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) unpack(w[q], t[0][q], t[1][q]);
+            } else {
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[tn][q] = zmulb[base + 32 * tn + ROWOFF(q)];
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[tn][q] *= act_grad_r16(t[tn][q], g.act);
+          } else if (g.act) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[tn][q] = act_apply_r16(v[tn][q], g.act);
+          }
+          if (zmulb || g.act) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[tn][q] = round_bf16(v[tn][q]);
+          }
+          if (resb) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) t[tn][q] = resb[base + 32 * tn + ROWOFF(q)];
+            if (g.gate) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float gm = gate_sigmoid(g.gate[mrow + q + 8 * h]);
+                v[0][q] = fmaf(gm, v[0][q] - t[0][q], t[0][q]);
+                v[1][q] = fmaf(gm, v[1][q] - t[1][q], t[1][q]);
+              }
+            } else {
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[tn][q] += t[tn][q];
+            }
+          }
+          if constexpr (C16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              reinterpret_cast<uint32_t*>(g.C)[(cb16 + pbase + ROWOFF(q)) >> 1] = pack(v[0][q], v[1][q]);
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) Cb[base + 32 * tn + ROWOFF(q)] = v[tn][q];
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#undef ROWOFF
+        }
+      }
+      return;
+    }
+  }
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -255,10 +407,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
               for (int q = 0; q < 8; ++q) t[q] = zmulb[base + ROWOFF(q)];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] *= act_grad(t[q], g.act);
+            for (int q = 0; q < 8; ++q) v[q] *= R16 ? act_grad_r16(t[q], g.act) : act_grad(t[q], g.act);
           } else if (g.act) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = act_apply(v[q], g.act);
+            for (int q = 0; q < 8; ++q) v[q] = R16 ? act_apply_r16(v[q], g.act) : act_apply(v[q], g.act);
           }
           if constexpr (R16) {
             if (zmulb || g.act) {
@@ -312,8 +464,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         if (g.map) v += g.map[off];
         if constexpr (R16) v = round_bf16(v);
         if (zoutb) { if constexpr (C16) st_bf16(g.zout, zob16 + off, v); else zoutb[off] = v; }
-        if (zmulb) v *= act_grad(ZM16 ? ld_bf16(g.zmul, zmb16 + off) : zmulb[off], g.act);
-        else if (g.act) v = act_apply(v, g.act);
+        if (zmulb) {
+          const float zm = ZM16 ? ld_bf16(g.zmul, zmb16 + off) : zmulb[off];
+          v *= R16 ? act_grad_r16(zm, g.act) : act_grad(zm, g.act);
+        } else if (g.act) {
+          v = R16 ? act_apply_r16(v, g.act) : act_apply(v, g.act);
+        }
         if constexpr (R16) { if (zmulb || g.act) v = round_bf16(v); }
         if (resb) {
           const float r = resb[off];

@@ -122,15 +122,28 @@ struct PlaneStager {
 #pragma unroll
     for (int j = 0; j < 2; ++j) { q[j] = load_at<f32x4>(b, vsrc[j]); hv[j] = load_at<float>(b, hsrc[j]); }
   }
-  // the same plane stored as bf16 (round 6: the cotangent of a bf16-stored output): half the byte offsets, widened on arrival
+  // the same plane stored as bf16 (round 6: the cotangent of a bf16-stored output): half the byte offsets.  load16 keeps the
+  // RAW words (q.x, q.y = four bf16; hv = one, zero-extended by the load) so that nothing waits for the data at the fetch
+  // site - the prefetch stays in flight under the previous plane's arithmetic - and store16 widens them on the way to LDS.
   __device__ __forceinline__ void load16(const uint16_t* __restrict__ F, f32x4 (&q)[2], float (&hv)[2]) const {
     const ubase_t b = uniform_base(F);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const u32x2 r = load_at<u32x2>(b, vsrc[j] >> 1);
-      q[j] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-                   __uint_as_float(r.y & 0xffff0000u)};
-      hv[j] = __uint_as_float((uint32_t)load_at<uint16_t>(b, hsrc[j] >> 1) << 16);
+      q[j].x = __uint_as_float(r.x); q[j].y = __uint_as_float(r.y);
+      hv[j] = __uint_as_float((uint32_t)load_at<uint16_t>(b, hsrc[j] >> 1));
+    }
+  }
+  __device__ __forceinline__ void store16(float* tile, const f32x4 (&q)[2], const float (&hv)[2]) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (vdst[j] >= 0) {
+        const uint32_t lo = __float_as_uint(q[j].x), hi = __float_as_uint(q[j].y);
+        float2* d = reinterpret_cast<float2*>(tile + vdst[j]);
+        d[0] = make_float2(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u));
+        d[1] = make_float2(__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+      }
+      if (hdst[j] >= 0) tile[hdst[j]] = __uint_as_float(__float_as_uint(hv[j]) << 16);
     }
   }
   __device__ __forceinline__ void store(float* tile, const f32x4 (&q)[2], const float (&hv)[2]) const {
@@ -615,7 +628,7 @@ dwconv_geo_bwd_planes_kernel(const float* __restrict__ gy, const float* __restri
   if (chunk < B) fetch(chunk);
   for (int item = chunk; item < B; item += chunks) {
     const int64_t off = ((int64_t)item * C + c) * (int64_t)H * W;
-    sg.store(tg, qg, hg);
+    if constexpr (GY16) sg.store16(tg, qg, hg); else sg.store(tg, qg, hg);
     sg.store(tx, qx, hx);
     __syncthreads();
     if (item + chunks < B) fetch(item + chunks);
