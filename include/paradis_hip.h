@@ -55,7 +55,7 @@ extern "C" {
 #define PARADIS_ADVECT_HALO_BWD_SHIFT 16
 #define PARADIS_ADVECT_HALO(h) (((h) + 1) << PARADIS_ADVECT_HALO_SHIFT)
 
-int paradis_abi_version(void);   /* 9: bf16-stored tensors of the bf16-mixed mode (paradis_pw_gemm_fwd16 / _dgrad16 / _wgrad16, paradis_bias_grads16, paradis_channel_norm_fwd16 / _bwd16, paradis_dwconv_geo_fwd16 / _bwd16): additions only; 8: PARADIS_GEMM_BF16 scheme, paradis_pw_gemm_wgrad_slabs (query); no signature changed; 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
+int paradis_abi_version(void);   /* 9: bf16-stored tensors of the bf16-mixed mode (paradis_pw_gemm_fwd16 / _dgrad16 / _wgrad16, paradis_bias_grads16, paradis_channel_norm_fwd16 / _bwd16, paradis_dwconv_geo_fwd16 / _bwd16, paradis_act_bwd16): additions only; 8: PARADIS_GEMM_BF16 scheme, paradis_pw_gemm_wgrad_slabs (query); no signature changed; 7: paradis_dwconv_geo_dgrad_add, paradis_dwconv_geo_bwd, paradis_pw_gemm_split_weights_pair, paradis_pw_gemm_fwd_gated, paradis_gated_blend_bwd_out; 6: paradis_sl_advect_ws_bytes takes the call's flags (strip schedule); 5: no amax side outputs, lat_cells table of sl_advect_* (4: GEMM `scheme` arguments, paradis_amax_partials; 3: `flags` of sl_advect_*) */
 const char* paradis_last_error(void);
 
 /* ---- a1: GeoCyclicPadding.forward (reference model/padding.py:11-39) and its adjoint.
@@ -241,6 +241,9 @@ int paradis_channel_norm_bwd16(const void* gy /* bf16 */, const float* x1, const
 int paradis_dwconv_geo_bwd16_ok(int H, int W, int k);
 int paradis_dwconv_geo_bwd16(const void* gy /* bf16 */, const float* x, const float* w, const float* addend, float* gx, float* gw,
                              float* gbias, int B, int C, int H, int W, int k, void* workspace, void* stream);
+/* paradis_act_bwd writing gx = gy * act'(x) as a bf16 tensor (to nearest even): d(pre-activation) of a pointwise layer, which both
+ * of its gradient GEMMs would round to bf16 on load.  n % 4 == 0, 16-byte aligned gy / x. */
+int paradis_act_bwd16(const float* gy, const float* x, void* gx /* bf16 */, int64_t n, int act, void* stream);
 /* paradis_bias_grads on a bf16-stored dz (P % 8 == 0, 16-byte aligned rows); outputs fp32 */
 int paradis_bias_grads16(const void* dz, float* gmap, float* gbias, int B, int C, int P, int64_t dz_bs, void* stream);
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "paradis_global_bias_map_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "paradis_act_fwd": (I, [P, P, L, I, P]),
     "paradis_act_bwd": (I, [P, P, P, L, I, P]),
+    "paradis_act_bwd16": (I, [P, P, P, L, I, P]),
     "paradis_gated_blend_fwd": (I, [P, P, P, P, I, I, I, P]),
     "paradis_gated_blend_bwd_ws_bytes": (S, [I, I, I]),
     "paradis_gated_blend_bwd": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),

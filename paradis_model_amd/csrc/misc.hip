@@ -284,10 +284,24 @@ gbias_finish_kernel(const float* __restrict__ T1, const float* __restrict__ T2,
 }
 
 // ------------------------------------------------------------------ activation
-template <bool BWD>
+// O16 (round 6, bf16-mixed mode, BWD only): out is a bf16 tensor - d(pre-activation) for the layer's two gradient GEMMs, which
+// round that operand to bf16 (to nearest even, as here) when they load it from fp32 words: same values, half the bytes thrice.
+template <bool BWD, bool O16 = false>
 __global__ void __launch_bounds__(256)
 act_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ out,
            int64_t n, int act, bool vec) {
+  if constexpr (O16) {
+    const int64_t n4 = n >> 2;      // (the host checks n % 4 == 0 and the alignment)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i], g = reinterpret_cast<const float4*>(gy)[i];
+      const float o[4] = {g.x * act_grad(v.x, act), g.y * act_grad(v.y, act), g.z * act_grad(v.z, act), g.w * act_grad(v.w, act)};
+      uint2 r;
+      r.x = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)o[1]) << 16);
+      r.y = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)o[3]) << 16);
+      reinterpret_cast<uint2*>(out)[i] = r;
+    }
+    return;
+  }
   if (vec) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -557,6 +571,19 @@ extern "C" int paradis_act_bwd(const float* gy, const float* x, float* gx, int64
   hipLaunchKernelGGL(act_kernel<true>, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0,
                      (hipStream_t)stream, gy, x, gx, n, act, vec);
   PD_CHECK_LAUNCH("act_bwd");
+  return 0;
+}
+
+// gx as a bf16 tensor (ABI 9; bf16-mixed mode: gx = d(pre-activation), the operand of the layer's gradient GEMMs).  n % 4 == 0,
+// 16-byte aligned gy / x, 8-byte aligned gx.
+extern "C" int paradis_act_bwd16(const float* gy, const float* x, void* gx, int64_t n, int act, void* stream) {
+  PD_REQUIRE(n >= 0 && act >= 0 && act <= 2, "act_bwd16: bad arguments");
+  if (n == 0) return 0;
+  PD_REQUIRE(n % 4 == 0 && aligned16(x) && aligned16(gy) && (reinterpret_cast<uintptr_t>(gx) & 7) == 0,
+             "act_bwd16: n %% 4 == 0 and aligned tensors required");
+  hipLaunchKernelGGL((act_kernel<true, true>), dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, gy, x,
+                     (float*)gx, n, act, true);
+  PD_CHECK_LAUNCH("act_bwd16");
   return 0;
 }
 

@@ -1345,18 +1345,24 @@ def _(x, weight, bias, bmap, residual, act, x_pre, x_act, defer_act_grad, m8, pw
             x.new_empty(AMAX_PARTIALS if scheme == GEMM_F16X2 else 0, dtype=torch.int32))
 
 
-@_define("act_backward(Tensor gy, Tensor z, int act) -> Tensor")
-def _act_backward(gy, z, act):
+@_define("act_backward(Tensor gy, Tensor z, int act, bool out_bf16=False) -> Tensor")
+def _act_backward(gy, z, act, out_bf16=False):
+    """``out_bf16`` (bf16-mixed scheme): d(pre-activation) as a bf16 tensor - the operand both gradient GEMMs of the layer
+    would round to bf16 on load (same values; the reference's autocast backward holds this tensor in bf16 as well)"""
     _f32(gy, z)
     gy, z = gy.contiguous(), z.contiguous()
+    if out_bf16 and gy.numel() % 4 == 0:
+        dz = torch.empty(gy.shape, dtype=torch.bfloat16, device=gy.device)
+        check(lib.paradis_act_bwd16(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, stream_ptr()), "act_bwd16")
+        return dz
     dz = torch.empty_like(gy)
     check(lib.paradis_act_bwd(dptr(gy), dptr(z), dptr(dz), gy.numel(), act, stream_ptr()), "act_bwd")
     return dz
 
 
 @_fake("act_backward")
-def _(gy, z, act):
-    return gy.new_empty(gy.shape)
+def _(gy, z, act, out_bf16=False):
+    return gy.new_empty(gy.shape, dtype=torch.bfloat16 if (out_bf16 and gy.numel() % 4 == 0) else gy.dtype)
 
 
 @_define("pw_gemm_dgrad(Tensor dz, Tensor weight, Tensor? zmul, int x_act, Tensor? dz_amax, int scheme, "
@@ -1597,7 +1603,10 @@ def _pw_backward(ctx, gy, gz=None, gamax=None, raw=False):
     else:
         gres = gy if has_res else None
     if act != 0 and not deferred:
-        dz = K["act_backward"](gy, z, act)
+        # (bf16-mixed scheme: dz leaves the activation-gradient pass as a bf16 tensor - what its consumers, the two gradient
+        #  GEMMs, round it to anyway - where their bf16-operand layout rules hold)
+        dz16 = (scheme == GEMM_BF16 and BF16_STORAGE and gy.dtype == torch.float32 and (gy.shape[-2] * gy.shape[-1]) % 16 == 0)
+        dz = K["act_backward"](gy, z, act, dz16)
     else:
         dz = gy          # no activation, or the consumer already applied act'(z) (deferred)
     gx = gw = gb = gmap = gm8 = gpw = None

@@ -420,6 +420,43 @@ def test_bf16_cotangent_of_a_bf16_stored_output():
         assert torch.equal(gx, gr), dt
 
 
+def test_activation_gradient_as_a_bf16_tensor_is_the_rounded_fp32_one():
+    """act_backward(out_bf16=True): bit for bit the fp32 result rounded to nearest even (what the gradient GEMMs round their
+    operand to), and a SiLU layer's gradients under autocast are the same with bf16 storage on and off - the GEMMs see the
+    same operand values either way (bias gradient: a sum of rounded instead of unrounded values)."""
+    from paradis_model_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for shape in ((2, 40, 16, 32), (1, 7, 9, 4), (3, 5, 3, 5)):
+        gy = torch.randn(*shape, generator=g).cuda()
+        z = (3 * torch.randn(*shape, generator=g)).cuda()
+        ref = ops._act_backward(gy, z, ops.ACT_CODES["SiLU"])
+        got = ops._act_backward(gy, z, ops.ACT_CODES["SiLU"], True)
+        if gy.numel() % 4 == 0:
+            assert got.dtype == torch.bfloat16 and torch.equal(got, ref.to(torch.bfloat16)), shape
+        else:
+            assert got.dtype == torch.float32 and torch.equal(got, ref), shape
+    B, Ci, Co, H, W = 2, 64, 48, 16, 32
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = torch.nn.Parameter((torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).cuda())
+    b = torch.nn.Parameter(torch.randn(Co, generator=g).cuda())
+    ct = torch.randn(B, Co, H, W, generator=g).cuda()
+    res = []
+    keep = ops.BF16_STORAGE
+    try:
+        for stored in (True, False):
+            ops.BF16_STORAGE = stored
+            w.grad = b.grad = None
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = ops.pointwise(xi, w, b, act="SiLU")
+            y.backward(ct)
+            res.append((xi.grad.clone(), w.grad.clone(), b.grad.clone()))
+    finally:
+        ops.BF16_STORAGE = keep
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert rms_rel(res[0][2], res[1][2]) <= 2e-3
+
+
 @pytest.mark.parametrize("B,C1,C2,H,W,add", [(2, 64, 0, 32, 64, True), (1, 1024, 128, 32, 64, True), (3, 40, 8, 12, 20, False),
                                              (1, 130, 0, 9, 16, True), (2, 33, 0, 7, 9, False)])
 def test_channel_norm_backward_reads_a_bf16_cotangent_as_stored(B, C1, C2, H, W, add):
