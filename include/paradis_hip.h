@@ -161,6 +161,8 @@ size_t paradis_pw_gemm_split_bytes(int M, int K, int scheme);   /* bytes of the 
 int paradis_pw_gemm_split_weights(const float* W, int M, int K, int transpose, int scheme, void* out, void* stream);
 /* PARADIS_GEMM_BF16X3 images of W (-> out) and of W^T (-> out_t) in one launch: a training step needs both (ABI 7) */
 int paradis_pw_gemm_split_weights_pair(const float* W, int M, int K, void* out, void* out_t, void* stream);
+/* the same for PARADIS_GEMM_BF16X3 or PARADIS_GEMM_BF16 (ABI 9) */
+int paradis_pw_gemm_split_weights_pair_scheme(const float* W, int M, int K, int scheme, void* out, void* out_t, void* stream);
 int paradis_pw_gemm_fwd(const float* Wt, const float* WtT /* optional [K,M] copy of Wt, or NULL */,
                         const void* Wsplit /* split image of Wt for `scheme`, NULL for PARADIS_GEMM_EXACT */,
                         int scheme, const uint32_t* x_amax /* amax partials of X: PARADIS_GEMM_F16X2 only */,

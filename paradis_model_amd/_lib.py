@@ -50,6 +50,7 @@ SIGNATURES = {
     "paradis_pw_gemm_split_bytes": (S, [I, I, I]),
     "paradis_pw_gemm_split_weights": (I, [P, I, I, I, I, P, P]),
     "paradis_pw_gemm_split_weights_pair": (I, [P, I, I, P, P, P]),
+    "paradis_pw_gemm_split_weights_pair_scheme": (I, [P, I, I, I, P, P, P]),
     "paradis_pw_gemm_fwd": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, I, I, I, I, L, L, L, I, P]),
     "paradis_pw_gemm_fwd_gated": (I, [P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, L, L, L, I, P]),
     "paradis_forcings_ws_bytes": (ctypes.c_size_t, [I, I]),

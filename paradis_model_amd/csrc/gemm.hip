@@ -1025,14 +1025,13 @@ split_weights_kernel(const float* __restrict__ W, int64_t rs, int64_t cs, int M,
 
 // both images of one row-major W[M,K] in ONE launch (a training step needs W for the forward GEMM and W^T for the
 // data gradient: 78 launches of a few microseconds per step instead of 155): blockIdx.y = 0 -> W, 1 -> W^T
-#if GEMM_PART < 2
+template <int NP>
 __global__ void __launch_bounds__(256)
 split_weights_pair_kernel(const float* __restrict__ W, int M, int K, int KT, int KTt, int64_t units, int64_t units_t,
                           u32x4* __restrict__ out, u32x4* __restrict__ out_t) {
-  if (blockIdx.y == 0) split_weights_body<3>(W, K, 1, M, K, KT, units, out);
-  else split_weights_body<3>(W, 1, K, K, M, KTt, units_t, out_t);
+  if (blockIdx.y == 0) split_weights_body<NP>(W, K, 1, M, K, KT, units, out);
+  else split_weights_body<NP>(W, 1, K, K, M, KTt, units_t, out_t);
 }
-#endif
 
 // f16x2 image: out[((mt*KT + kt)*2 + s)*256 + half*128 + row]; `tail` = the words behind the image:
 // [0] = bits of max |W| (written here, read by the GEMMs), [4 ..) = the amax partials of W (input)
@@ -3007,17 +3006,30 @@ extern "C" int paradis_pw_gemm_split_weights(const float* W, int M, int K, int t
   return 0;
 }
 
-// bf16x3 images of W[M,K] (-> out, split_bytes(M,K)) and of W^T (-> out_t, split_bytes(K,M)) in one launch
-extern "C" int paradis_pw_gemm_split_weights_pair(const float* W, int M, int K, void* out, void* out_t, void* stream) {
+// images of W[M,K] (-> out, split_bytes(M,K,scheme)) and of W^T (-> out_t, split_bytes(K,M,scheme)) in one launch:
+// PARADIS_GEMM_BF16X3 or PARADIS_GEMM_BF16 (the f16x2 image needs the amax of W first: paradis_pw_gemm_split_weights)
+extern "C" int paradis_pw_gemm_split_weights_pair_scheme(const float* W, int M, int K, int scheme, void* out, void* out_t,
+                                                         void* stream) {
   PD_REQUIRE(W != nullptr && out != nullptr && out_t != nullptr && out != out_t && M >= 1 && K >= 1,
              "pw_gemm_split_weights_pair: bad arguments");
-  const int KT = (K + SBK - 1) / SBK, KTt = (M + SBK - 1) / SBK;
+  PD_REQUIRE(scheme == PARADIS_GEMM_BF16X3 || scheme == PARADIS_GEMM_BF16,
+             "pw_gemm_split_weights_pair: scheme %d has no paired images", scheme);
+  const int np = scheme == PARADIS_GEMM_BF16 ? 1 : 3;
+  const int KT = split_image_ktiles(K, np), KTt = split_image_ktiles(M, np);      // (bf16-mixed images: an even count of k16 tiles)
   const int64_t units = (int64_t)((M + BM - 1) / BM) * KT * 256, units_t = (int64_t)((K + BM - 1) / BM) * KTt * 256;
   const int blocks = (int)std::min<int64_t>((std::max(units, units_t) + 255) / 256, 4096);
-  hipLaunchKernelGGL(split_weights_pair_kernel, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, W, M, K, KT, KTt,
-                     units, units_t, (u32x4*)out, (u32x4*)out_t);
+  if (scheme == PARADIS_GEMM_BF16X3)
+    hipLaunchKernelGGL(split_weights_pair_kernel<3>, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, W, M, K, KT, KTt,
+                       units, units_t, (u32x4*)out, (u32x4*)out_t);
+  else
+    hipLaunchKernelGGL(split_weights_pair_kernel<1>, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, W, M, K, KT, KTt,
+                       units, units_t, (u32x4*)out, (u32x4*)out_t);
   PD_CHECK_LAUNCH("pw_gemm_split_weights_pair");
   return 0;
+}
+// (ABI 7's spelling: the bf16x3 pair)
+extern "C" int paradis_pw_gemm_split_weights_pair(const float* W, int M, int K, void* out, void* out_t, void* stream) {
+  return paradis_pw_gemm_split_weights_pair_scheme(W, M, K, PARADIS_GEMM_BF16X3, out, out_t, stream);
 }
 
 namespace {

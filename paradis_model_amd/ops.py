@@ -1174,15 +1174,18 @@ def _version_of(t: Tensor) -> int:
     return 0 if t.is_inference() else t._version
 
 
+_PAIRED_SCHEMES = (GEMM_BF16X3, GEMM_BF16)       # schemes whose W and W^T images come from one launch
+
+
 def _build_images(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int, pair: bool):
-    """(image, image of the transpose or None): ``pair`` (bf16x3, not ``transpose``) writes both from one launch"""
+    """(image, image of the transpose or None): ``pair`` (bf16x3 / bf16-mixed, not ``transpose``) writes both from one launch"""
     w2 = weight.reshape(Co, Ci).contiguous()
     nbytes = lib.paradis_pw_gemm_split_bytes(Ci, Co, scheme) if transpose else \
         lib.paradis_pw_gemm_split_bytes(Co, Ci, scheme)
     out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    if pair and not transpose and scheme == GEMM_BF16X3:
+    if pair and not transpose and scheme in _PAIRED_SCHEMES:
         out_t = torch.empty(lib.paradis_pw_gemm_split_bytes(Ci, Co, scheme), dtype=torch.uint8, device=weight.device)
-        check(lib.paradis_pw_gemm_split_weights_pair(dptr(w2), Co, Ci, dptr(out), dptr(out_t), stream_ptr()),
+        check(lib.paradis_pw_gemm_split_weights_pair_scheme(dptr(w2), Co, Ci, scheme, dptr(out), dptr(out_t), stream_ptr()),
               "pw_gemm_split_weights_pair")
         return out, out_t
     check(lib.paradis_pw_gemm_split_weights(dptr(w2), Co, Ci, 1 if transpose else 0, scheme, dptr(out),
@@ -1205,7 +1208,7 @@ def _split_image(weight: Tensor, Co: int, Ci: int, transpose: bool, scheme: int,
                 and ent[3] == WEIGHT_EPOCH)
     ent = _IMAGES.get(key)
     ent_t = _IMAGES.get((id(weight), True, scheme)) if (want_wt and not transpose) else None
-    if valid(ent) and (not (want_wt and not transpose and scheme == GEMM_BF16X3) or valid(ent_t)):
+    if valid(ent) and (not (want_wt and not transpose and scheme in _PAIRED_SCHEMES) or valid(ent_t)):
         return ent[4], (ent_t[4] if valid(ent_t) else None)
     out, out_t = _build_images(weight, Co, Ci, transpose, scheme, want_wt)
     if isinstance(weight, torch.nn.Parameter) or weight.is_leaf:

@@ -105,9 +105,27 @@ def test_clinear_golden(ops):
 @pytest.mark.parametrize("M,K", [(7, 10), (130, 258), (1024, 1068), (97, 512)])
 def test_weight_images_pair_launch_equals_the_two_single_launches(ops, M, K):
     """paradis_pw_gemm_split_weights_pair: the bf16x3 images of W and W^T from one launch are byte-identical to the
-    two single launches; the recorded forward of ``pointwise`` caches both (one launch), a no-grad forward only W's."""
+    two single launches (and so are the bf16-mixed scheme's, paradis_pw_gemm_split_weights_pair_scheme); the recorded
+    forward of ``pointwise`` caches both (one launch), a no-grad forward only W's."""
     from paradis_model_amd._lib import lib
     w = seeded(7, M, K).cuda()
+    images_t = {}
+    for sch in (ops.GEMM_BF16, ops.GEMM_BF16X3):
+        n, nt = lib.paradis_pw_gemm_split_bytes(M, K, sch), lib.paradis_pw_gemm_split_bytes(K, M, sch)
+        a, at = torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(nt, dtype=torch.uint8, device="cuda")
+        b, bt = torch.zeros_like(a), torch.zeros_like(at)
+        assert lib.paradis_pw_gemm_split_weights(ops.dptr(w), M, K, 0, sch, ops.dptr(a), ops.stream_ptr()) == 0
+        assert lib.paradis_pw_gemm_split_weights(ops.dptr(w), M, K, 1, sch, ops.dptr(at), ops.stream_ptr()) == 0
+        assert lib.paradis_pw_gemm_split_weights_pair_scheme(ops.dptr(w), M, K, sch, ops.dptr(b), ops.dptr(bt), ops.stream_ptr()) == 0
+        assert torch.equal(a, b) and torch.equal(at, bt), sch
+        images_t[sch] = at
+    assert lib.paradis_pw_gemm_split_weights_pair_scheme(ops.dptr(w), M, K, ops.GEMM_F16X2, ops.dptr(b), ops.dptr(bt), ops.stream_ptr()) == 1
+    # the bf16-mixed scheme's recorded forward hands its backward the W^T image of the same launch as well
+    wq = torch.nn.Parameter(w.clone().reshape(M, K, 1, 1))
+    xq = seeded(8, 2, K, 8, 16).cuda().requires_grad_(True)
+    yq = ops.pointwise(xq, wq, scheme=ops.GEMM_BF16)
+    assert yq.grad_fn.wt_image is not None and torch.equal(yq.grad_fn.wt_image, images_t[ops.GEMM_BF16])
+    yq.sum().backward()
     n, nt = lib.paradis_pw_gemm_split_bytes(M, K, ops.GEMM_BF16X3), lib.paradis_pw_gemm_split_bytes(K, M, ops.GEMM_BF16X3)
     a, at = torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(nt, dtype=torch.uint8, device="cuda")
     b, bt = torch.zeros_like(a), torch.zeros_like(at)
