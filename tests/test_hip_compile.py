@@ -52,6 +52,34 @@ def test_compile_fullgraph_matches_eager(backend):
     assert max_rel(y2, y0) <= 1e-6
 
 
+def test_compile_under_bf16_autocast_matches_the_eager_bf16_mixed_step():
+    """The reference's two switches together (compute.compile + use_amp, trainer.py:261-269 with train.py:56): the traced
+    graph under torch.autocast(bfloat16) runs the bf16-mixed scheme with fp32-stored activations (a traced graph makes no
+    storage requests) and the bf16 d(pre-activation) of ``act_backward`` - whose fake kernel must name the dtype the HIP
+    kernel returns.  Against the eager bf16-mixed step (bf16 storage on): same values up to rounding flips."""
+    from tests._util import rms_rel
+    cfg = reduced_config()
+    eager = _build(cfg)
+    comp = copy.deepcopy(eager)
+    comp.compile(mode="default", fullgraph=True, dynamic=False, backend="aot_eager")
+    x = seeded(5, 2, 186, 16, 32).cuda()
+
+    def run(model):
+        model.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(xd)
+            loss = y.square().mean()
+        loss.backward()
+        return y.detach(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    y0, g0 = run(eager)
+    y1, g1 = run(comp)
+    assert y1.dtype == torch.float32 and rms_rel(y1, y0) <= 2e-3
+    errs = sorted(rms_rel(g1[n], g0[n]) for n in g0 if float(g0[n].abs().max()) > 0)
+    assert errs[len(errs) // 2] <= 2e-3 and errs[-1] <= 3e-2, (errs[len(errs) // 2], errs[-1])
+
+
 def test_per_module_compile_matches_eager():
     """reference model/paradis.py:195-206 (compute.compile == "modules")"""
     cfg = reduced_config()
