@@ -2508,7 +2508,7 @@ pw_gemm_wgrad_square_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
-  if constexpr (A16 && B16) {
+  {
     // Two k-tiles per barrier (sixteen MFMAs per wave between two barriers instead of eight): a ring of FOUR stages, tile t in
     // stage t & 3.  Entering a pair (t, t + 1) both tiles are staged and the loads of t + 2 / t + 3 sit in r0 / r1; inside the
     // pair tile t + 2 is stored behind the MFMAs of t and tile t + 3 behind those of t + 1 (their stages were last read a pair
@@ -2519,8 +2519,8 @@ pw_gemm_wgrad_square_kernel(GemmArgs g) {
     };
     if (T > 0) { fetch(r0); }
     if (T > 1) { fetch(r1); }
-    if (T > 0) { stage_tile(0, r0, T > 1); if (T > 2) fetch(r0); }
-    if (T > 1) { stage_tile(1, r1, T > 2); if (T > 3) fetch(r1); }
+    if (T > 0) { stage_tile(0, r0, T > 1); asm volatile("" : "+v"(rs)); if (T > 2) fetch(r0); }      // (the pin: see half())
+    if (T > 1) { stage_tile(1, r1, T > 2); asm volatile("" : "+v"(rs)); if (T > 3) fetch(r1); }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     auto half = [&](int t, Regs& r) __attribute__((always_inline)) {      // tile t is staged; r holds the loads of tile t + 2
       const u32x4* As = img + (t & 3) * SQ_STAGE + lh * SQ_P + wm * 64 + li;
@@ -2534,6 +2534,12 @@ pw_gemm_wgrad_square_kernel(GemmArgs g) {
       split_tile_mfma<1>(f2, acc2);
       if (t + 2 < T) {
         stage_tile(t + 2, r, t + 3 < T);       // (the fetch of tile t + 3, issued after this one's, may stay in flight)
+        // The row sum must be COMPLETE before the next fetch is issued.  Left alone, the compiler sinks the add chain of an
+        // fp32 dY below the (volatile, but register-only) load statements: the old value of r then lives across them, the new
+        // loads get other registers and a copy "new -> old registers" follows the load at once - it reads registers whose data
+        // has not arrived, and the data lands later in registers that hold addresses by then (NaNs, memory faults on long
+        // slabs: this schedule's first version; tools/async_load_check.py finds such copies in the ISA).
+        asm volatile("" : "+v"(rs));
         if (t + 4 < T) fetch(r);
       }
     };
@@ -2541,33 +2547,6 @@ pw_gemm_wgrad_square_kernel(GemmArgs g) {
       half(t, r0);
       if (t + 1 < T) half(t + 1, r1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-  } else {
-    if (T > 0) {
-      fetch(r0);
-      if (T > 1) { fetch(r1); wait_keep_one(r0); } else { USE_RN(r0, "0"); }
-      split_store(r0, 0, do_rowsum);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-    auto step = [&](int t, int cur, Regs& rload, Regs& rsplit) __attribute__((always_inline)) {
-      const u32x4* As = img + cur * SQ_STAGE + lh * SQ_P + wm * 64 + li;
-      const u32x4* Bs = img + cur * SQ_STAGE + 2 * SQ_P + lh * SQ_P + wn * 128 + li;
-      SplitFrags<1> f, f2;
-      split_tile_read<1, 0, 0>(As, Bs, f);
-      f2.a[0][0] = f.a[0][0]; f2.a[0][1] = f.a[0][1];
-      f2.b[0][0] = Bs[64]; f2.b[0][1] = Bs[96];
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < T) { fetch(rload); wait_keep_one(rsplit); }
-      else USE_RN(rsplit, "0");
-      split_tile_mfma<1>(f, acc);
-      split_tile_mfma<1>(f2, acc2);
-      split_store(rsplit, cur ^ 1, do_rowsum && t + 1 < T);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    for (int t = 0; t < T; t += 2) {
-      step(t, 0, r0, r1);
-      if (t + 1 < T) step(t + 1, 1, r1, r0);
     }
   }
 #undef USE_RN

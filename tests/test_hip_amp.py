@@ -501,7 +501,7 @@ def test_stencil_backward_reads_a_bf16_cotangent_as_stored(B, C, H, W, k, add):
                                          (1, 384, 1536, 32, 64), (2, 97, 896, 16, 32), (1, 256, 256, 4, 8), (5, 1024, 384, 8, 16)])
 def test_bf16_mixed_weight_gradient_tiles_and_operand_types(B, Co, Ci, H, W):
     """The bf16-mixed weight gradient over its three tiles (128 x 128, 256 x 128, 256 x 256 - the last with two k-tiles per
-    barrier for bf16 / bf16 operands) and the four operand-storage combinations, from one to ~90 k-tiles per slab: every
+    barrier) and the four operand-storage combinations, from one to ~90 k-tiles per slab: every
     entry against an fp64 evaluation of the bf16-rounded operands, the four combinations bit-identical to one another
     (same values in the same order through the same MFMAs), the bias gradient (row sums of dY) alongside."""
     from paradis_model_amd import ops
