@@ -199,7 +199,13 @@ class GraphedTrainStep:
         self.warmup_steps = max(1, warmup)
         self.graph = torch.cuda.CUDAGraph()
         step.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, RCCL's watchdog thread polls its work events (hipEventQuery) whenever it likes; under the
+        # default capture mode ("global") such a call from ANY thread while this one captures is an error that kills the
+        # process ("operation not permitted when stream is capturing": seen once in ~10 runs of the 1-rank nccl test).
+        # "thread_local" checks the capturing thread only.
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_loss = step(self.static_batch)
         # the graph's optimiser nodes copy the pinned pointer tables of the capture on every replay: keep a snapshot
         # (and the captured gradient tensors, which live in the graph's private pool) for eager_step()
