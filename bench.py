@@ -422,7 +422,10 @@ def main():
     ap.add_argument("--launch-only", action="store_true",
                     help="with --gpus N > 1 and no torchrun environment: print the launcher command line that would start "
                          "the N ranks (one JSON line) and exit; nothing touches a GPU")
+    ap.add_argument("--ddp-leg-child", action="store_true", help=argparse.SUPPRESS)    # (the ddp_overhead leg, in a process of its own)
     args = ap.parse_args()
+    if args.ddp_leg_child:
+        args.no_cpu_baseline = args.no_other_configs = args.no_kernel_events = args.no_extra_legs = True
 
     # `python bench.py --gpus N` called bare (no torchrun environment): start the N ranks OURSELVES, as fresh child
     # processes, before anything in this process touches the GPU (the parent never initialises HIP, so there is no
@@ -573,7 +576,8 @@ def main():
                    "warmup": max(args.warmup, 5),
                    "gemm_arithmetic": "NOT reference-width, reference AMP mode: torch.autocast(bfloat16) - pointwise GEMMs "
                                       "with operands rounded to bf16, one product, fp32 accumulate, bf16-rounded results; "
-                                      "advection / stencils / norms fp32; fp32 storage"}
+                                      "advection / stencils / norms fp32; tensors fp32 except, inside a block, the ones autocast makes bf16 between "
+                                      "a producer and its pointwise consumer (bf16 tensors since round 6; PARADIS_BF16_STORAGE=0: fp32 words)"}
             del astep
             try:
                 gstep = GraphedTrainStep(TrainStep(model, loss_fn, cfg, num_common=lay.num_common_features,
@@ -635,48 +639,75 @@ def main():
     # world_size = 1 nccl (RCCL) group - Reducer hooks, bucket copies and the RCCL all-reduce kernels of 240 MB of
     # gradients, no wire - eager and replayed from a captured graph.  (The 1 -> 8 curve needs a node; this leg is the
     # part of it a one-GPU box can measure.)
+    # Runs in a CHILD process: a process group brings RCCL's watchdog thread, whose failures (it once aborted the process
+    # when it polled an event during a graph capture) cannot be caught by a try block - and the headline line must never be
+    # lost over an extra leg.  The child rebuilds the same model and step and prints the leg's record as its one line.
+    def ddp_leg():
+        import socket
+        from paradis_model_amd.harness import GraphedTrainStep
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        d1 = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, force=True, capturable=True)
+        dstep = TrainStep(d1, loss_fn, cfg, num_common=lay.num_common_features,
+                          n_inputs=cfg.dataset.n_time_inputs, capturable=True)
+
+        def timed(fn, n):
+            for _ in range(3):
+                fn(batch)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn(batch)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t) / n
+        ms_plain = timed(step, args.steps)
+        ms_ddp = timed(dstep, args.steps)
+        rec = {"ms_per_step_plain": ms_plain, "ms_per_step_ddp_nccl_world1": ms_ddp,
+               "ddp_overhead_ms": ms_ddp - ms_plain, "bucket_cap_mb": args.bucket_mb,
+               "what": "TrainStep through DistributedDataParallel over a 1-rank nccl (RCCL) group vs the plain step, "
+                       "same process (a child of the bench), same box"}
+        try:
+            gd = GraphedTrainStep(dstep, batch)           # 11 eager DDP iterations, then the capture
+            rec["ms_per_step_ddp_graph_replay"] = timed(gd, args.steps)
+            t2 = time.perf_counter()
+            gd(batch)
+            rec["host_ms_one_ddp_replay"] = 1e3 * (time.perf_counter() - t2)
+            torch.cuda.synchronize()
+            del gd
+        except Exception as exc:
+            rec["ddp_graph_error"] = repr(exc)[:300]
+        del dstep, d1
+        torch.distributed.destroy_process_group()
+        return rec
+
+    if args.ddp_leg_child:
+        try:
+            rec = ddp_leg()
+        except Exception as exc:
+            rec = {"error": repr(exc)[:300]}
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        os.close(real_stdout)
+        return
     if (not args.no_extra_legs and not args.graph and world == 1 and not args.forward_only
             and args.optimizer == "adamw" and not torch.distributed.is_initialized()):
         try:
-            import socket
-            from paradis_model_amd.harness import GraphedTrainStep
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-            torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-            d1 = wrap_ddp(model, device_ids=[local], bucket_cap_mb=args.bucket_mb, force=True, capturable=True)
-            dstep = TrainStep(d1, loss_fn, cfg, num_common=lay.num_common_features,
-                              n_inputs=cfg.dataset.n_time_inputs, capturable=True)
-
-            def timed(fn, n):
-                for _ in range(3):
-                    fn(batch)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(n):
-                    fn(batch)
-                torch.cuda.synchronize()
-                return 1e3 * (time.perf_counter() - t) / n
-            ms_plain = timed(step, args.steps)
-            ms_ddp = timed(dstep, args.steps)
-            rec = {"ms_per_step_plain": ms_plain, "ms_per_step_ddp_nccl_world1": ms_ddp,
-                   "ddp_overhead_ms": ms_ddp - ms_plain, "bucket_cap_mb": args.bucket_mb,
-                   "what": "TrainStep through DistributedDataParallel over a 1-rank nccl (RCCL) group vs the plain step, "
-                           "same process, same box"}
-            try:
-                gd = GraphedTrainStep(dstep, batch)           # 11 eager DDP iterations, then the capture
-                rec["ms_per_step_ddp_graph_replay"] = timed(gd, args.steps)
-                t2 = time.perf_counter()
-                gd(batch)
-                rec["host_ms_one_ddp_replay"] = 1e3 * (time.perf_counter() - t2)
-                torch.cuda.synchronize()
-                del gd
-            except Exception as exc:
-                rec["ddp_graph_error"] = repr(exc)[:300]
-            legs["ddp_overhead"] = rec
-            del dstep, d1
-            torch.distributed.destroy_process_group()
+            import subprocess
+            torch.cuda.empty_cache()
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--ddp-leg-child", "--steps", str(args.steps), "--warmup", "2",
+                   "--gemm", args.gemm, "--bucket-mb", str(args.bucket_mb), "--workload", args.workload]
+            if args.batch:
+                cmd += ["--batch", str(args.batch)]
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                legs["ddp_overhead"] = json.loads(lines[-1])
+            else:
+                legs["ddp_overhead"] = {"error": f"child rc {r.returncode}: " + r.stderr[-300:]}
         except Exception as exc:
             legs["ddp_overhead"] = {"error": repr(exc)[:300]}
 
@@ -694,7 +725,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "ddp_efficiency_vs": None,     # never reported here: the driver divides by its own N = 1 run
-        "dtype": ("bf16-mixed (NOT reference-width: the reference's AMP mode; one-product bf16 GEMMs, fp32 storage)" if args.amp
+        "dtype": ("bf16-mixed (NOT reference-width: the reference's AMP mode; one-product bf16 GEMMs; module inputs / outputs, residual stream, parameters fp32)" if args.amp
                   else "f32" if args.gemm != "f16x2" else "f32 storage, f16x2 block-exponent GEMM emulation"),
         "data": "synthetic",
         "config": {"workload": args.workload, "grid": f"{nlat}x{nlon}", "rollout_steps": S,
