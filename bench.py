@@ -707,7 +707,9 @@ def main():
             if r.returncode == 0 and lines:
                 legs["ddp_overhead"] = json.loads(lines[-1])
             else:
-                legs["ddp_overhead"] = {"error": f"child rc {r.returncode}: " + r.stderr[-300:]}
+                err = r.stderr
+                at = max(err.find("terminate called"), err.find("Traceback"), 0)        # (the message, not the frames below it)
+                legs["ddp_overhead"] = {"error": f"child rc {r.returncode}: " + (err[at:at + 700] if at else err[-300:])}
         except Exception as exc:
             legs["ddp_overhead"] = {"error": repr(exc)[:300]}
 
