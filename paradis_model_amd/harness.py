@@ -204,7 +204,13 @@ class GraphedTrainStep:
         # process ("operation not permitted when stream is capturing": seen once in ~10 runs of the 1-rank nccl test).
         # "thread_local" checks the capturing thread only.
         import torch.distributed as dist
-        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with_pg = dist.is_available() and dist.is_initialized()
+        mode = "thread_local" if with_pg else "global"
+        if with_pg:
+            # ... and give the watchdog two of its 100 ms rounds to retire the work items of the eager warm-up iterations
+            # (all complete: the device is synchronised), so that it holds no event to poll while the capture runs
+            import time as _time
+            _time.sleep(0.25)
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_loss = step(self.static_batch)
         # the graph's optimiser nodes copy the pinned pointer tables of the capture on every replay: keep a snapshot
