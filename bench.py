@@ -506,7 +506,7 @@ def main():
                                   batch[3][:, :1].permute(0, 1, 4, 2, 3))
 
         def step(_b, _m=model, _x=mi):
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(args.amp)):
                 return _m(_x).mean()
 
     for _ in range(args.warmup):
